@@ -1,0 +1,115 @@
+"""ctypes mirror of include/dellyhip.h (the C-ABI of the MI355X split-read
+refinement path).  Pure declarations: the structs are shared by the product
+bindings (delly_amd.refine) and by the test-only oracle bindings
+(oracle/pyoracle.py), so parity tests compare identical record layouts.
+
+Reference types mirrored: the duck-typed TConfig fields (SURVEY.md 8b,
+src/delly.h:49-82), torali::StructuralVariantRecord (src/tags.h:93-130) and
+torali::AlignDescriptor (src/split.h:15-25).
+"""
+import ctypes as C
+
+OK = 0
+E_NODEVICE = -1
+E_ARG = -2
+E_RUNTIME = -3
+E_LIMIT = -4
+E_NOMEM = -5
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("match", C.c_int32),
+        ("mismatch", C.c_int32),
+        ("gap_open", C.c_int32),
+        ("gap_extend", C.c_int32),
+        ("min_clique_size", C.c_int32),
+        ("minimum_flank_size", C.c_int32),
+        ("indelsize", C.c_int32),
+        ("min_cons_window", C.c_int32),
+        ("flank_quality", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
+def params_sr():
+    """`delly sr` defaults: src/delly.h:221,240,393-398."""
+    return Params(5, -4, -10, -1, 2, 13, 1000, 100, 0.95, 0)
+
+
+def params_lr():
+    """`delly lr` defaults: src/tegua.h:230-241 (aliscore unused on that path)."""
+    return Params(5, -4, -10, -1, 3, 100, 10000, 1000, 0.9, 0)
+
+
+class Junction(C.Structure):
+    _fields_ = [
+        ("svid", C.c_int32),
+        ("svt", C.c_int32),
+        ("chr", C.c_int32),
+        ("chr2", C.c_int32),
+        ("sv_start", C.c_int32),
+        ("sv_end", C.c_int32),
+        ("ins_len", C.c_int32),
+        ("n_seq", C.c_int32),
+        ("seq_first", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("svid", C.c_int32),
+        ("ok", C.c_int32),
+        ("sv_start", C.c_int32),
+        ("sv_end", C.c_int32),
+        ("ci_wiggle", C.c_int32),
+        ("ins_len", C.c_int32),
+        ("cons_bp", C.c_int32),
+        ("hom_len", C.c_int32),
+        ("sr_support", C.c_int32),
+        ("sr_align_quality", C.c_float),
+        ("matches", C.c_int32),
+        ("mismatches", C.c_int32),
+        ("c_start", C.c_int32),
+        ("c_end", C.c_int32),
+        ("r_start", C.c_int32),
+        ("r_end", C.c_int32),
+        ("hom_left", C.c_int32),
+        ("hom_right", C.c_int32),
+        ("score_unsplit", C.c_int32),
+        ("score_best", C.c_int32),
+        ("cons_left", C.c_int32),
+        ("ref_left", C.c_int32),
+        ("ref_right", C.c_int32),
+        ("cons_len", C.c_int32),
+        ("ref_len", C.c_int32),
+        ("cons_off", C.c_uint64),
+        ("allele_off", C.c_uint64),
+        ("aln_off", C.c_uint64),
+        ("allele_len", C.c_int32),
+        ("aln_len", C.c_int32),
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# numpy structured dtypes with the same layout (for vectorised comparisons)
+def _np_dtype(struct):
+    import numpy as np
+
+    m = {C.c_int32: "<i4", C.c_uint64: "<u8", C.c_float: "<f4"}
+    names, formats, offsets = [], [], []
+    for name, typ in struct._fields_:
+        names.append(name)
+        formats.append(m[typ])
+        offsets.append(getattr(struct, name).offset)
+    return np.dtype({"names": names, "formats": formats, "offsets": offsets,
+                     "itemsize": C.sizeof(struct)})
+
+
+def junction_dtype():
+    return _np_dtype(Junction)
+
+
+def result_dtype():
+    return _np_dtype(Result)

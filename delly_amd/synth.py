@@ -1,0 +1,191 @@
+"""Synthetic junction batches shared by the parity tests, the
+oracle and bench.py.  Counter-based: junction j of a batch depends only on
+(seed, j), never on the batch size or on the rank that generates it, so
+N-GPU shards of one logical batch are reproducible.
+
+A batch mimics what the loop of src/shortpe.h:96-201 holds per chromosome:
+one chromosome string (here: the per-junction 4 kb windows concatenated), the
+SV candidates with approximate coordinates, and either their consensus
+(unit U: alignConsensus only) or their split reads in host iteration order
+(unit U_full: msa + alignConsensus).
+"""
+import numpy as np
+
+from . import abi
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.arange(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[a] = b
+
+WINDOW = 4000  # bases of private genome per junction
+
+
+def revcomp(a):
+    return _COMP[a[::-1]]
+
+
+def _rng(seed, j):
+    return np.random.Generator(np.random.Philox(key=[seed, 0x5eed], counter=[j, 0, 0, 0]))
+
+
+def _mutate(rng, seq, rate):
+    seq = seq.copy()
+    if rate > 0:
+        hit = np.nonzero(rng.random(seq.size) < rate)[0]
+        for i in hit:
+            # substitute with a different base
+            cur = seq[i]
+            cand = ACGT[ACGT != cur]
+            seq[i] = cand[rng.integers(0, cand.size)]
+    return seq
+
+
+class Batch:
+    """Host-side junction batch in the layout of include/dellyhip.h."""
+
+    def __init__(self, chroms, junctions, seq_blob, seq_off, with_msa, truth):
+        self.chroms = chroms            # list of np.uint8 arrays
+        self.junctions = junctions      # structured array, abi.junction_dtype()
+        self.seq_blob = seq_blob        # np.uint8
+        self.seq_off = seq_off          # np.uint64, n_seq + 1
+        self.with_msa = with_msa
+        self.truth = truth              # list of dicts (generator ground truth)
+
+    @property
+    def n(self):
+        return int(self.junctions.shape[0])
+
+    @property
+    def n_seq(self):
+        return int(self.seq_off.shape[0] - 1)
+
+    def seqs_of(self, i):
+        j = self.junctions[i]
+        first = int(j["seq_first"])
+        return [bytes(self.seq_blob[int(self.seq_off[first + k]):int(self.seq_off[first + k + 1])])
+                for k in range(int(j["n_seq"]))]
+
+
+def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_flank=75,
+               sub_rate=0.005, del_len=700):
+    """Builds junctions first..first+n-1.
+
+    mode "c2"   : BASELINE config 2 -- DEL, 150 bp consensus (or reads), ref
+                  window 150+700+150 = 1000, plus 1 % each of N-run,
+                  micro-homology and pure-reference (no split) junctions.
+    mode "mixed": parity coverage -- DEL with l in 300..700 and 5000
+                  (two-window branch src/split.h:117), DUP, INV 3to3/5to5 and
+                  the four BND orientations across two chromosomes, varying
+                  flank lengths.
+    n_reads 0   : unit U (one consensus per junction); >0: unit U_full (that
+                  many distinct split reads per junction, host order = as generated).
+    """
+    two_chr = mode == "mixed"
+    chrA = np.empty(n * WINDOW, dtype=np.uint8)
+    chrB = np.empty(n * WINDOW if two_chr else 0, dtype=np.uint8)
+    junc = np.zeros(n, dtype=abi.junction_dtype())
+    seqs = []
+    truth = []
+    for k in range(n):
+        j = first + k
+        rng = _rng(seed, j)
+        G = ACGT[rng.integers(0, 4, WINDOW)]
+        base = k * WINDOW
+        svt = 2
+        s = 1500
+        ell = del_len
+        flankL = flankR = cons_flank
+        kind = "del"
+        H = None
+        if mode == "mixed":
+            H = ACGT[rng.integers(0, 4, WINDOW)]
+            sel = j % 12
+            flankL = int(rng.integers(40, 140))
+            flankR = int(rng.integers(40, 140))
+            if sel in (0, 1, 2, 3):
+                ell = int(rng.integers(300, 701))
+            elif sel == 4:
+                ell = 1800  # > indelsize: two-window branch (kept inside the 4 kb window)
+            elif sel == 5:
+                kind, svt, ell = "dup", 3, int(rng.integers(200, 900))
+            elif sel == 6:
+                kind, svt, ell = "inv0", 0, int(rng.integers(400, 1500))
+            elif sel == 7:
+                kind, svt, ell = "inv1", 1, int(rng.integers(400, 1500))
+            else:
+                kind, svt = "bnd%d" % (sel - 8), 5 + (sel - 8)
+        else:
+            v = j % 100
+            if v == 1:
+                kind = "noref"       # pure reference: no split -> alignConsensus false
+            elif v == 2:
+                kind = "nrun"
+            elif v == 3:
+                kind = "hom"
+        e = s + ell
+        if kind == "nrun":
+            G[s - 60:s - 50] = ord("N")
+        if kind == "hom":
+            h = int(rng.integers(2, 11))
+            G[e:e + h] = G[s:s + h]
+        # ALT haplotype around the junction (left part ‖ right part), 150+150
+        L = 150
+        if kind in ("del", "nrun", "hom"):
+            left, right = G[s - L:s], G[e:e + L]
+        elif kind == "noref":
+            left, right = G[s - L:s], G[s:s + L]
+        elif kind == "dup":
+            left, right = G[e - L:e], G[s:s + L]
+        elif kind == "inv0":
+            left, right = G[s - L:s], revcomp(G[e - L:e])
+        elif kind == "inv1":
+            left, right = revcomp(G[s:s + L]), G[e:e + L]
+        elif kind == "bnd0":
+            left, right = G[s - L:s], revcomp(H[e - L:e])
+        elif kind == "bnd1":
+            left, right = revcomp(G[s:s + L]), H[e:e + L]
+        elif kind == "bnd2":
+            left, right = G[s - L:s], H[e:e + L]
+        elif kind == "bnd3":
+            left, right = H[e - L:e], G[s:s + L]
+        else:
+            raise ValueError(kind)
+        alt = np.concatenate([left, right])
+        chrA[base:base + WINDOW] = G
+        if two_chr:
+            chrB[base:base + WINDOW] = H
+        jit_s, jit_e = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+        rec = junc[k]
+        rec["svid"] = j
+        rec["svt"] = svt
+        rec["chr"] = 0
+        rec["chr2"] = 1 if kind.startswith("bnd") else 0
+        rec["sv_start"] = base + s + jit_s
+        rec["sv_end"] = base + e + jit_e
+        rec["ins_len"] = 0
+        rec["seq_first"] = len(seqs)
+        if n_reads <= 0:
+            cons = _mutate(rng, alt[L - flankL:L + flankR], sub_rate)
+            seqs.append(cons)
+            rec["n_seq"] = 1
+        else:
+            seen = set()
+            lo, hi = 25, 2 * L - read_len - 25
+            tries = 0
+            while len(seen) < n_reads and tries < 50 * n_reads:
+                tries += 1
+                o = int(rng.integers(lo, hi + 1))
+                r = _mutate(rng, alt[o:o + read_len], sub_rate)
+                key = r.tobytes()
+                if key in seen:
+                    continue
+                seen.add(key)
+                seqs.append(r)
+            rec["n_seq"] = len(seen)
+        truth.append(dict(kind=kind, svt=svt, start=base + s, end=base + e, flankL=flankL, flankR=flankR))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs], dtype=np.uint64)
+    blob = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
+    chroms = [chrA, chrB] if two_chr else [chrA]
+    return Batch(chroms, junc, blob, off, n_reads > 0, truth)

@@ -1,0 +1,200 @@
+/*
+ * dellyhip.h -- C-ABI of the MI355X-native split-read refinement path.
+ *
+ * Drop-in boundary for the one data-parallel hot path of dellytools/delly
+ * (v2.5.1): per-junction consensus building + consensus-vs-reference split
+ * alignment.  The reference has no FFI layer for this path (C++ header
+ * templates in namespace torali); the functions below are what a maintainer
+ * binds at the loop bodies of
+ *     src/shortpe.h:175-201 / :243-268      (sr: msa() + alignConsensus())
+ *     src/assemble.h:833-872                 (lr: msaEdlib()/alignConsensus())
+ * Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, caller owns every buffer, no callee allocation
+ *     crosses the ABI (matches std::string& out-parameters of the reference).
+ *   - return value: 0 = ok, <0 = infrastructure error (DELLYHIP_E_*).  The
+ *     per-junction boolean of alignConsensus()/longNeedle() is in result.ok.
+ *     There is NO CPU fallback inside the library: if no gfx950 device or the
+ *     code object is unusable, calls fail with DELLYHIP_E_NODEVICE.
+ *   - coordinates are 0-based genomic offsets exactly as in
+ *     torali::StructuralVariantRecord (src/tags.h:93-130).
+ */
+#ifndef DELLYHIP_H
+#define DELLYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DELLYHIP_VERSION 1
+
+#define DELLYHIP_OK 0
+#define DELLYHIP_E_NODEVICE (-1)  /* no usable gfx950 device / kernel image      */
+#define DELLYHIP_E_ARG (-2)       /* malformed arguments                          */
+#define DELLYHIP_E_RUNTIME (-3)   /* HIP runtime error (message: dellyhip_last_error) */
+#define DELLYHIP_E_LIMIT (-4)     /* a junction exceeds a compiled kernel limit   */
+#define DELLYHIP_E_NOMEM (-5)
+
+/* Duck-typed TConfig fields read by the path:
+ * aliscore (src/delly.h:393), minCliqueSize, flankQuality (:394),
+ * minimumFlankSize (:397), indelsize (:398), minConsWindow. */
+typedef struct dellyhip_params {
+  int32_t match;              /* c.aliscore.match     5  */
+  int32_t mismatch;           /* c.aliscore.mismatch -4  */
+  int32_t gap_open;           /* c.aliscore.go      -10  */
+  int32_t gap_extend;         /* c.aliscore.ge       -1  */
+  int32_t min_clique_size;    /* c.minCliqueSize (sr default 2, -z) */
+  int32_t minimum_flank_size; /* c.minimumFlankSize  13 sr / 100 lr */
+  int32_t indelsize;          /* c.indelsize       1000 sr / 10000 lr */
+  int32_t min_cons_window;    /* c.minConsWindow    100 sr / 1000 lr */
+  float flank_quality;        /* c.flankQuality    0.95 sr / 0.9 lr */
+  int32_t reserved;
+} dellyhip_params;
+
+/* One SV candidate ("junction").  Mirrors the fields of
+ * torali::StructuralVariantRecord that the path reads (src/tags.h:93-130):
+ * chr, svStart, chr2, svEnd, svt, insLen (+ consensus when given). */
+typedef struct dellyhip_junction {
+  int32_t svid;      /* caller tag, echoed in the result                      */
+  int32_t svt;       /* 0 INV3to3, 1 INV5to5, 2 DEL, 3 DUP, 4 INS, 5-8 BND    */
+  int32_t chr;       /* index into the uploaded chromosome table              */
+  int32_t chr2;
+  int32_t sv_start;  /* sv.svStart */
+  int32_t sv_end;    /* sv.svEnd   */
+  int32_t ins_len;   /* sv.insLen (svt 4 only)                                 */
+  int32_t n_seq;     /* #reads (refine_batch) or 1 (align_consensus_batch)    */
+  uint64_t seq_first;/* index of this junction's first entry in seq_off[]     */
+} dellyhip_junction;
+
+/* What alignConsensus() writes into the StructuralVariantRecord
+ * (src/split.h:626-637) plus msa()'s return value and consensus. */
+typedef struct dellyhip_result {
+  int32_t svid;
+  int32_t ok;          /* 1: alignConsensus() returned true; 0: false          */
+  int32_t sv_start;    /* sv.svStart = finalGapStart                            */
+  int32_t sv_end;      /* sv.svEnd   = finalGapEnd                              */
+  int32_t ci_wiggle;   /* ciposhigh = ciendhigh = -ciposlow = -ciendlow         */
+  int32_t ins_len;     /* sv.insLen = cEnd - cStart - 1                         */
+  int32_t cons_bp;     /* sv.consBp = cStart                                    */
+  int32_t hom_len;     /* sv.homLen                                             */
+  int32_t sr_support;  /* msa() return value = rows of the MSA                  */
+  float sr_align_quality; /* ad.percId (float32 division, src/split.h:315)      */
+  int32_t matches;     /* ma, mm of _percentIdentity (so the host can recheck)  */
+  int32_t mismatches;
+  int32_t c_start, c_end, r_start, r_end; /* AlignDescriptor (src/split.h:15)   */
+  int32_t hom_left, hom_right;
+  /* longNeedle internals (parity diagnostics; src/needle.h:104-123) */
+  int32_t score_unsplit;  /* mat[m][n]            */
+  int32_t score_best;     /* bestScore            */
+  int32_t cons_left, ref_left, ref_right;
+  int32_t cons_len;       /* |consensus| used for the split alignment          */
+  int32_t ref_len;        /* |svRefStr|                                         */
+  /* byte ranges in out_blob */
+  uint64_t cons_off;      /* consensus (sv.consensus), cons_len bytes            */
+  uint64_t allele_off;    /* sv.alleles = "REF,ALT" (src/split.h:606-624)        */
+  uint64_t aln_off;       /* 2-row gapped alignment, row-major 2 x aln_len       */
+  int32_t allele_len;     /* 0 when that block is not executed                   */
+  int32_t aln_len;        /* columns of the alignment (0 if not requested)       */
+  int32_t status;         /* 0, or DELLYHIP_E_LIMIT for this junction            */
+  int32_t reserved;
+} dellyhip_result;
+
+typedef struct dellyhip_ctx dellyhip_ctx;
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Creates a context bound to HIP device `device` (one ctx per GPU / process
+ * rank).  Replaces the ThreadPool(c.maxThreads) of src/shortpe.h:80. */
+int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** out);
+void dellyhip_destroy(dellyhip_ctx* ctx);
+const char* dellyhip_last_error(void);
+/* Default parameters of `delly sr` (src/delly.h:393-398) and `delly lr`
+ * (src/tegua.h:237-241). */
+void dellyhip_default_params_sr(dellyhip_params* p);
+void dellyhip_default_params_lr(dellyhip_params* p);
+
+/* Keeps chromosome `chr` resident in HBM.  Replaces the per-chromosome
+ * faidx_fetch_seq() buffer `seq` that src/shortpe.h:88 hands to
+ * alignConsensus(c, hdr, seq, sndSeq, sv), and hdr->target_len[chr]
+ * (src/tags.h:156-169).  A whole genome (3.1 GB) fits many times in 288 GB. */
+int dellyhip_set_chromosome(dellyhip_ctx* ctx, int32_t chr, const char* seq, int64_t len);
+
+/* ---- batched hot path -------------------------------------------------- */
+
+/* msa(c, seqStore[svid], sv.consensus) + alignConsensus(c, hdr, seq, sndSeq, sv)
+ * for every junction: the loop body of src/shortpe.h:183-197 / :248-266.
+ *   seq_blob / seq_off : reads of all junctions, concatenated, in the HOST's
+ *                        std::unordered_set iteration order;
+ *                        read i spans seq_blob[seq_off[i], seq_off[i+1]).
+ *   out_blob           : receives consensus (+ alignment rows if want_alignment)
+ *   out_blob_cap/len   : capacity in, bytes used out.
+ */
+int dellyhip_refine_batch(dellyhip_ctx* ctx, int32_t n_junctions,
+                          const dellyhip_junction* junctions, const char* seq_blob,
+                          const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results,
+                          char* out_blob, uint64_t out_blob_cap, uint64_t* out_blob_len,
+                          int want_alignment);
+
+/* alignConsensus(c, hdr, seq, sndSeq, sv, realign=false) only
+ * (src/split.h:644-672), consensus supplied by the caller: each junction has
+ * n_seq == 1 and its sequence is sv.consensus.  This is BASELINE.json's unit U. */
+int dellyhip_align_consensus_batch(dellyhip_ctx* ctx, int32_t n_junctions,
+                                   const dellyhip_junction* junctions, const char* seq_blob,
+                                   const uint64_t* seq_off, uint64_t n_seq,
+                                   dellyhip_result* results, char* out_blob,
+                                   uint64_t out_blob_cap, uint64_t* out_blob_len,
+                                   int want_alignment);
+
+/* ---- device-resident batches (bench / pipelined callers) ---------------- */
+
+/* Uploads a batch once; run_resident() then executes the same work as
+ * dellyhip_align_consensus_batch / dellyhip_refine_batch with inputs already in
+ * HBM and results left in HBM; fetch_results() copies them back. `stream` is a
+ * hipStream_t passed as void* (0 = the context's own stream). */
+typedef struct dellyhip_batch dellyhip_batch;
+int dellyhip_batch_upload(dellyhip_ctx* ctx, int32_t n_junctions,
+                          const dellyhip_junction* junctions, const char* seq_blob,
+                          const uint64_t* seq_off, uint64_t n_seq, int with_msa,
+                          dellyhip_batch** out);
+int dellyhip_batch_run(dellyhip_ctx* ctx, dellyhip_batch* b, void* stream);
+int dellyhip_batch_sync(dellyhip_ctx* ctx, dellyhip_batch* b);
+int dellyhip_batch_fetch(dellyhip_ctx* ctx, dellyhip_batch* b, dellyhip_result* results,
+                         char* out_blob, uint64_t out_blob_cap, uint64_t* out_blob_len);
+void dellyhip_batch_free(dellyhip_ctx* ctx, dellyhip_batch* b);
+/* Average duration in milliseconds of the dominant kernel (split alignment)
+ * over the launches since the last call, measured with hipEvents on the
+ * launch stream; also returns the launch count. */
+int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_split,
+                             double* ms_msa, int32_t* launches);
+
+/* ---- single-item wrappers (parity tests, assemble.h / asmode.h call sites) */
+
+/* bool longNeedle(s1, s2, align, AlignConfig<true,false>, DnaScore(1,-1,-1,-1))
+ * src/needle.h:45-222 as called from src/split.h:555.  align_rows receives the
+ * 2 x *aln_len gapped alignment (row-major, row stride aln_cap). */
+int dellyhip_long_needle(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
+                         char* align_rows, int32_t aln_cap, int32_t* aln_len, int32_t* found);
+
+/* int lcs(s1, s2)  src/msa.h:10-30 */
+int dellyhip_lcs(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
+                 int32_t* out);
+
+/* int gotoh(a1, a2, align, AlignConfig<true,true>, c.aliscore) src/gotoh.h:71-174
+ * as called from palign, src/msa.h:106-107.  a1 is r1 x m, a2 is r2 x n
+ * (row-major); align_out receives (r1+r2) x *len (row stride cap). */
+int dellyhip_gotoh(dellyhip_ctx* ctx, const char* a1, int32_t r1, int32_t m, const char* a2,
+                   int32_t r2, int32_t n, char* align_out, int32_t cap, int32_t* len,
+                   int32_t* score);
+
+/* int msa(c, sps, cs)  src/msa.h:185-239: returns rows in *rows, consensus in cs. */
+int dellyhip_msa(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,
+                 char* cs, int32_t cs_cap, int32_t* cs_len, int32_t* rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELLYHIP_H */

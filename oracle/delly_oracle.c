@@ -1,0 +1,1110 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- see delly_oracle.h.  CPU restatement (plain C)
+ * of the reference's split-read refinement path; each function cites the
+ * reference file:line it follows (paths relative to /root/reference).
+ * Parity pinned against oracle/_ref (the reference's own headers).
+ */
+#define _GNU_SOURCE
+#include "delly_oracle.h"
+
+#include <ctype.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* small helpers                                                             */
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+typedef struct {
+  char* d; /* row-major rows x cols */
+  int rows, cols;
+} amat;
+
+static amat amat_new(int rows, int cols) {
+  amat a;
+  a.rows = rows;
+  a.cols = cols;
+  a.d = (char*)calloc((size_t)rows * (size_t)(cols > 0 ? cols : 1) + 1, 1);
+  return a;
+}
+static void amat_free(amat* a) {
+  free(a->d);
+  a->d = NULL;
+}
+#define AT(a, i, j) ((a).d[(size_t)(i) * (size_t)(a).cols + (size_t)(j)])
+
+/* src/util.h:549-563 reverseComplement: upper-cased reverse, complemented; a
+ * letter outside ACGTN leaves the ORIGINAL (un-reversed) byte at index i. */
+void dor_reverse_complement(char* s, int n) {
+  char* up = (char*)malloc((size_t)n + 1);
+  for (int i = 0; i < n; ++i) up[i] = (char)toupper((unsigned char)s[n - 1 - i]);
+  for (int i = 0; i < n; ++i) {
+    switch (up[i]) {
+      case 'A': s[i] = 'T'; break;
+      case 'C': s[i] = 'G'; break;
+      case 'G': s[i] = 'C'; break;
+      case 'T': s[i] = 'A'; break;
+      case 'N': s[i] = 'N'; break;
+      default: break;
+    }
+  }
+  free(up);
+}
+
+/* ------------------------------------------------------------------------ */
+/* K1: lcs  src/msa.h:10-30                                                   */
+
+int dor_lcs(const char* s1, int m, const char* s2, int n) {
+  int32_t* onecol = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+  int32_t prevdiag = 0;
+  for (int i = 0; i <= m; ++i) {
+    for (int j = 0; j <= n; ++j) {
+      if (i == 0 || j == 0) {
+        onecol[j] = 0;
+        prevdiag = 0;
+      } else {
+        int32_t prevprevdiag = prevdiag;
+        prevdiag = onecol[j];
+        if (s1[i - 1] == s2[j - 1]) onecol[j] = prevprevdiag + 1;
+        else onecol[j] = (onecol[j] > onecol[j - 1]) ? onecol[j] : onecol[j - 1];
+      }
+    }
+  }
+  int r = onecol[n];
+  free(onecol);
+  return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* K4: longestHomology  src/needle.h:13-42 (band k=|threshold|)               */
+
+int dor_longest_homology(const char* s1, int m, const char* s2, int n, int thr) {
+  size_t W = (size_t)n + 3;
+  int32_t* mat = (int32_t*)calloc(((size_t)m + 3) * W, sizeof(int32_t));
+  int k = abs(thr);
+  mat[0] = 0;
+  for (int col = 1; col <= k; ++col) mat[col] = mat[col - 1] - 1;
+  for (int row = 1; row <= k; ++row) mat[(size_t)row * W] = mat[(size_t)(row - 1) * W] - 1;
+  int ret = 0;
+  int done = 0;
+  for (int row = 1; row <= m && !done; ++row) {
+    int bestCol = thr - 1;
+    for (int h = -k; h <= k; ++h) {
+      int col = row + h;
+      if (col >= 1 && col <= n) {
+        int32_t* c = &mat[(size_t)row * W + col];
+        *c = mat[(size_t)(row - 1) * W + col - 1] + (s1[row - 1] == s2[col - 1] ? 0 : -1);
+        if ((row - 1 - col >= -k) && (row - 1 - col <= k)) *c = imax(*c, mat[(size_t)(row - 1) * W + col] - 1);
+        if ((row - col + 1 >= -k) && (row - col + 1 <= k)) *c = imax(*c, mat[(size_t)row * W + col - 1] - 1);
+        if (*c > bestCol) bestCol = *c;
+      }
+    }
+    if (bestCol < thr) {
+      ret = row - 1;
+      done = 1;
+    }
+  }
+  free(mat);
+  return ret;
+}
+
+/* ------------------------------------------------------------------------ */
+/* K3: longNeedle  src/needle.h:45-222 with AlignConfig<true,false> and       */
+/* DnaScore(1,-1,-1,-1) as fixed by src/split.h:543-555.                      */
+
+static inline int hgap(int row, int m) { return (row == 0 || row == m) ? 0 : -1; } /* align.h:67-73 */
+
+static void fill_needle(const char* a, int m, const char* b, int n, int32_t* mat) {
+  size_t W = (size_t)n + 1;
+  mat[0] = 0;
+  for (int col = 1; col <= n; ++col) mat[col] = mat[col - 1] + hgap(0, m);
+  for (int row = 1; row <= m; ++row) mat[(size_t)row * W] = mat[(size_t)(row - 1) * W] + (-1);
+  for (int row = 1; row <= m; ++row) {
+    int hg = hgap(row, m);
+    const int32_t* up = &mat[(size_t)(row - 1) * W];
+    int32_t* cur = &mat[(size_t)row * W];
+    for (int col = 1; col <= n; ++col) {
+      int d = up[col - 1] + (a[row - 1] == b[col - 1] ? 1 : -1);
+      int v = up[col] + (-1);
+      int h = cur[col - 1] + hg;
+      cur[col] = imax(imax(d, v), h);
+    }
+  }
+}
+
+/* traceback of src/needle.h:159-171 / :180-192; returns trace length, ops in
+ * push order (from the end of the path backwards) */
+static int trace_needle(const int32_t* mat, int m, int n, int rr, int cc, char* trace) {
+  size_t W = (size_t)n + 1;
+  int t = 0;
+  while (rr > 0 || cc > 0) {
+    if (rr > 0 && mat[(size_t)rr * W + cc] == mat[(size_t)(rr - 1) * W + cc] + (-1)) {
+      --rr;
+      trace[t++] = 'v';
+    } else if (cc > 0 && mat[(size_t)rr * W + cc] == mat[(size_t)rr * W + cc - 1] + hgap(rr, m)) {
+      --cc;
+      trace[t++] = 'h';
+    } else {
+      --rr;
+      --cc;
+      trace[t++] = 's';
+    }
+  }
+  return t;
+}
+
+/* src/align.h:173-200 _createAlignment for two strings */
+static amat make_alignment(const char* trace, int tlen, const char* s1, const char* s2) {
+  amat al = amat_new(2, tlen);
+  int row = 0, col = 0, ai = 0;
+  for (int t = tlen - 1; t >= 0; --t, ++ai) {
+    if (trace[t] == 's') {
+      AT(al, 0, ai) = s1[row++];
+      AT(al, 1, ai) = s2[col++];
+    } else if (trace[t] == 'h') {
+      AT(al, 0, ai) = '-';
+      AT(al, 1, ai) = s2[col++];
+    } else {
+      AT(al, 0, ai) = s1[row++];
+      AT(al, 1, ai) = '-';
+    }
+  }
+  return al;
+}
+
+/* returns 1 found, 0 not found; *out receives the 2 x len alignment */
+static int long_needle_core(const char* s1, int m, const char* s2, int n, amat* out, int* diag) {
+  size_t W = (size_t)n + 1;
+  size_t cells = ((size_t)m + 1) * W;
+  int32_t* mat = (int32_t*)malloc(cells * sizeof(int32_t));
+  int32_t* rev = (int32_t*)malloc(cells * sizeof(int32_t));
+  char* r1 = (char*)malloc((size_t)m + 1);
+  char* r2 = (char*)malloc((size_t)n + 1);
+  memcpy(r1, s1, (size_t)m);
+  memcpy(r2, s2, (size_t)n);
+  dor_reverse_complement(r1, m);
+  dor_reverse_complement(r2, n);
+  fill_needle(s1, m, s2, n, mat);
+  fill_needle(r1, m, r2, n, rev);
+  int found = 0;
+  if (diag) {
+    diag[0] = mat[cells - 1];
+    diag[1] = diag[2] = diag[3] = diag[4] = -1;
+  }
+  out->d = NULL;
+  out->rows = 2;
+  out->cols = 0;
+  if (mat[cells - 1] == rev[cells - 1]) {
+    /* best join, needle.h:87-123 */
+    int32_t* bm = (int32_t*)malloc(cells * sizeof(int32_t));
+    int32_t* br = (int32_t*)malloc(cells * sizeof(int32_t));
+    for (int row = 0; row <= m; ++row) {
+      bm[(size_t)row * W] = mat[(size_t)row * W];
+      br[(size_t)row * W] = rev[(size_t)row * W];
+      for (int col = 1; col <= n; ++col) {
+        size_t i = (size_t)row * W + col;
+        bm[i] = (mat[i] > bm[i - 1]) ? mat[i] : bm[i - 1];
+        br[i] = (rev[i] > br[i - 1]) ? rev[i] : br[i - 1];
+      }
+    }
+    int best = mat[cells - 1];
+    int consLeft = 0, refLeft = 0;
+    for (int row = 0; row <= m; ++row)
+      for (int col = 0; col <= n; ++col) {
+        int v = bm[(size_t)row * W + col] + br[(size_t)(m - row) * W + (n - col)];
+        if (v > best) {
+          best = v;
+          consLeft = row;
+          refLeft = col;
+        }
+      }
+    int consRight = m - consLeft;
+    int refRight = 0;
+    for (int right = 0; right <= n - refLeft; ++right)
+      if (mat[(size_t)consLeft * W + refLeft] + rev[(size_t)consRight * W + right] == best) refRight = right;
+    free(bm);
+    free(br);
+    if (diag) {
+      diag[1] = best;
+      diag[2] = consLeft;
+      diag[3] = refLeft;
+      diag[4] = refRight;
+    }
+    if (best != mat[cells - 1]) {
+      char* tr = (char*)malloc((size_t)m + n + 2);
+      int tl = trace_needle(mat, m, n, consLeft, refLeft, tr);
+      amat fwd = make_alignment(tr, tl, s1, s2);
+      int rl = trace_needle(rev, m, n, consRight, refRight, tr);
+      amat rvs = make_alignment(tr, rl, r1, r2);
+      free(tr);
+      /* concat, needle.h:196-219 */
+      int gapref = (n - refRight) - refLeft;
+      int alilen = fwd.cols + rvs.cols + gapref;
+      amat al = amat_new(2, alilen);
+      int jEnd = rvs.cols;
+      for (int i = 0; i < 2; ++i) {
+        int ac = 0;
+        for (; ac < fwd.cols; ++ac) AT(al, i, ac) = AT(fwd, i, ac);
+        for (int j = refLeft; j < n - refRight; ++j, ++ac) AT(al, i, ac) = (i == 0) ? '-' : s2[j];
+        for (int j = 0; j < rvs.cols; ++j, ++ac) {
+          switch (AT(rvs, i, jEnd - j - 1)) {
+            case 'A': AT(al, i, ac) = 'T'; break;
+            case 'C': AT(al, i, ac) = 'G'; break;
+            case 'G': AT(al, i, ac) = 'C'; break;
+            case 'T': AT(al, i, ac) = 'A'; break;
+            case 'N': AT(al, i, ac) = 'N'; break;
+            case '-': AT(al, i, ac) = '-'; break;
+            default: break; /* stays '\0' (value-initialised multi_array) */
+          }
+        }
+      }
+      amat_free(&fwd);
+      amat_free(&rvs);
+      *out = al;
+      found = 1;
+    }
+  }
+  free(mat);
+  free(rev);
+  free(r1);
+  free(r2);
+  return found;
+}
+
+int dor_long_needle(const char* s1, int m, const char* s2, int n, char* rows, int cap, int* len,
+                    int* diag) {
+  amat al;
+  int found = long_needle_core(s1, m, s2, n, &al, diag);
+  *len = 0;
+  if (!found) return 0;
+  *len = al.cols;
+  int rc = 1;
+  if (al.cols > cap) rc = -1;
+  else
+    for (int j = 0; j < al.cols; ++j) {
+      rows[j] = AT(al, 0, j);
+      rows[(size_t)cap + j] = AT(al, 1, j);
+    }
+  amat_free(&al);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* K2: profile Gotoh  src/gotoh.h:71-174, src/align.h:89-171,202-229          */
+/* AlignConfig<true,true> (src/msa.h:106): both end gaps free.                */
+
+/* src/align.h:131-171 _createProfile: 6 x cols float (A,C,G,T,N,-) */
+static float* create_profile(const amat* a) {
+  int R = a->rows, C = a->cols;
+  float* p = (float*)calloc((size_t)6 * (size_t)(C > 0 ? C : 1), sizeof(float));
+  int32_t* first = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+  int32_t* last = (int32_t*)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+  for (int i = 0; i < R; ++i) {
+    first[i] = -1;
+    last[i] = C;
+    for (int j = 0; j < C; ++j) {
+      if (first[i] == -1) {
+        if (AT(*a, i, j) != '-') first[i] = j;
+      }
+      if (first[i] != -1) {
+        if (AT(*a, i, j) != '-') last[i] = j;
+      }
+    }
+  }
+  for (int j = 0; j < C; ++j) {
+    int sum = 0;
+    for (int i = 0; i < R; ++i) {
+      if (first[i] <= j && j <= last[i]) {
+        ++sum;
+        char ch = AT(*a, i, j);
+        if (ch == 'A' || ch == 'a') p[0 * (size_t)C + j] += 1;
+        else if (ch == 'C' || ch == 'c') p[1 * (size_t)C + j] += 1;
+        else if (ch == 'G' || ch == 'g') p[2 * (size_t)C + j] += 1;
+        else if (ch == 'T' || ch == 't') p[3 * (size_t)C + j] += 1;
+        else if (ch == 'N' || ch == 'n') p[4 * (size_t)C + j] += 1;
+        else if (ch == '-') p[5 * (size_t)C + j] += 1;
+        else --sum;
+      }
+    }
+    for (int k = 0; k < 6; ++k) p[k * (size_t)C + j] /= sum; /* float / int -> float division */
+  }
+  free(first);
+  free(last);
+  return p;
+}
+
+static inline int gap_free(int i, int iend, int cost) { return (i == 0 || i == iend) ? 0 : cost; }
+
+/* returns score; *out = (r1+r2) x len alignment */
+static int gotoh_core(const dellyhip_params* sc, const amat* a1, const amat* a2, amat* out) {
+  int m = a1->cols, n = a2->cols;
+  const int inf = 1000000; /* DnaScore::inf, align.h:21 */
+  size_t mf = (size_t)n + 1;
+  size_t cells = ((size_t)m + 1) * mf;
+  int32_t* s = (int32_t*)calloc(mf, sizeof(int32_t));
+  int32_t* v = (int32_t*)calloc(mf, sizeof(int32_t));
+  uint8_t* bits = (uint8_t*)calloc(cells, 1); /* bit0..3 = bit1..bit4 of gotoh.h:88-91 */
+  int32_t newhoz = 0, prevsub = 0;
+  int single = (a1->rows == 1 && a2->rows == 1);
+  float *p1 = NULL, *p2 = NULL;
+  if (!single) {
+    p1 = create_profile(a1);
+    p2 = create_profile(a2);
+  }
+  int go = sc->gap_open, ge = sc->gap_extend;
+  for (int row = 0; row <= m; ++row) {
+    for (int col = 0; col <= n; ++col) {
+      if (row == 0 && col == 0) {
+        s[0] = 0;
+        v[0] = -inf;
+        newhoz = -inf;
+        bits[0] |= 1 | 2;
+      } else if (row == 0) {
+        v[col] = -inf;
+        s[col] = gap_free(0, m, go + col * ge);
+        newhoz = gap_free(0, m, go + col * ge);
+        bits[col] |= 4;
+      } else if (col == 0) {
+        newhoz = -inf;
+        s[0] = gap_free(0, n, go + row * ge);
+        if (row - 1 == 0) prevsub = 0;
+        else prevsub = gap_free(0, n, go + (row - 1) * ge);
+        v[0] = gap_free(0, n, go + row * ge);
+        bits[(size_t)row * mf] |= 8;
+      } else {
+        int32_t prevhoz = newhoz;
+        int32_t prevver = v[col];
+        int32_t prevprevsub = prevsub;
+        prevsub = s[col];
+        newhoz = imax(s[col - 1] + gap_free(row, m, go + ge), prevhoz + gap_free(row, m, ge));
+        v[col] = imax(prevsub + gap_free(col, n, go + ge), prevver + gap_free(col, n, ge));
+        int sco;
+        if (single) sco = (AT(*a1, 0, row - 1) == AT(*a2, 0, col - 1)) ? sc->match : sc->mismatch;
+        else {
+          /* align.h:105-109: float accumulation in this exact order */
+          float score = 0;
+          for (int k1 = 0; k1 < 5; ++k1)
+            for (int k2 = 0; k2 < 5; ++k2)
+              score += p1[(size_t)k1 * (size_t)m + (row - 1)] * p2[(size_t)k2 * (size_t)n + (col - 1)] *
+                       ((k1 == k2) ? sc->match : sc->mismatch);
+          sco = (int)score;
+        }
+        s[col] = imax(imax(prevprevsub + sco, newhoz), v[col]);
+        uint8_t b = 0;
+        if (s[col] == newhoz) b |= 4;
+        else if (s[col] == v[col]) b |= 8;
+        if (newhoz != prevhoz + gap_free(row, m, ge)) b |= 1;
+        if (v[col] != prevver + gap_free(col, n, ge)) b |= 2;
+        bits[(size_t)row * mf + col] |= b;
+      }
+    }
+  }
+  int score = s[n];
+  /* traceback, gotoh.h:143-167 */
+  char* btr = (char*)malloc((size_t)m + n + 2);
+  int tl = 0;
+  int row = m, col = n;
+  char last = 's';
+  while (row > 0 || col > 0) {
+    uint8_t b = bits[(size_t)row * mf + col];
+    if (last == 's') {
+      if (b & 4) last = 'h';
+      else if (b & 8) last = 'v';
+      else {
+        --row;
+        --col;
+        btr[tl++] = 's';
+      }
+    } else if (last == 'h') {
+      if (b & 1) last = 's';
+      --col;
+      btr[tl++] = 'h';
+    } else {
+      if (b & 2) last = 's';
+      --row;
+      btr[tl++] = 'v';
+    }
+  }
+  /* _createAlignment, align.h:202-229 */
+  int numN = a1->rows, numM = a2->rows;
+  amat al = amat_new(numN + numM, tl);
+  int r = 0, c = 0, ai = 0;
+  for (int t = tl - 1; t >= 0; --t, ++ai) {
+    if (btr[t] == 's') {
+      for (int i = 0; i < numN; ++i) AT(al, i, ai) = AT(*a1, i, r);
+      for (int i = 0; i < numM; ++i) AT(al, numN + i, ai) = AT(*a2, i, c);
+      ++r;
+      ++c;
+    } else if (btr[t] == 'h') {
+      for (int i = 0; i < numN; ++i) AT(al, i, ai) = '-';
+      for (int i = 0; i < numM; ++i) AT(al, numN + i, ai) = AT(*a2, i, c);
+      ++c;
+    } else {
+      for (int i = 0; i < numN; ++i) AT(al, i, ai) = AT(*a1, i, r);
+      for (int i = 0; i < numM; ++i) AT(al, numN + i, ai) = '-';
+      ++r;
+    }
+  }
+  free(btr);
+  free(bits);
+  free(s);
+  free(v);
+  free(p1);
+  free(p2);
+  *out = al;
+  return score;
+}
+
+int dor_gotoh(const dellyhip_params* p, const char* a1, int r1, int m, const char* a2, int r2, int n,
+              char* out, int cap, int* len) {
+  amat A1 = amat_new(r1, m), A2 = amat_new(r2, n), A;
+  memcpy(A1.d, a1, (size_t)r1 * m);
+  memcpy(A2.d, a2, (size_t)r2 * n);
+  int score = gotoh_core(p, &A1, &A2, &A);
+  *len = A.cols;
+  if (A.cols <= cap)
+    for (int i = 0; i < A.rows; ++i) memcpy(out + (size_t)i * cap, A.d + (size_t)i * A.cols, (size_t)A.cols);
+  amat_free(&A1);
+  amat_free(&A2);
+  amat_free(&A);
+  return score;
+}
+
+/* ------------------------------------------------------------------------ */
+/* K7: consensus  src/msa.h:111-173                                           */
+
+static int consensus_core(const dellyhip_params* p, const amat* al, char* cs /* cap >= cols */) {
+  int R = al->rows, C = al->cols;
+  uint8_t* fl = (uint8_t*)calloc((size_t)(R > 0 ? R : 1) * (size_t)(C > 0 ? C : 1), 1);
+  int* cov = (int*)calloc((size_t)(C > 0 ? C : 1), sizeof(int));
+  for (int i = 0; i < R; ++i) {
+    int start = 0, end = -1;
+    for (int j = 0; j < C; ++j) {
+      if (AT(*al, i, j) != '-') end = j;
+      else if (end == -1) start = j + 1;
+    }
+    for (int j = start; j <= end; ++j) {
+      ++cov[j];
+      fl[(size_t)i * C + j] = 1;
+    }
+  }
+  int thr = imax(2, imin(p->min_clique_size, R));
+  int L = 0;
+  for (int j = 0; j < C; ++j) {
+    int maxIdx = 4;
+    if (cov[j] >= thr) {
+      int count[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < R; ++i)
+        if (fl[(size_t)i * C + j]) {
+          char ch = AT(*al, i, j);
+          if (ch == 'A' || ch == 'a') ++count[0];
+          else if (ch == 'C' || ch == 'c') ++count[1];
+          else if (ch == 'G' || ch == 'g') ++count[2];
+          else if (ch == 'T' || ch == 't') ++count[3];
+          else ++count[4];
+        }
+      maxIdx = 0;
+      int maxCount = count[0];
+      for (int i = 1; i < 5; ++i)
+        if (count[i] > maxCount) {
+          maxCount = count[i];
+          maxIdx = i;
+        }
+    }
+    if (maxIdx < 4) cs[L++] = "ACGT"[maxIdx];
+  }
+  free(fl);
+  free(cov);
+  return L;
+}
+
+int dor_consensus(const dellyhip_params* p, const char* a, int r, int m, char* cs, int cap) {
+  amat A = amat_new(r, m);
+  memcpy(A.d, a, (size_t)r * m);
+  char* tmp = (char*)malloc((size_t)m + 1);
+  int L = consensus_core(p, &A, tmp);
+  if (L <= cap) memcpy(cs, tmp, (size_t)L);
+  free(tmp);
+  amat_free(&A);
+  return L;
+}
+
+/* ------------------------------------------------------------------------ */
+/* guide tree: distanceMatrix + upgma  src/msa.h:32-89                        */
+
+static int guide_tree(int num, const char* blob, const uint64_t* off, int* d /* (2num+1)^2 */,
+                      int* p /* (2num+1) x 3 */) {
+  int D = 2 * num + 1;
+  for (int i = 0; i < D; ++i)
+    for (int j = 0; j < D; ++j) d[i * D + j] = (j > i) ? -1 : 0; /* msa.h:192-195 (rest value-init 0) */
+  for (int i = 0; i < num; ++i)
+    for (int j = i + 1; j < num; ++j) {
+      int li = (int)(off[i + 1] - off[i]), lj = (int)(off[j + 1] - off[j]);
+      int l = dor_lcs(blob + off[i], li, blob + off[j], lj);
+      uint64_t mn = (uint64_t)(li < lj ? li : lj);
+      d[i * D + j] = (int)(((uint64_t)(int64_t)(l * 100)) / mn); /* msa.h:41: int*100 / size_t */
+    }
+  for (int i = 0; i < D; ++i) p[i * 3 + 0] = p[i * 3 + 1] = p[i * 3 + 2] = -1;
+  int nn = num;
+  for (; nn < 2 * num + 1; ++nn) {
+    /* closestPair msa.h:46-60 */
+    int dMax = -1, dI = 0, dJ = 0;
+    for (int i = 0; i < nn; ++i)
+      for (int j = i + 1; j < nn; ++j)
+        if (d[i * D + j] > dMax) {
+          dMax = d[i * D + j];
+          dI = i;
+          dJ = j;
+        }
+    if (dMax == -1) break;
+    p[dI * 3] = nn;
+    p[dJ * 3] = nn;
+    p[nn * 3 + 1] = dI;
+    p[nn * 3 + 2] = dJ;
+    /* updateDistanceMatrix msa.h:62-72 */
+    for (int i = 0; i < nn; ++i)
+      if (p[i * 3] == -1)
+        d[i * D + nn] = (((dI < i) ? d[dI * D + i] : d[i * D + dI]) + ((dJ < i) ? d[dJ * D + i] : d[i * D + dJ])) / 2;
+    for (int i = 0; i < dI; ++i) d[i * D + dI] = -1;
+    for (int i = dI + 1; i < nn + 1; ++i) d[dI * D + i] = -1;
+    for (int i = 0; i < dJ; ++i) d[i * D + dJ] = -1;
+    for (int i = dJ + 1; i < nn + 1; ++i) d[dJ * D + i] = -1;
+  }
+  return (nn > 0) ? (nn - 1) : 0;
+}
+
+int dor_guide_tree(int n_reads, const char* blob, const uint64_t* off, int* dflat, int* pflat) {
+  int D = 2 * n_reads + 1;
+  int* d = dflat ? dflat : (int*)malloc(sizeof(int) * (size_t)D * D);
+  int root = guide_tree(n_reads, blob, off, d, pflat);
+  if (!dflat) free(d);
+  return root;
+}
+
+/* palign  src/msa.h:91-109 */
+static amat palign(const dellyhip_params* p, const char* blob, const uint64_t* off, const int* ph,
+                   int root) {
+  if (ph[root * 3 + 1] == -1 && ph[root * 3 + 2] == -1) {
+    int L = (int)(off[root + 1] - off[root]);
+    amat a = amat_new(1, L);
+    memcpy(a.d, blob + off[root], (size_t)L);
+    return a;
+  }
+  amat a1 = palign(p, blob, off, ph, ph[root * 3 + 1]);
+  amat a2 = palign(p, blob, off, ph, ph[root * 3 + 2]);
+  amat out;
+  gotoh_core(p, &a1, &a2, &out);
+  amat_free(&a1);
+  amat_free(&a2);
+  return out;
+}
+
+/* msa  src/msa.h:185-239 */
+static int msa_core(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off,
+                    char** cs, int* cs_len) {
+  int D = 2 * n_reads + 1;
+  int* d = (int*)malloc(sizeof(int) * (size_t)D * D);
+  int* ph = (int*)malloc(sizeof(int) * (size_t)D * 3);
+  int root = guide_tree(n_reads, blob, off, d, ph);
+  amat al = palign(p, blob, off, ph, root);
+  *cs = (char*)malloc((size_t)al.cols + 1);
+  *cs_len = consensus_core(p, &al, *cs);
+  int rows = al.rows;
+  amat_free(&al);
+  free(d);
+  free(ph);
+  return rows;
+}
+
+int dor_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
+            int cap, int* cs_len) {
+  char* tmp;
+  int rows = msa_core(p, n_reads, blob, off, &tmp, cs_len);
+  if (*cs_len <= cap) memcpy(cs, tmp, (size_t)*cs_len);
+  free(tmp);
+  return rows;
+}
+
+/* ------------------------------------------------------------------------ */
+/* split.h / tags.h: breakpoint window, split detection, coordinates          */
+
+static inline int is_tra(int svt) { return (5 <= svt) && (svt < 9); } /* tags.h:22-25 */
+static inline int span_orient(int svt) { return is_tra(svt) ? svt - 5 : svt; } /* tags.h:33-40 */
+
+typedef struct { /* tags.h:132-148 */
+  int32_t svStartBeg, svStartEnd, svEndBeg, svEndEnd, svStart, svEnd, svt, chr, chr2;
+} bpoint;
+
+/* tags.h:151-172 */
+static void init_breakpoint(const int64_t* chr_len, bpoint* bp, int32_t boundary, int svt) {
+  if (is_tra(svt) || svt == 4) {
+    bp->svStartBeg = imax(0, bp->svStart - boundary);
+    bp->svStartEnd = imin((int32_t)(uint32_t)chr_len[bp->chr], bp->svStart + boundary);
+    bp->svEndBeg = imax(0, bp->svEnd - boundary);
+    bp->svEndEnd = imin((int32_t)(uint32_t)chr_len[bp->chr2], bp->svEnd + boundary);
+  } else {
+    bp->svStartBeg = imax(0, bp->svStart - boundary);
+    bp->svStartEnd = imin(bp->svStart + boundary, (bp->svStart + bp->svEnd) / 2);
+    bp->svEndBeg = imax((bp->svStart + bp->svEnd) / 2 + 1, bp->svEnd - boundary);
+    bp->svEndEnd = imin((int32_t)(uint32_t)chr_len[bp->chr2], bp->svEnd + boundary);
+  }
+}
+
+typedef struct {
+  char* d;
+  size_t n, cap;
+} sbuf;
+static void sb_init(sbuf* s) { s->d = (char*)malloc(64); s->n = 0; s->cap = 64; }
+static void sb_reserve(sbuf* s, size_t extra) {
+  if (s->n + extra + 1 > s->cap) {
+    while (s->n + extra + 1 > s->cap) s->cap *= 2;
+    s->d = (char*)realloc(s->d, s->cap);
+  }
+}
+/* append upper(ref[beg,end)) -- boost::to_upper_copy(std::string(ref+beg, ref+end)) */
+static void sb_upper(sbuf* s, const char* ref, int32_t beg, int32_t end) {
+  if (end <= beg) return;
+  sb_reserve(s, (size_t)(end - beg));
+  for (int32_t i = beg; i < end; ++i) s->d[s->n++] = (char)toupper((unsigned char)ref[i]);
+}
+static void sb_append(sbuf* s, const char* p, size_t n) {
+  sb_reserve(s, n);
+  memcpy(s->d + s->n, p, n);
+  s->n += n;
+}
+/* append the split.h:78-91 style reverse complement of upper(ref[beg,end)):
+ * out[i] = comp(str[len-1-i]) for ACGTN, else str[i] (un-reversed) */
+static void sb_upper_rc(sbuf* s, const char* ref, int32_t beg, int32_t end) {
+  if (end <= beg) return;
+  size_t L = (size_t)(end - beg);
+  sb_reserve(s, L);
+  char* o = s->d + s->n;
+  for (size_t i = 0; i < L; ++i) {
+    char fwd = (char)toupper((unsigned char)ref[beg + (int32_t)i]);
+    char r = (char)toupper((unsigned char)ref[beg + (int32_t)(L - 1 - i)]);
+    switch (r) {
+      case 'A': o[i] = 'T'; break;
+      case 'C': o[i] = 'G'; break;
+      case 'G': o[i] = 'C'; break;
+      case 'T': o[i] = 'A'; break;
+      case 'N': o[i] = 'N'; break;
+      default: o[i] = fwd; break;
+    }
+  }
+  s->n += L;
+}
+
+/* _getSVRef  src/split.h:70-163.  part1 = second-chromosome part (BND). */
+static void get_sv_ref(const dellyhip_params* c, const char* ref, const bpoint* r, int refIndex,
+                       int svt, const sbuf* part1, sbuf* out) {
+  out->n = 0;
+  if (is_tra(svt)) {
+    int ct = span_orient(svt);
+    if (r->chr == refIndex) {
+      if (ct == 0 || ct == 2) {
+        sb_upper(out, ref, r->svStartBeg, r->svStartEnd);
+        sb_append(out, part1->d, part1->n);
+      } else if (ct == 1) {
+        sb_upper_rc(out, ref, r->svStartBeg, r->svStartEnd);
+        sb_append(out, part1->d, part1->n);
+      } else {
+        sb_append(out, part1->d, part1->n);
+        sb_upper(out, ref, r->svStartBeg, r->svStartEnd);
+      }
+    } else {
+      if (ct == 0) sb_upper_rc(out, ref, r->svEndBeg, r->svEndEnd);
+      else sb_upper(out, ref, r->svEndBeg, r->svEndEnd);
+    }
+  } else if (svt == 2) {
+    if (r->svEnd - r->svStart <= c->indelsize) sb_upper(out, ref, r->svStartBeg, r->svEndEnd);
+    else {
+      sb_upper(out, ref, r->svStartBeg, r->svStartEnd);
+      sb_upper(out, ref, r->svEndBeg, r->svEndEnd);
+    }
+  } else if (svt == 4) {
+    sb_upper(out, ref, r->svStartBeg, r->svEndEnd);
+  } else if (svt == 3) {
+    sb_upper(out, ref, r->svEndBeg, r->svEndEnd);
+    sb_upper(out, ref, r->svStartBeg, r->svStartEnd);
+  } else if (svt == 0) {
+    int big = (r->svEnd - r->svStart) > c->min_cons_window;
+    sb_upper(out, ref, r->svStartBeg, r->svStartEnd);
+    if (big) sb_upper_rc(out, ref, r->svEndBeg, r->svEndEnd);
+    else {
+      sb_upper_rc(out, ref, r->svStart, r->svEndEnd);
+      sb_upper(out, ref, r->svEnd, r->svEndEnd);
+    }
+  } else if (svt == 1) {
+    int big = (r->svEnd - r->svStart) > c->min_cons_window;
+    if (big) {
+      sb_upper_rc(out, ref, r->svStartBeg, r->svStartEnd);
+      sb_upper(out, ref, r->svEndBeg, r->svEndEnd);
+    } else {
+      sb_upper(out, ref, r->svStartBeg, r->svStart);
+      sb_upper_rc(out, ref, r->svStartBeg, r->svEnd);
+      sb_upper(out, ref, r->svEndBeg, r->svEndEnd);
+    }
+  }
+}
+
+typedef struct { /* split.h:15-25 */
+  int32_t cStart, cEnd, rStart, rEnd, homLeft, homRight;
+  float percId;
+  uint32_t ma, mm;
+} adesc;
+
+/* _percentIdentity  split.h:282-316 */
+static void percent_identity(const amat* al, int gS, int gE, adesc* ad) {
+  int varSeen = 0, refSeen = 0, inGap = 0;
+  uint32_t gapMM = 0, mm = 0, ma = 0;
+  for (int j = 0; j < al->cols; ++j) {
+    if (j < gS || j > gE) {
+      char a0 = AT(*al, 0, j), a1 = AT(*al, 1, j);
+      if (a0 != '-') varSeen = 1;
+      if (a1 != '-') refSeen = 1;
+      if (a0 == '-' || a1 == '-') {
+        if (refSeen && varSeen) {
+          if (!inGap) {
+            inGap = 1;
+            gapMM = 0;
+          }
+          gapMM += 1;
+        }
+      } else {
+        if (inGap) {
+          mm += gapMM;
+          inGap = 0;
+        }
+        if (a0 == a1) ma += 1;
+        else mm += 1;
+      }
+    }
+  }
+  ad->ma = ma;
+  ad->mm = mm;
+  ad->percId = (float)ma / (float)(ma + mm);
+}
+
+static char* dup_rev(const char* s, int n) {
+  char* r = (char*)malloc((size_t)n + 1);
+  for (int i = 0; i < n; ++i) r[i] = s[n - 1 - i];
+  return r;
+}
+
+/* _findHomology  split.h:262-280 */
+static void find_homology(const char* cons, int m, const char* ref, int n, adesc* ad, int svt) {
+  if (svt == 4) {
+    ad->homRight = dor_longest_homology(cons + ad->cStart, m - ad->cStart, ref + (ad->rEnd - 1), n - (ad->rEnd - 1), -1);
+    int lc = imin(ad->cEnd - 1, m), lr = imin(ad->rStart, n);
+    char* preC = dup_rev(cons, lc);
+    char* preR = dup_rev(ref, lr);
+    ad->homLeft = dor_longest_homology(preC, lc, preR, lr, -1);
+    free(preC);
+    free(preR);
+  } else {
+    ad->homRight = dor_longest_homology(cons + (ad->cEnd - 1), m - (ad->cEnd - 1), ref + ad->rStart, n - ad->rStart, -1);
+    int lc = imin(ad->cStart, m), lr = imin(ad->rEnd - 1, n);
+    char* preC = dup_rev(cons, lc);
+    char* preR = dup_rev(ref, lr);
+    ad->homLeft = dor_longest_homology(preC, lc, preR, lr, -1);
+    free(preC);
+    free(preR);
+  }
+}
+
+/* _findSplit  split.h:319-375; gS/gE returned for the allele scan */
+static int find_split(const dellyhip_params* c, const char* cons, int m, const char* ref, int n,
+                      const amat* al, adesc* ad, int svt) {
+  int gS = 0, gE = 0, refIndex = 0, varIndex = 0, gapStartRefIndex = 0, gapStartVarIndex = 0, a1 = 0;
+  int inGap = 0;
+  for (int j = 0; j < al->cols; ++j) {
+    char c0 = AT(*al, 0, j), c1 = AT(*al, 1, j);
+    if (c0 != '-') ++varIndex;
+    if (c1 != '-') ++refIndex;
+    if ((c0 == '-' || c1 == '-') && refIndex > 0 && varIndex > 0) {
+      if (!inGap) {
+        gapStartVarIndex = (c0 != '-') ? (varIndex - 1) : varIndex;
+        gapStartRefIndex = (c1 != '-') ? (refIndex - 1) : refIndex;
+        a1 = j;
+        inGap = 1;
+      }
+    } else {
+      int better = (svt == 4) ? ((varIndex - gapStartVarIndex) > (ad->cEnd - ad->cStart))
+                              : ((refIndex - gapStartRefIndex) > (ad->rEnd - ad->rStart));
+      if (inGap && better) {
+        ad->rStart = gapStartRefIndex;
+        ad->rEnd = refIndex;
+        ad->cStart = gapStartVarIndex;
+        ad->cEnd = varIndex;
+        gS = a1;
+        gE = j - 1;
+      }
+      inGap = 0;
+    }
+  }
+  if (ad->rEnd <= ad->rStart) return 0;
+  /* _validSRAlignment split.h:247-253 */
+  if (svt == 4) {
+    if (!(((ad->rEnd - ad->rStart) < 5) && ((ad->cEnd - ad->cStart) > 15))) return 0;
+  } else {
+    if (!(((ad->cEnd - ad->cStart) < 5) && ((ad->rEnd - ad->rStart) > 15))) return 0;
+  }
+  percent_identity(al, gS, gE, ad);
+  if (ad->percId < c->flank_quality) return 0;
+  find_homology(cons, m, ref, n, ad, svt);
+  if ((ad->homLeft + c->minimum_flank_size > ad->cStart) || (varIndex < ad->cEnd + ad->homRight + c->minimum_flank_size)) return 0;
+  if ((ad->homLeft + c->minimum_flank_size > ad->rStart) || (refIndex < ad->rEnd + ad->homRight + c->minimum_flank_size)) return 0;
+  return 1;
+}
+
+/* _coordTransform  split.h:166-244 (unsigned int outputs) */
+static int coord_transform(const dellyhip_params* c, uint64_t refsize, const bpoint* sv, const adesc* ad,
+                           uint32_t* gs, uint32_t* ge, int svt) {
+  int32_t annealed;
+  if (is_tra(svt)) {
+    int ct = span_orient(svt);
+    if (ct == 0) {
+      annealed = sv->svStartEnd - sv->svStartBeg;
+      if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)((uint64_t)(int64_t)sv->svEndBeg + (refsize - (uint64_t)(int64_t)ad->rEnd) + 1);
+    } else if (ct == 1) {
+      annealed = sv->svStartEnd - sv->svStartBeg;
+      if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+      *gs = (uint32_t)(sv->svStartBeg + (annealed - ad->rStart) + 1);
+      *ge = (uint32_t)(sv->svEndBeg + (ad->rEnd - annealed));
+    } else if (ct == 2) {
+      annealed = sv->svStartEnd - sv->svStartBeg;
+      if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)(sv->svEndBeg + (ad->rEnd - annealed));
+    } else if (ct == 3) {
+      annealed = sv->svEndEnd - sv->svEndBeg;
+      if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+      *gs = (uint32_t)(sv->svStartBeg + (ad->rEnd - annealed));
+      *ge = (uint32_t)(sv->svEndBeg + ad->rStart);
+    } else return 0;
+    return 1;
+  }
+  if (svt == 2) {
+    if (sv->svEnd - sv->svStart > c->indelsize) {
+      annealed = sv->svStartEnd - sv->svStartBeg;
+      if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)(sv->svEndBeg + (ad->rEnd - annealed));
+    } else {
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)(sv->svStartBeg + ad->rEnd);
+    }
+    return 1;
+  } else if (svt == 3) {
+    annealed = sv->svEndEnd - sv->svEndBeg;
+    if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+    *gs = (uint32_t)(sv->svStartBeg + (ad->rEnd - annealed));
+    *ge = (uint32_t)(sv->svEndBeg + ad->rStart);
+    return 1;
+  } else if (svt == 0) {
+    annealed = sv->svStartEnd - sv->svStartBeg;
+    if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+    if ((sv->svEnd - sv->svStart) > c->min_cons_window) {
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)((uint64_t)(int64_t)sv->svEndBeg + (refsize - (uint64_t)(int64_t)ad->rEnd) + 1);
+    } else {
+      *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+      *ge = (uint32_t)(sv->svEndEnd - (ad->rEnd - annealed));
+    }
+    return 1;
+  } else if (svt == 1) {
+    if ((sv->svEnd - sv->svStart) > c->min_cons_window) annealed = sv->svStartEnd - sv->svStartBeg;
+    else annealed = (sv->svStart - sv->svStartBeg) + (sv->svEnd - sv->svStartBeg);
+    if (ad->rStart >= annealed || ad->rEnd < annealed) return 0;
+    *gs = (uint32_t)(sv->svStartBeg + (annealed - ad->rStart) + 1);
+    *ge = (uint32_t)(sv->svEndBeg + (ad->rEnd - annealed));
+    return 1;
+  } else if (svt == 4) {
+    *gs = (uint32_t)(sv->svStartBeg + ad->rStart);
+    *ge = (uint32_t)(sv->svStartBeg + ad->rEnd);
+    return 1;
+  }
+  return 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* batch driver: loop body of src/shortpe.h:183-197 (msa + alignConsensus)    */
+
+typedef struct {
+  const dellyhip_params* p;
+  int n_chr;
+  const char* const* chr_seq;
+  const int64_t* chr_len;
+  int n_junc;
+  const dellyhip_junction* junc;
+  const char* blob;
+  const uint64_t* off;
+  dellyhip_result* results;
+  char* out_blob;
+  uint64_t out_cap;
+  _Atomic uint64_t used;
+  _Atomic uint32_t next;
+  int with_msa, want_alignment;
+} batch_t;
+
+static uint64_t blob_put(batch_t* b, const char* p, uint64_t n) {
+  uint64_t o = atomic_fetch_add(&b->used, n);
+  if (b->out_blob == NULL || o + n > b->out_cap) return UINT64_MAX;
+  if (n) memcpy(b->out_blob + o, p, n);
+  return o;
+}
+
+static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* R) {
+  const dellyhip_params* c = b->p;
+  memset(R, 0, sizeof(*R));
+  R->svid = J->svid;
+  R->sv_start = J->sv_start;
+  R->sv_end = J->sv_end;
+  R->ins_len = J->ins_len;
+  R->score_unsplit = R->score_best = R->cons_left = R->ref_left = R->ref_right = -1;
+  R->matches = R->mismatches = -1;
+
+  char* cons = NULL;
+  int m = 0;
+  if (b->with_msa) {
+    if (J->n_seq <= 1) return; /* shortpe.h:166-171 */
+    R->sr_support = msa_core(c, J->n_seq, b->blob, b->off + J->seq_first, &cons, &m);
+    /* NOTE: off + seq_first keeps absolute offsets into blob */
+  } else {
+    m = (int)(b->off[J->seq_first + 1] - b->off[J->seq_first]);
+    cons = (char*)malloc((size_t)m + 1);
+    memcpy(cons, b->blob + b->off[J->seq_first], (size_t)m);
+  }
+  R->cons_len = m;
+  R->cons_off = blob_put(b, cons, (uint64_t)m);
+
+  if (J->svt == 4) { /* splitAlign/edlib not restated */
+    R->status = DELLYHIP_E_LIMIT;
+    free(cons);
+    return;
+  }
+  /* alignConsensus  split.h:644-666 */
+  if (m < (2 * c->minimum_flank_size + J->ins_len)) {
+    free(cons);
+    return;
+  }
+  bpoint bp;
+  bp.svStartBeg = bp.svStartEnd = bp.svStart = J->sv_start;
+  bp.svEndBeg = bp.svEndEnd = bp.svEnd = J->sv_end;
+  bp.svt = J->svt;
+  bp.chr = J->chr;
+  bp.chr2 = J->chr2;
+  init_breakpoint(b->chr_len, &bp, m, J->svt);
+  sbuf part1, ref;
+  sb_init(&part1);
+  sb_init(&ref);
+  if (bp.chr != bp.chr2) get_sv_ref(c, b->chr_seq[J->chr2], &bp, bp.chr2, J->svt, &part1, &part1);
+  /* (part1 is empty on entry, so aliasing in/out is harmless: the chr2 branch never reads it) */
+  get_sv_ref(c, b->chr_seq[J->chr], &bp, bp.chr, J->svt, &part1, &ref);
+  int n = (int)ref.n;
+  R->ref_len = n;
+
+  /* _alignConsensus split.h:560-642 (realign=false) */
+  amat al;
+  int diag[5];
+  int found = long_needle_core(cons, m, ref.d, n, &al, diag);
+  R->score_unsplit = diag[0];
+  R->score_best = diag[1];
+  R->cons_left = diag[2];
+  R->ref_left = diag[3];
+  R->ref_right = diag[4];
+  if (found) {
+    if (b->want_alignment) {
+      R->aln_off = blob_put(b, al.d, (uint64_t)2 * (uint64_t)al.cols);
+      R->aln_len = al.cols;
+    }
+    adesc ad;
+    memset(&ad, 0, sizeof(ad));
+    if (find_split(c, cons, m, ref.d, n, &al, &ad, J->svt)) {
+      R->c_start = ad.cStart; R->c_end = ad.cEnd; R->r_start = ad.rStart; R->r_end = ad.rEnd;
+      R->hom_left = ad.homLeft; R->hom_right = ad.homRight;
+      R->matches = (int32_t)ad.ma;
+      R->mismatches = (int32_t)ad.mm;
+      uint32_t gs = 0, ge = 0;
+      if (coord_transform(c, (uint64_t)n, &bp, &ad, &gs, &ge, J->svt) && (is_tra(J->svt) || gs < ge)) {
+        /* exact alleles split.h:606-624 */
+        if (J->sv_end - J->sv_start <= c->indelsize && (J->svt == 2 || J->svt == 4)) {
+          char* refV = (char*)malloc((size_t)al.cols + 2);
+          char* altV = (char*)malloc((size_t)al.cols + 2);
+          int nr = 0, na = 0, cpos = 0, inSV = 0;
+          for (int j = 0; j < al.cols; ++j) {
+            if (AT(al, 0, j) != '-') {
+              ++cpos;
+              if (cpos == ad.cStart) inSV = 1;
+              else if (cpos == ad.cEnd) inSV = 0;
+            }
+            if (inSV) {
+              if (AT(al, 0, j) != '-') altV[na++] = AT(al, 0, j);
+              if (AT(al, 1, j) != '-') refV[nr++] = AT(al, 1, j);
+            }
+          }
+          char* both = (char*)malloc((size_t)nr + na + 2);
+          memcpy(both, refV, (size_t)nr);
+          both[nr] = ',';
+          memcpy(both + nr + 1, altV, (size_t)na);
+          R->allele_off = blob_put(b, both, (uint64_t)nr + na + 1);
+          R->allele_len = nr + na + 1;
+          free(refV);
+          free(altV);
+          free(both);
+        }
+        R->ok = 1;
+        R->sv_start = (int32_t)gs;
+        R->sv_end = (int32_t)ge;
+        R->sr_align_quality = ad.percId;
+        R->ins_len = ad.cEnd - ad.cStart - 1;
+        R->cons_bp = ad.cStart;
+        R->hom_len = imax(0, ad.homLeft + ad.homRight - 2);
+        R->ci_wiggle = imax(ad.homLeft, ad.homRight);
+      }
+    }
+    amat_free(&al);
+  }
+  free(part1.d);
+  free(ref.d);
+  free(cons);
+}
+
+static void* worker(void* arg) {
+  batch_t* b = (batch_t*)arg;
+  for (;;) {
+    uint32_t i = atomic_fetch_add(&b->next, 1);
+    if (i >= (uint32_t)b->n_junc) break;
+    refine_one(b, &b->junc[i], &b->results[i]);
+  }
+  return NULL;
+}
+
+int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                     const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                     const char* blob, const uint64_t* off, dellyhip_result* results,
+                     char* out_blob, uint64_t out_cap, uint64_t* out_used, int with_msa,
+                     int want_alignment, int n_threads) {
+  batch_t b;
+  b.p = p; b.n_chr = n_chr; b.chr_seq = chr_seq; b.chr_len = chr_len; b.n_junc = n_junc;
+  b.junc = junc; b.blob = blob; b.off = off; b.results = results; b.out_blob = out_blob;
+  b.out_cap = out_cap; b.with_msa = with_msa; b.want_alignment = want_alignment;
+  atomic_init(&b.used, 0);
+  atomic_init(&b.next, 0);
+  if (n_threads <= 1) worker(&b);
+  else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, worker, &b);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+  }
+  uint64_t used = atomic_load(&b.used);
+  if (out_used) *out_used = used;
+  return (out_blob && used > out_cap) ? -1 : 0;
+}

@@ -1,0 +1,49 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- the parity oracle.  Never imported, linked or
+ * executed by the product path (delly_amd/, libdellyhip.so); only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Plain-C restatement of the reference's split-read refinement algorithm
+ * (dellytools/delly v2.5.1).  Pinned against the reference itself:
+ * oracle/_ref/libdelly_ref.so compiles the reference's own headers, and
+ * tests/test_oracle_vs_ref.py + tests/golden/ hold every function below to
+ * bit-identical outputs on seeded inputs (the reference ships no tests or
+ * golden vectors of its own -- SURVEY.md F8).
+ *
+ * NOT restated (yet): svt==4 insertions (splitAlign -> edlib) and the
+ * long-read MSA (msaEdlib/msaWfa); dor_refine_batch reports
+ * DELLYHIP_E_LIMIT in result.status for those.
+ */
+#ifndef DELLY_ORACLE_H
+#define DELLY_ORACLE_H
+
+#include <stdint.h>
+#include "../include/dellyhip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int dor_lcs(const char* s1, int m, const char* s2, int n);
+void dor_reverse_complement(char* s, int n);
+int dor_longest_homology(const char* a, int la, const char* b, int lb, int thr);
+/* returns 1 found / 0 not found / -1 cap too small; diag[5] (may be NULL) =
+ * {mat[m][n], bestScore, consLeft, refLeft, refRight} */
+int dor_long_needle(const char* s1, int m, const char* s2, int n, char* rows, int cap, int* len,
+                    int* diag);
+int dor_gotoh(const dellyhip_params* p, const char* a1, int r1, int m, const char* a2, int r2, int n,
+              char* out, int cap, int* len);
+int dor_consensus(const dellyhip_params* p, const char* a, int r, int m, char* cs, int cap);
+int dor_guide_tree(int n_reads, const char* blob, const uint64_t* off, int* dflat, int* pflat);
+int dor_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
+            int cap, int* cs_len);
+int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                     const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                     const char* blob, const uint64_t* off, dellyhip_result* results,
+                     char* out_blob, uint64_t out_cap, uint64_t* out_used, int with_msa,
+                     int want_alignment, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

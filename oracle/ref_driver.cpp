@@ -1,0 +1,364 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+//
+// oracle/_ref/libdelly_ref.so: the REFERENCE ITSELF on the hot path.  This
+// translation unit #includes the reference's own headers from where they lie
+// under /root/reference/src (tags.h, edlib.h, msa.h -> align.h gotoh.h needle.h,
+// split.h) UNMODIFIED, against the container-only shim in oracle/shim/
+// (SURVEY.md 8c), and exposes them through a small C interface that tests,
+// the golden-vector generator and bench.py's cpu_baseline leg drive.
+//
+// Restated here (because src/util.h drags in boost::iostreams/filesystem and
+// htslib and cannot be included): reverseComplement (src/util.h:549-563),
+// infixStart/infixEnd (src/util.h:86-99), _addAlleles (src/util.h:250-253).
+// They keep the reference's observable behaviour, including the quirk that a
+// non-ACGTN letter leaves the un-reversed original byte in place.
+//
+// Build: oracle/Makefile (g++ -std=c++17 -O3 -fno-tree-vectorize -DNDEBUG,
+// the reference's release flags, Makefile:47 of the reference).
+#include "ref_prelude.h"
+
+#include <atomic>
+#include <thread>
+#include <unordered_set>
+
+#include "edlib.h"
+#include "tags.h"
+
+namespace torali {
+
+// src/util.h:86-99
+inline uint32_t infixStart(EdlibAlignResult const& cigar) {
+  int32_t tIdx = cigar.endLocations[0];
+  for (int32_t i = 0; i < cigar.alignmentLength; ++i)
+    if (cigar.alignment[i] != EDLIB_EDOP_INSERT) --tIdx;
+  return (tIdx >= 0) ? (uint32_t)(tIdx + 1) : 0u;
+}
+inline uint32_t infixEnd(EdlibAlignResult const& cigar) { return cigar.endLocations[0]; }
+
+// src/util.h:250-253
+inline std::string _addAlleles(std::string const& ref, std::string const& alt) {
+  return ref + "," + alt;
+}
+
+// src/util.h:549-563
+inline void reverseComplement(std::string& sequence) {
+  std::size_t n = sequence.size();
+  std::string up(n, ' ');
+  for (std::size_t i = 0; i < n; ++i) up[i] = (char)std::toupper((unsigned char)sequence[n - 1 - i]);
+  for (std::size_t i = 0; i < n; ++i) {
+    switch (up[i]) {
+      case 'A': sequence[i] = 'T'; break;
+      case 'C': sequence[i] = 'G'; break;
+      case 'G': sequence[i] = 'C'; break;
+      case 'T': sequence[i] = 'A'; break;
+      case 'N': sequence[i] = 'N'; break;
+      default: break;  // byte i keeps its ORIGINAL (un-reversed) value
+    }
+  }
+}
+
+}  // namespace torali
+
+#include "msa.h"
+#include "split.h"
+
+#include "../include/dellyhip.h"
+
+namespace {
+
+struct RefConfig {  // the duck-typed TConfig of the path
+  torali::DnaScore<int> aliscore;
+  uint32_t minCliqueSize;
+  float flankQuality;
+  int32_t minimumFlankSize;
+  int32_t indelsize;
+  int32_t minConsWindow;
+};
+
+RefConfig make_config(const dellyhip_params* p) {
+  RefConfig c;
+  c.aliscore = torali::DnaScore<int>(p->match, p->mismatch, p->gap_open, p->gap_extend);
+  c.minCliqueSize = (uint32_t)p->min_clique_size;
+  c.flankQuality = p->flank_quality;
+  c.minimumFlankSize = p->minimum_flank_size;
+  c.indelsize = p->indelsize;
+  c.minConsWindow = p->min_cons_window;
+  return c;
+}
+
+typedef boost::multi_array<char, 2> TAlign;
+
+void to_align(const char* a, int r, int m, TAlign& out) {
+  out.resize(boost::extents[r][m]);
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < m; ++j) out[i][j] = a[(size_t)i * m + j];
+}
+
+struct BlobWriter {
+  char* base;
+  uint64_t cap;
+  std::atomic<uint64_t> used;
+  BlobWriter(char* b, uint64_t c) : base(b), cap(c), used(0) {}
+  // returns offset or UINT64_MAX on overflow
+  uint64_t put(const char* p, uint64_t n) {
+    uint64_t off = used.fetch_add(n);
+    if (off + n > cap || base == NULL) return UINT64_MAX;
+    if (n) std::memcpy(base + off, p, n);
+    return off;
+  }
+};
+
+void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr_seq,
+                const dellyhip_junction& J, const char* blob, const uint64_t* off,
+                dellyhip_result& R, BlobWriter& bw, int with_msa, int want_alignment) {
+  using namespace torali;
+  std::memset(&R, 0, sizeof(R));
+  R.svid = J.svid;
+  R.score_unsplit = R.score_best = R.cons_left = R.ref_left = R.ref_right = -1;  // not observable
+  StructuralVariantRecord sv;
+  sv.chr = J.chr;
+  sv.chr2 = J.chr2;
+  sv.svStart = J.sv_start;
+  sv.svEnd = J.sv_end;
+  sv.svt = J.svt;
+  sv.insLen = J.ins_len;
+  sv.id = J.svid;
+  R.sv_start = J.sv_start;
+  R.sv_end = J.sv_end;
+  R.ins_len = J.ins_len;
+
+  if (with_msa) {
+    // src/shortpe.h:166-171: <=1 read -> no consensus, junction skipped
+    if (J.n_seq <= 1) return;
+    std::vector<std::string> sps;  // iteration order == the host's set order
+    for (int32_t k = 0; k < J.n_seq; ++k)
+      sps.push_back(std::string(blob + off[J.seq_first + k], blob + off[J.seq_first + k + 1]));
+    R.sr_support = msa(c, sps, sv.consensus);  // src/shortpe.h:185
+  } else {
+    sv.consensus = std::string(blob + off[J.seq_first], blob + off[J.seq_first + 1]);
+    R.sr_support = 0;
+  }
+  std::string consIn = sv.consensus;
+  R.cons_len = (int32_t)consIn.size();
+  R.cons_off = bw.put(consIn.data(), consIn.size());
+
+  // Diagnostics: replay the inner calls of alignConsensus (src/split.h:646-666,
+  // :582,:596) with the reference's own functions to expose the alignment rows
+  // and the AlignDescriptor, which alignConsensus() itself does not return.
+  const char* seq = chr_seq[J.chr];
+  const char* sndSeq = (J.chr2 != J.chr) ? chr_seq[J.chr2] : NULL;
+  if (!((int32_t)sv.consensus.size() < (2 * c.minimumFlankSize + sv.insLen))) {
+    Breakpoint bp(sv);
+    if (sv.svt == 4) {
+      int32_t bufferSpace = std::max((int32_t)((sv.consensus.size() - sv.insLen) / 3), c.minimumFlankSize);
+      _initBreakpoint(hdr, bp, bufferSpace, sv.svt);
+    } else _initBreakpoint(hdr, bp, sv.consensus.size(), sv.svt);
+    if (bp.chr != bp.chr2) bp.part1 = _getSVRef(c, sndSeq, bp, bp.chr2, sv.svt);
+    std::string svRefStr = _getSVRef(c, seq, bp, bp.chr, sv.svt);
+    R.ref_len = (int32_t)svRefStr.size();
+    TAlign align;
+    if (_consRefAlignment(sv.consensus, svRefStr, align, sv.svt)) {
+      if (want_alignment) {
+        uint64_t len = align.shape()[1];
+        std::string rows(2 * len, ' ');
+        for (uint64_t j = 0; j < len; ++j) {
+          rows[j] = align[0][j];
+          rows[len + j] = align[1][j];
+        }
+        R.aln_off = bw.put(rows.data(), rows.size());
+        R.aln_len = (int32_t)len;
+      }
+      AlignDescriptor ad;
+      if (_findSplit(c, sv.consensus, svRefStr, align, ad, sv.svt)) {
+        R.c_start = ad.cStart; R.c_end = ad.cEnd; R.r_start = ad.rStart; R.r_end = ad.rEnd;
+        R.hom_left = ad.homLeft; R.hom_right = ad.homRight;
+      }
+    }
+  }
+
+  // The authoritative call: src/shortpe.h:186 / src/split.h:668-672
+  bool ok = alignConsensus(c, const_cast<bam_hdr_t*>(hdr), seq, sndSeq, sv);
+  R.ok = ok ? 1 : 0;
+  if (ok) {
+    R.sv_start = sv.svStart;
+    R.sv_end = sv.svEnd;
+    R.ci_wiggle = sv.ciposhigh;
+    R.ins_len = sv.insLen;
+    R.cons_bp = sv.consBp;
+    R.hom_len = sv.homLen;
+    R.sr_align_quality = sv.srAlignQuality;
+    if (!sv.alleles.empty()) {
+      R.allele_off = bw.put(sv.alleles.data(), sv.alleles.size());
+      R.allele_len = (int32_t)sv.alleles.size();
+    }
+  }
+  R.matches = R.mismatches = -1;  // not observable through the reference API
+}
+
+}  // namespace
+
+extern "C" {
+
+// int lcs(s1,s2)  src/msa.h:10-30
+int dref_lcs(const char* a, int la, const char* b, int lb) {
+  return torali::lcs(std::string(a, a + la), std::string(b, b + lb));
+}
+
+// longestHomology  src/needle.h:13-42
+int dref_longest_homology(const char* a, int la, const char* b, int lb, int thr) {
+  return torali::longestHomology(std::string(a, a + la), std::string(b, b + lb), thr);
+}
+
+// reverseComplement (restated above)
+void dref_reverse_complement(char* s, int n) {
+  std::string t(s, s + n);
+  torali::reverseComplement(t);
+  std::memcpy(s, t.data(), n);
+}
+
+// longNeedle(cons, ref, align, AlignConfig<true,false>, DnaScore(1,-1,-1,-1))
+// src/needle.h:45-222 exactly as called from src/split.h:543-555.
+int dref_long_needle(const char* s1, int m, const char* s2, int n, char* rows, int cap, int* len) {
+  using namespace torali;
+  AlignConfig<true, false> semiglobal;
+  DnaScore<int> lnsc(1, -1, -1, -1);
+  TAlign aln;
+  bool ok = longNeedle(std::string(s1, s1 + m), std::string(s2, s2 + n), aln, semiglobal, lnsc);
+  *len = 0;
+  if (!ok) return 0;
+  int L = (int)aln.shape()[1];
+  *len = L;
+  if (L > cap) return -1;
+  for (int j = 0; j < L; ++j) {
+    rows[j] = aln[0][j];
+    rows[(size_t)cap + j] = aln[1][j];
+  }
+  return 1;
+}
+
+// gotoh(a1, a2, align, AlignConfig<true,true>, c.aliscore)  src/gotoh.h:71-174
+// as called by palign, src/msa.h:106-107.
+int dref_gotoh(const dellyhip_params* p, const char* a1, int r1, int m, const char* a2, int r2,
+               int n, char* out, int cap, int* len) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  TAlign A1, A2, A;
+  to_align(a1, r1, m, A1);
+  to_align(a2, r2, n, A2);
+  AlignConfig<true, true> endFree;
+  int score = gotoh(A1, A2, A, endFree, c.aliscore);
+  int L = (int)A.shape()[1];
+  *len = L;
+  if (L <= cap)
+    for (int i = 0; i < r1 + r2; ++i)
+      for (int j = 0; j < L; ++j) out[(size_t)i * cap + j] = A[i][j];
+  return score;
+}
+
+// consensus(c, align, cs)  src/msa.h:175-183
+int dref_consensus(const dellyhip_params* p, const char* a, int r, int m, char* cs, int cap) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  TAlign A;
+  to_align(a, r, m, A);
+  std::string s;
+  consensus(c, A, s);
+  if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
+  return (int)s.size();
+}
+
+// msa(c, sps, cs)  src/msa.h:185-239; returns rows, consensus in cs
+int dref_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
+             int cap, int* cs_len) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  std::vector<std::string> sps;
+  for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
+  std::string s;
+  int rows = msa(c, sps, s);
+  *cs_len = (int)s.size();
+  if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
+  return rows;
+}
+
+// distanceMatrix + upgma (src/msa.h:32-89): returns root, fills d[(2n+1)^2], p[(2n+1)*3]
+int dref_guide_tree(int n_reads, const char* blob, const uint64_t* off, int* dflat, int* pflat) {
+  using namespace torali;
+  typedef boost::multi_array<int, 2> TDist;
+  typedef TDist::index TDIndex;
+  std::vector<std::string> sps;
+  for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
+  TDIndex num = n_reads;
+  TDist d(boost::extents[2 * num + 1][2 * num + 1]);
+  for (TDIndex i = 0; i < (2 * num + 1); ++i)
+    for (TDIndex j = i + 1; j < (2 * num + 1); ++j) d[i][j] = -1;
+  distanceMatrix(sps, d);
+  if (dflat)
+    for (TDIndex i = 0; i < (2 * num + 1); ++i)
+      for (TDIndex j = 0; j < (2 * num + 1); ++j) dflat[i * (2 * num + 1) + j] = d[i][j];
+  TDist ph(boost::extents[2 * num + 1][3]);
+  for (TDIndex i = 0; i < (2 * num + 1); ++i)
+    for (TDIndex j = 0; j < 3; ++j) ph[i][j] = -1;
+  TDIndex root = upgma(d, ph, num);
+  for (TDIndex i = 0; i < (2 * num + 1); ++i)
+    for (TDIndex j = 0; j < 3; ++j) pflat[i * 3 + j] = ph[i][j];
+  return (int)root;
+}
+
+// The loop body of src/shortpe.h:175-201 over a batch, with the reference's
+// threading model: n_threads std::threads pulling junction indices from one
+// std::atomic counter.  with_msa=0: alignConsensus only (BASELINE unit U).
+int dref_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                      const char* blob, const uint64_t* off, dellyhip_result* results,
+                      char* out_blob, uint64_t out_cap, uint64_t* out_used, int with_msa,
+                      int want_alignment, int n_threads) {
+  RefConfig c = make_config(p);
+  std::vector<uint32_t> tlen(n_chr);
+  for (int i = 0; i < n_chr; ++i) tlen[i] = (uint32_t)chr_len[i];
+  bam_hdr_t hdr;
+  hdr.n_targets = n_chr;
+  hdr.target_len = tlen.data();
+  hdr.target_name = NULL;
+  BlobWriter bw(out_blob, out_cap);
+  std::atomic<uint32_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      uint32_t idx = next.fetch_add(1, std::memory_order_relaxed);
+      if (idx >= (uint32_t)n_junc) break;
+      refine_one(c, &hdr, chr_seq, junc[idx], blob, off, results[idx], bw, with_msa, want_alignment);
+    }
+  };
+  if (n_threads <= 1) worker();
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  if (out_used) *out_used = bw.used.load();
+  return (bw.used.load() > out_cap && out_blob) ? -1 : 0;
+}
+
+// std::unordered_set<std::string> iteration order of the host
+// (src/shortpe.h:68,96): inserts the reads in the given order and returns the
+// permutation in which the set iterates (perm[k] = input index, -1 padded when
+// duplicates collapse).  Returns the set size.
+int dref_unordered_set_order(int n_reads, const char* blob, const uint64_t* off, int* perm) {
+  std::unordered_set<std::string> s;
+  std::vector<std::string> in;
+  for (int k = 0; k < n_reads; ++k) {
+    in.push_back(std::string(blob + off[k], blob + off[k + 1]));
+    s.insert(in.back());
+  }
+  int k = 0;
+  for (auto const& x : s) {
+    int idx = -1;
+    for (int i = 0; i < n_reads; ++i)
+      if (in[i] == x) { idx = i; break; }
+    perm[k++] = idx;
+  }
+  for (int i = k; i < n_reads; ++i) perm[i] = -1;
+  return (int)s.size();
+}
+
+}  // extern "C"
