@@ -1,0 +1,34 @@
+"""Builds delly_amd/libdellyhip.so (hand-written HIP for gfx950 + the C-ABI host
+side) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdellyhip.so")
+SOURCES = ["dellyhip.hip"]
+HEADERS = ["split_kernel.hpp", "split_main.hpp", "msa_kernel.hpp", "../../include/dellyhip.h"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off",  # profile-Gotoh scores must round like the reference
+           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_lib(force=True, verbose=True)

@@ -1,0 +1,571 @@
+// dellyhip.hip -- host side of the C-ABI declared in include/dellyhip.h.
+// Thin marshalling only: every byte of DP work happens in the gfx950 kernels
+// of split_kernel.hpp / split_main.hpp / msa_kernel.hpp.  There is no CPU
+// fallback: without a usable device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dellyhip.h"
+#include "msa_kernel.hpp"
+#include "split_main.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[512];
+  if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof buf, "%s", what);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(x)                                          \
+  do {                                                     \
+    hipError_t _e = (x);                                   \
+    if (_e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, #x, _e); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; n = 0; return fail(DELLYHIP_E_NOMEM, "hipMalloc", e); }
+    return 0;
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct dellyhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  dellyhip_params params{};
+  int n_cu = 0;
+  // chromosome table
+  std::vector<uint8_t*> chr_dev;   // device pointers
+  std::vector<int64_t> chr_len;
+  DevBuf<const uint8_t*> d_chr_ptr;
+  DevBuf<int64_t> d_chr_len;
+  bool chr_dirty = true;
+  // per-resident-block scratch of the split kernel
+  DevBuf<uint32_t> scratch;
+  uint64_t scratch_words = 0;
+  int scratch_blocks = 0;
+  DevBuf<int32_t> counters;  // work counters (one per K bin + MSA)
+};
+
+struct dellyhip_batch {
+  int32_t n = 0;
+  uint64_t n_seq = 0;
+  int with_msa = 0;
+  int want_alignment = 0;
+  std::vector<dellyhip_junction> h_junc;
+  std::vector<int32_t> h_cons_len;   // U path: known on the host
+  DevBuf<dellyhip_junction> junc;
+  DevBuf<uint8_t> seq_blob;
+  DevBuf<uint64_t> seq_off;
+  DevBuf<uint64_t> cons_off;
+  DevBuf<int32_t> cons_len;
+  DevBuf<dellyhip_result> res;
+  DevBuf<uint8_t> out_blob;
+  uint64_t out_stride = 0;
+  DevBuf<int32_t> work;              // K-binned work lists, concatenated
+  std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
+  // direct (single longNeedle) mode
+  DevBuf<uint8_t> ref_blob;
+  DevBuf<uint64_t> ref_off;
+  DevBuf<int32_t> ref_len;
+  // MSA stage
+  DevBuf<uint8_t> msa_ws;
+  uint64_t msa_ws_stride = 0;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  double ms_split = 0, ms_msa = 0;
+  int launches = 0;
+  bool pending = false;
+};
+
+namespace {
+
+int ensure_chr_table(dellyhip_ctx* c) {
+  if (!c->chr_dirty) return 0;
+  size_t n = c->chr_dev.size();
+  if (n == 0) return fail(DELLYHIP_E_ARG, "no chromosome uploaded (dellyhip_set_chromosome)");
+  int rc;
+  if ((rc = c->d_chr_ptr.alloc(n))) return rc;
+  if ((rc = c->d_chr_len.alloc(n))) return rc;
+  HIPCHK(hipMemcpy(c->d_chr_ptr.p, c->chr_dev.data(), n * sizeof(uint8_t*), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_chr_len.p, c->chr_len.data(), n * sizeof(int64_t), hipMemcpyHostToDevice));
+  c->chr_dirty = false;
+  return 0;
+}
+
+int ensure_scratch(dellyhip_ctx* c) {
+  if (c->scratch.p) return 0;
+  const uint64_t nblk = (dh::NMAX + 63 + 15) / 16 + 1;
+  c->scratch_words = nblk * dh::KMAX * dh::WAVE;
+  c->scratch_blocks = c->n_cu * 14;  // LDS-limited residency of the split kernel
+  int rc = c->scratch.alloc((size_t)c->scratch_words * c->scratch_blocks);
+  if (rc) return rc;
+  return c->counters.alloc(16);
+}
+
+template <int K>
+void launch_split(const dh::SplitArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(grid), dim3(dh::WAVE), 0, s, a);
+}
+
+// Launches the split-alignment kernels for every K bin of the batch.
+int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
+  int rc;
+  if (!direct && (rc = ensure_chr_table(c))) return rc;
+  if ((rc = ensure_scratch(c))) return rc;
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(int32_t), s));
+  dh::SplitArgs a{};
+  a.junc = b->junc.p;
+  a.cons_off = b->cons_off.p;
+  a.cons_len = b->cons_len.p;
+  a.cons_base = b->with_msa ? b->out_blob.p : b->seq_blob.p;
+  a.chr_seq = c->d_chr_ptr.p;
+  a.chr_len = c->d_chr_len.p;
+  a.n_chr = (int)c->chr_dev.size();
+  a.p = c->params;
+  a.res = b->res.p;
+  a.out_blob = b->out_blob.p;
+  a.out_stride = b->out_stride;
+  a.scratch = c->scratch.p;
+  a.scratch_words = c->scratch_words;
+  a.want_alignment = b->want_alignment;
+  if (direct) {
+    a.ref_base = b->ref_blob.p;
+    a.ref_off = b->ref_off.p;
+    a.ref_len = b->ref_len.p;
+  }
+  for (int K = 1; K <= dh::KMAX; ++K) {
+    int cnt = b->bin_count[K];
+    if (cnt == 0) continue;
+    a.work_list = b->work.p + b->bin_first[K];
+    a.n_work = cnt;
+    a.work_counter = c->counters.p + K;
+    int grid = std::min(cnt, c->scratch_blocks);
+    switch (K) {
+      case 1: launch_split<1>(a, grid, s); break;
+      case 2: launch_split<2>(a, grid, s); break;
+      case 3: launch_split<3>(a, grid, s); break;
+      case 4: launch_split<4>(a, grid, s); break;
+      default: launch_split<5>(a, grid, s); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// K-bins junctions by consensus length; junctions beyond the kernel limit go to
+// the KMAX bin, where the kernel flags them with DELLYHIP_E_LIMIT.
+int build_bins(dellyhip_batch* b) {
+  b->bin_first.assign(dh::KMAX + 2, 0);
+  b->bin_count.assign(dh::KMAX + 2, 0);
+  std::vector<int32_t> k(b->n);
+  for (int i = 0; i < b->n; ++i) {
+    int m = b->h_cons_len[i];
+    int kk = (m + 1 + dh::WAVE - 1) / dh::WAVE;
+    kk = std::max(1, std::min(kk, dh::KMAX));
+    k[i] = kk;
+    b->bin_count[kk]++;
+  }
+  int acc = 0;
+  for (int K = 1; K <= dh::KMAX; ++K) {
+    b->bin_first[K] = acc;
+    acc += b->bin_count[K];
+  }
+  std::vector<int32_t> fill(dh::KMAX + 2, 0), work(b->n);
+  for (int i = 0; i < b->n; ++i) work[b->bin_first[k[i]] + fill[k[i]]++] = i;
+  int rc = b->work.alloc(b->n);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(b->work.p, work.data(), b->n * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dellyhip_last_error(void) { return g_err.c_str(); }
+
+void dellyhip_default_params_sr(dellyhip_params* p) {
+  *p = dellyhip_params{5, -4, -10, -1, 2, 13, 1000, 100, 0.95f, 0};
+}
+void dellyhip_default_params_lr(dellyhip_params* p) {
+  *p = dellyhip_params{5, -4, -10, -1, 3, 100, 10000, 1000, 0.9f, 0};
+}
+
+int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** out) {
+  if (!params || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(DELLYHIP_E_NODEVICE, "no HIP device", e);
+  if (device < 0 || device >= ndev) return fail(DELLYHIP_E_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(DELLYHIP_E_NODEVICE, "device is not gfx950 (kernels are built for MI355X only)");
+  dellyhip_ctx* c = new dellyhip_ctx();
+  c->device = device;
+  c->params = *params;
+  c->n_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(DELLYHIP_E_RUNTIME, "hipStreamCreate", e);
+  }
+  *out = c;
+  return 0;
+}
+
+void dellyhip_destroy(dellyhip_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  for (auto p : c->chr_dev)
+    if (p) hipFree(p);
+  c->d_chr_ptr.release();
+  c->d_chr_len.release();
+  c->scratch.release();
+  c->counters.release();
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64_t len) {
+  if (!c || chr < 0 || len < 0 || (!seq && len)) return fail(DELLYHIP_E_ARG, "bad chromosome");
+  HIPCHK(hipSetDevice(c->device));
+  if ((size_t)chr >= c->chr_dev.size()) {
+    c->chr_dev.resize(chr + 1, nullptr);
+    c->chr_len.resize(chr + 1, 0);
+  }
+  if (c->chr_dev[chr]) hipFree(c->chr_dev[chr]);
+  uint8_t* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
+  if (e != hipSuccess) return fail(DELLYHIP_E_NOMEM, "hipMalloc(chromosome)", e);
+  HIPCHK(hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice));
+  c->chr_dev[chr] = d;
+  c->chr_len[chr] = len;
+  c->chr_dirty = true;
+  return 0;
+}
+
+void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
+  if (!b) return;
+  if (c) hipSetDevice(c->device);
+  if (b->pending && c) hipStreamSynchronize(c->stream);
+  b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
+  b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release();
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev2) hipEventDestroy(b->ev2);
+  delete b;
+}
+
+static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                             const uint64_t* seq_off, uint64_t n_seq, int with_msa, int want_alignment,
+                             dellyhip_batch** out) {
+  if (!c || !out || n < 0 || (n && (!junc || !seq_off))) return fail(DELLYHIP_E_ARG, "bad batch arguments");
+  HIPCHK(hipSetDevice(c->device));
+  for (int i = 0; i < n; ++i) {
+    const dellyhip_junction& J = junc[i];
+    if (J.n_seq < 0 || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
+    if (!with_msa && J.n_seq != 1) return fail(DELLYHIP_E_ARG, "align_consensus needs exactly one sequence per junction");
+    if (J.chr < 0 || J.chr2 < 0 || (size_t)J.chr >= c->chr_dev.size() || (size_t)J.chr2 >= c->chr_dev.size() ||
+        !c->chr_dev[J.chr] || !c->chr_dev[J.chr2])
+      return fail(DELLYHIP_E_ARG, "junction refers to a chromosome that was not uploaded");
+  }
+  dellyhip_batch* b = new dellyhip_batch();
+  b->n = n;
+  b->n_seq = n_seq;
+  b->with_msa = with_msa;
+  b->want_alignment = want_alignment;
+  b->h_junc.assign(junc, junc + n);
+  b->out_stride = dh::OUT_CONS_CAP + dh::OUT_ALLELE_CAP + (want_alignment ? dh::OUT_ALN_CAP : 0);
+  b->out_stride = (b->out_stride + 15) & ~15ull;
+  uint64_t blob_bytes = n_seq ? seq_off[n_seq] : 0;
+  int rc = 0;
+  auto bail = [&](int r) { dellyhip_batch_free(c, b); return r; };
+  if ((rc = b->junc.alloc(std::max(n, 1)))) return bail(rc);
+  if ((rc = b->seq_blob.alloc(std::max<uint64_t>(blob_bytes, 1)))) return bail(rc);
+  if ((rc = b->seq_off.alloc(n_seq + 1))) return bail(rc);
+  if ((rc = b->cons_off.alloc(std::max(n, 1)))) return bail(rc);
+  if ((rc = b->cons_len.alloc(std::max(n, 1)))) return bail(rc);
+  if ((rc = b->res.alloc(std::max(n, 1)))) return bail(rc);
+  if ((rc = b->out_blob.alloc(std::max<uint64_t>((uint64_t)n * b->out_stride, 1)))) return bail(rc);
+  hipError_t e;
+  if (n) {
+    e = hipMemcpy(b->junc.p, junc, n * sizeof(dellyhip_junction), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D junctions", e));
+    if (blob_bytes) {
+      e = hipMemcpy(b->seq_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D sequences", e));
+    }
+    e = hipMemcpy(b->seq_off.p, seq_off, (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D offsets", e));
+  }
+  e = hipMemset(b->res.p, 0, std::max(n, 1) * sizeof(dellyhip_result));
+  if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset results", e));
+  b->h_cons_len.resize(n);
+  if (!with_msa) {
+    std::vector<uint64_t> coff(n);
+    for (int i = 0; i < n; ++i) {
+      coff[i] = seq_off[junc[i].seq_first];
+      b->h_cons_len[i] = (int32_t)(seq_off[junc[i].seq_first + 1] - seq_off[junc[i].seq_first]);
+    }
+    if (n) {
+      e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
+      e = hipMemcpy(b->cons_len.p, b->h_cons_len.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
+    }
+    if ((rc = build_bins(b))) return bail(rc);
+  } else {
+    // consensus is produced on the device at out_blob + i*stride
+    std::vector<uint64_t> coff(n);
+    for (int i = 0; i < n; ++i) coff[i] = (uint64_t)i * b->out_stride;
+    if (n) {
+      e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
+    }
+    if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride))) return bail(fail(rc, "msa_prepare: junction exceeds MSA kernel limits"));
+    if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+    if ((rc = b->work.alloc(std::max(n, 1)))) return bail(rc);
+  }
+  hipEventCreate(&b->ev0);
+  hipEventCreate(&b->ev1);
+  hipEventCreate(&b->ev2);
+  *out = b;
+  return 0;
+}
+
+int dellyhip_batch_upload(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                          const uint64_t* seq_off, uint64_t n_seq, int with_msa, dellyhip_batch** out) {
+  return batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, with_msa, 0, out);
+}
+
+int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (b->n == 0) return 0;
+  int rc;
+  HIPCHK(hipEventRecord(b->ev0, s));
+  if (b->with_msa) {
+    if ((rc = ensure_scratch(c))) return rc;
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(int32_t), s));
+    dh::MsaArgs ma{};
+    ma.junc = b->junc.p;
+    ma.seq_blob = b->seq_blob.p;
+    ma.seq_off = b->seq_off.p;
+    ma.p = c->params;
+    ma.res = b->res.p;
+    ma.out_blob = b->out_blob.p;
+    ma.out_stride = b->out_stride;
+    ma.cons_len = b->cons_len.p;
+    ma.ws = b->msa_ws.p;
+    ma.ws_stride = b->msa_ws_stride;
+    ma.n_work = b->n;
+    ma.work_counter = c->counters.p;
+    int grid = std::min(b->n, c->n_cu * 8);
+    if ((rc = dh::msa_launch(ma, grid, s))) return fail(rc, "msa_launch");
+    HIPCHK(hipGetLastError());
+    // consensus lengths decide the K bin of the split kernel
+    HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if ((rc = build_bins(b))) return rc;
+  }
+  HIPCHK(hipEventRecord(b->ev1, s));
+  if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
+  HIPCHK(hipEventRecord(b->ev2, s));
+  b->pending = true;
+  b->launches++;
+  return 0;
+}
+
+int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
+  if (!b->pending) return 0;
+  HIPCHK(hipEventSynchronize(b->ev2));
+  float a = 0, d = 0;
+  HIPCHK(hipEventElapsedTime(&a, b->ev0, b->ev1));
+  HIPCHK(hipEventElapsedTime(&d, b->ev1, b->ev2));
+  b->ms_msa += a;
+  b->ms_split += d;
+  b->pending = false;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "kernel execution", e);
+  return 0;
+}
+
+int dellyhip_batch_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_split, double* ms_msa, int32_t* launches) {
+  if (!b) return fail(DELLYHIP_E_ARG, "null argument");
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc) return rc;
+  int L = std::max(1, b->launches);
+  if (ms_split) *ms_split = b->ms_split / L;
+  if (ms_msa) *ms_msa = b->ms_msa / L;
+  if (launches) *launches = b->launches;
+  b->ms_split = b->ms_msa = 0;
+  b->launches = 0;
+  return 0;
+}
+
+int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* results, char* out_blob,
+                         uint64_t out_blob_cap, uint64_t* out_blob_len) {
+  if (!c || !b || (!results && b->n)) return fail(DELLYHIP_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc) return rc;
+  uint64_t used = 0;
+  if (b->n) {
+    HIPCHK(hipMemcpy(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> tmp((size_t)b->n * b->out_stride);
+    HIPCHK(hipMemcpy(tmp.data(), b->out_blob.p, tmp.size(), hipMemcpyDeviceToHost));
+    // compact the fixed-stride device blob into the caller's blob
+    bool overflow = false;
+    auto put = [&](uint64_t& off, uint64_t len) {
+      if (len == 0) { off = 0; return; }
+      if (!out_blob || used + len > out_blob_cap) { overflow = true; off = 0; used += len; return; }
+      memcpy(out_blob + used, tmp.data() + off, len);
+      off = used;
+      used += len;
+    };
+    for (int i = 0; i < b->n; ++i) {
+      dellyhip_result& R = results[i];
+      put(R.cons_off, (uint64_t)std::max(R.cons_len, 0));
+      put(R.allele_off, (uint64_t)std::max(R.allele_len, 0));
+      put(R.aln_off, 2ull * (uint64_t)std::max(R.aln_len, 0));
+    }
+    if (overflow) {
+      if (out_blob_len) *out_blob_len = used;
+      return fail(DELLYHIP_E_ARG, "out_blob too small");
+    }
+  }
+  if (out_blob_len) *out_blob_len = used;
+  return 0;
+}
+
+static int run_host_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                          const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results, char* out_blob,
+                          uint64_t cap, uint64_t* used, int with_msa, int want_alignment) {
+  dellyhip_batch* b = nullptr;
+  int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, with_msa, want_alignment, &b);
+  if (rc) return rc;
+  rc = dellyhip_batch_run(c, b, nullptr);
+  if (!rc) rc = dellyhip_batch_fetch(c, b, results, out_blob, cap, used);
+  dellyhip_batch_free(c, b);
+  return rc;
+}
+
+int dellyhip_align_consensus_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                                   const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results,
+                                   char* out_blob, uint64_t cap, uint64_t* used, int want_alignment) {
+  return run_host_batch(c, n, junc, seq_blob, seq_off, n_seq, results, out_blob, cap, used, 0, want_alignment);
+}
+
+int dellyhip_refine_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                          const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results, char* out_blob,
+                          uint64_t cap, uint64_t* used, int want_alignment) {
+  return run_host_batch(c, n, junc, seq_blob, seq_off, n_seq, results, out_blob, cap, used, 1, want_alignment);
+}
+
+int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,
+                         int32_t aln_cap, int32_t* aln_len, int32_t* found) {
+  if (!c || !s1 || !s2 || !aln_len || !found || m < 0 || n < 0) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (m > dh::MMAX || n > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "longNeedle operand exceeds the short-read kernel limits");
+  HIPCHK(hipSetDevice(c->device));
+  dellyhip_batch* b = new dellyhip_batch();
+  b->n = 1;
+  b->want_alignment = 1;
+  b->out_stride = (dh::OUT_CONS_CAP + dh::OUT_ALLELE_CAP + dh::OUT_ALN_CAP + 15) & ~15ull;
+  dellyhip_junction J{};
+  J.svt = 2;
+  J.n_seq = 1;
+  b->h_junc.assign(1, J);
+  b->h_cons_len.assign(1, m);
+  int rc = 0;
+  auto bail = [&](int r) { dellyhip_batch_free(c, b); return r; };
+  uint64_t zero = 0;
+  if ((rc = b->junc.alloc(1)) || (rc = b->seq_blob.alloc(std::max(m, 1))) || (rc = b->cons_off.alloc(1)) ||
+      (rc = b->cons_len.alloc(1)) || (rc = b->res.alloc(1)) || (rc = b->out_blob.alloc(b->out_stride)) ||
+      (rc = b->ref_blob.alloc(std::max(n, 1))) || (rc = b->ref_off.alloc(1)) || (rc = b->ref_len.alloc(1)))
+    return bail(rc);
+  hipMemcpy(b->junc.p, &J, sizeof J, hipMemcpyHostToDevice);
+  hipMemcpy(b->seq_blob.p, s1, m, hipMemcpyHostToDevice);
+  hipMemcpy(b->cons_off.p, &zero, 8, hipMemcpyHostToDevice);
+  hipMemcpy(b->cons_len.p, &m, 4, hipMemcpyHostToDevice);
+  hipMemcpy(b->ref_blob.p, s2, n, hipMemcpyHostToDevice);
+  hipMemcpy(b->ref_off.p, &zero, 8, hipMemcpyHostToDevice);
+  hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
+  hipMemset(b->res.p, 0, sizeof(dellyhip_result));
+  if ((rc = build_bins(b))) return bail(rc);
+  hipEventCreate(&b->ev0); hipEventCreate(&b->ev1); hipEventCreate(&b->ev2);
+  rc = dellyhip_batch_run(c, b, nullptr);
+  dellyhip_result R;
+  std::vector<char> blob(b->out_stride);
+  uint64_t used = 0;
+  if (!rc) rc = dellyhip_batch_fetch(c, b, &R, blob.data(), blob.size(), &used);
+  if (!rc) {
+    if (R.status) rc = fail(R.status, "longNeedle: kernel limit");
+    else {
+      *found = R.ok;
+      *aln_len = R.aln_len;
+      if (R.ok) {
+        if (R.aln_len > aln_cap || !align_rows) rc = fail(DELLYHIP_E_ARG, "align_rows too small");
+        else {
+          memcpy(align_rows, blob.data() + R.aln_off, R.aln_len);
+          memcpy(align_rows + aln_cap, blob.data() + R.aln_off + R.aln_len, R.aln_len);
+        }
+      }
+    }
+  }
+  dellyhip_batch_free(c, b);
+  return rc;
+}
+
+int dellyhip_lcs(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, int32_t* out) {
+  if (!c || !out) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  return dh::msa_single_lcs(c->stream, s1, m, s2, n, out) ? fail(DELLYHIP_E_RUNTIME, "lcs") : 0;
+}
+
+int dellyhip_gotoh(dellyhip_ctx* c, const char* a1, int32_t r1, int32_t m, const char* a2, int32_t r2, int32_t n,
+                   char* align_out, int32_t cap, int32_t* len, int32_t* score) {
+  if (!c || !len || !score) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = dh::msa_single_gotoh(c->stream, c->params, a1, r1, m, a2, r2, n, align_out, cap, len, score);
+  return rc ? fail(rc, "gotoh") : 0;
+}
+
+int dellyhip_msa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off, char* cs,
+                 int32_t cs_cap, int32_t* cs_len, int32_t* rows) {
+  if (!c || !cs_len || !rows || n_reads < 0) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = dh::msa_single(c->stream, c->params, c->n_cu, n_reads, seq_blob, seq_off, cs, cs_cap, cs_len, rows);
+  return rc ? fail(rc, "msa") : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// split_kernel.hpp -- gfx950 device code for alignConsensus() (BASELINE unit U):
+//   _initBreakpoint/_getSVRef (src/tags.h:151-172, src/split.h:70-163)
+//   longNeedle                (src/needle.h:45-222, AlignConfig<true,false>, +1/-1/-1)
+//   _findSplit/_percentIdentity/_findHomology/longestHomology/_coordTransform,
+//   exact alleles             (src/split.h:166-375,606-637, src/needle.h:13-42)
+//
+// One junction per 64-lane wavefront.  Lanes own K consecutive DP rows
+// ("slots" s = lane*K+i), anti-diagonal skew of one column per lane, row
+// hand-off between neighbouring lanes with DPP wave shifts, no LDS traffic in
+// the recurrence.  Written for CDNA4 only.
+//
+// DP domain: V'[s][c] = score[s][c] + s.  With match +1 / mismatch -1 / gap -1
+// this turns the vertical move into a plain copy, the diagonal into +2 / +0 and
+// makes column 0 identically 0 ("split kernel").
+//
+// Pass structure per junction
+//   R-pass : reverse-complement DP (rev of needle.h:74-81).  Emits, per cell, a
+//            2-bit code of how the row's running maximum (bestRev, :96-103)
+//            moved: {below, tie, +1, +2}.  Codes form a per-lane LIFO stack in
+//            global scratch (coalesced dwords, 16 cells each).
+//   M-pass : forward DP with MIRRORED slots (row r = m - s, lane 63 leads), so
+//            that the lane that owns M row r pops exactly the codes it pushed
+//            for rev row m - r, in reverse order: bestRev[m-r][n-c] is rebuilt
+//            incrementally and the join of needle.h:104-115 is evaluated on
+//            the fly.  No score matrix is ever stored.
+//   trace  : the two tracebacks (needle.h:154-192) need direction codes only on
+//            rows <= consLeft / consRight and columns <= refLeft / refRight;
+//            those sub-matrices are recomputed with 2-bit direction output.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dellyhip.h"
+
+namespace dh {
+
+constexpr int WAVE = 64;
+constexpr int NMAX = 2048;            // max |svRefStr| of the short-read kernel
+constexpr int KMAX = 5;               // rows per lane: |consensus| <= 64*KMAX-1
+constexpr int MMAX = WAVE * KMAX - 1; // 319
+constexpr int TRACE_CAP = MMAX + NMAX + 8;
+constexpr int MASKW = (MMAX + NMAX + 127) / 64;  // alignment columns / 64
+constexpr int NEGBIG = -(1 << 28);
+constexpr int NOMATCH = 0x1FF;        // row "character" that equals no byte
+constexpr int SCALE_SHIFT = 12;       // M-pass runs on scores << 12 (n < 4096)
+
+struct SplitArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* cons_base;     // consensus i = cons_base[cons_off[i] .. +cons_len[i])
+  const uint64_t* cons_off;
+  const int32_t* cons_len;
+  const uint8_t* const* chr_seq;  // device table of device pointers
+  const int64_t* chr_len;
+  int32_t n_chr;
+  dellyhip_params p;
+  dellyhip_result* res;
+  uint8_t* out_blob;            // fixed stride per junction
+  uint64_t out_stride;          // [cons MMAX+1][allele ALLELE_CAP][aln 2*TRACE_CAP]
+  uint32_t* scratch;            // per resident block
+  uint64_t scratch_words;       // words per block
+  const uint8_t* ref_base;      // direct mode (single longNeedle): s2 given, no breakpoint logic
+  const uint64_t* ref_off;
+  const int32_t* ref_len;
+  const int32_t* work_list;     // junction indices for this launch (one K bin)
+  int32_t n_work;
+  int32_t* work_counter;        // zeroed before launch (the atomic of shortpe.h:181)
+  int32_t want_alignment;
+};
+
+constexpr int OUT_CONS_CAP = MMAX + 1;
+constexpr int OUT_ALLELE_CAP = NMAX + MMAX + 8;
+constexpr int OUT_ALN_CAP = 2 * TRACE_CAP;
+
+// ---- small device helpers -------------------------------------------------
+
+__device__ __forceinline__ int dpp_from_prev(int src, int old) {  // lane l <- lane l-1
+  return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_from_next(int src, int old) {  // lane l <- lane l+1
+  return __builtin_amdgcn_update_dpp(old, src, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ uint32_t ld_scratch(const uint32_t* p) {
+  // L1-bypassing load: scratch words are re-written by this wave for every junction
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint8_t upc(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+// complement of an (already upper-cased) base; 0 when outside ACGTN
+__device__ __forceinline__ uint8_t comp_acgtn(uint8_t u) {
+  return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : u == 'N' ? 'N' : 0;
+}
+// the output switch of needle.h:209-217 (adds '-' -> '-', everything else -> 0)
+__device__ __forceinline__ uint8_t outmap(uint8_t ch) {
+  return ch == '-' ? '-' : comp_acgtn(ch);
+}
+
+// per-wave LDS image
+struct __attribute__((aligned(16))) WaveLds {
+  uint8_t cons[MMAX + 1];   // s1
+  uint8_t rcons[MMAX + 1];  // reverseComplement(s1), util.h:549-563 semantics
+  uint8_t ref[NMAX];        // s2 = svRefStr
+  uint8_t rref[NMAX];       // reverseComplement(s2)
+  uint8_t trF[TRACE_CAP];   // forward traceback ops in push order (0 's',1 'v',2 'h')
+  uint8_t trR[TRACE_CAP];
+  unsigned long long mV[MASKW], mR[MASKW], mE[MASKW];  // column masks: var/ref present, equal
+  int32_t cumV[MASKW + 1], cumR[MASKW + 1];
+};
+
+// reference-window segment (piece of _getSVRef's concatenation)
+struct Seg {
+  const uint8_t* base;  // chromosome pointer
+  int32_t beg, len;     // [beg, beg+len)
+  int32_t rc;           // split.h:78-91 style reverse complement
+};
+
+// ---- DP passes --------------------------------------------------------------
+
+// R-pass.  rows: slot s (valid 1..m) holds rcons[s-1]; columns: rref[c-1].
+// Pushes (steps+15)/16 blocks of K*64 dwords.  Returns per-slot final V' and
+// running max.
+template <int K>
+__device__ __forceinline__ void pass_R(const WaveLds& L, int m, int n, uint32_t* stack, int lane,
+                                       int (&hfin)[K], int (&brfin)[K]) {
+  int a[K], hg[K], h[K], br[K];
+  uint32_t acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int s = lane * K + i;
+    a[i] = (s >= 1 && s <= m) ? (int)L.rcons[s - 1] : NOMATCH;
+    hg[i] = (s >= 1 && s < m) ? -1 : 0;
+    h[i] = 0;
+    br[i] = 0;
+    acc[i] = 0;
+  }
+  const int T = n + 63;
+  const int nblk = (T + 15) >> 4;
+  int upPrev = NEGBIG;
+  int b = NOMATCH;
+  int c = -lane;  // column of this lane at step t is t - lane; incremented before use
+  for (int blk = 0; blk < nblk; ++blk) {
+    // characters for lane 0 of the next 16 steps: rref[blk*16 + f], f = 0..15
+    int ci = blk * 16 + (lane & 15);
+    int chunk = (ci < n) ? (int)L.rref[ci] : NOMATCH;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      int newc = __builtin_amdgcn_readlane(chunk, f);
+      b = dpp_from_prev(b, newc);
+      int recv = dpp_from_prev(h[K - 1], NEGBIG);
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)n) {
+        int diag = upPrev, up = recv;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          int x = diag + ((a[i] == b) ? 2 : 0);
+          int z = h[i] + hg[i];
+          int nv = max3i(x, up, z);
+          diag = h[i];
+          up = nv;
+          h[i] = nv;
+          int d = nv - br[i];
+          br[i] = max(br[i], nv);
+          int dm = max(d, -1);
+          acc[i] = acc[i] + ((uint32_t)dm << (2 * f));
+        }
+      }
+      upPrev = recv;
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      stack[((size_t)blk * K + i) * WAVE + lane] = acc[i] + 0x55555555u;
+      acc[i] = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    hfin[i] = h[i];
+    brfin[i] = br[i];
+  }
+}
+
+// M-pass with join.  Mirrored slots: slot s is M row r = m - s; lane 63 leads.
+// brfin[] = final running maxima of the R-pass (same slots).  Outputs: the
+// per-slot best join key ((sum' << 12) | (4095 - c)) and the final V' of row m.
+template <int K>
+__device__ __forceinline__ void pass_M(const WaveLds& L, int m, int n, const uint32_t* stack, int lane,
+                                       const int (&brfin)[K], int (&bestkey)[K], int& hrow_m) {
+  int a[K], hg[K], h[K], bm[K], g[K];
+  uint32_t dw[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int s = lane * K + i;
+    int r = m - s;
+    a[i] = (r >= 1) ? (int)L.cons[r - 1] : NOMATCH;
+    hg[i] = (r >= 1 && r < m) ? -(1 << SCALE_SHIFT) : 0;
+    h[i] = 0;
+    bm[i] = 0;
+    g[i] = (r >= 0) ? (brfin[i] << SCALE_SHIFT) : NEGBIG;
+    bestkey[i] = (r >= 0) ? (bm[i] + g[i] + 4095) : (int)0x80000000;  // column 0 candidate
+    dw[i] = 0;
+  }
+  const int T = n + 63;
+  const int nblk = (T + 15) >> 4;
+  int upPrev = NEGBIG;
+  int b = NOMATCH;
+  // consumer step t = T - t' + 1, t' descending from nblk*16; column c = t - 63 + lane
+  int c = (T - nblk * 16) - 63 + lane;  // value at "t'= nblk*16 + 1"; incremented before use
+  for (int blk = nblk - 1; blk >= 0; --blk) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      uint32_t w = ld_scratch(&stack[((size_t)blk * K + i) * WAVE + lane]);
+      // codes {0 below,1 tie,2 +1,3 +2} -> delta fields {0,0,1,2}
+      uint32_t hi = (w >> 1) & 0x55555555u, lo = w & 0x55555555u;
+      dw[i] = (hi & ~lo) | ((hi & lo) << 1);
+    }
+    // lane 63's characters for the 16 steps of this block: step f (15..0) has
+    // t = T - (blk*16+f+1) + 1, column t, character ref[t-1] = ref[T - blk*16 - f - 1]
+    int ci = T - blk * 16 - 16 + (lane & 15);  // f = 15 - (lane&15)
+    int chunk = (ci >= 0 && ci < n) ? (int)L.ref[ci] : NOMATCH;
+#pragma unroll
+    for (int f = 15; f >= 0; --f) {
+      int newc = __builtin_amdgcn_readlane(chunk, 15 - f);
+      b = dpp_from_next(b, newc);
+      int recv = dpp_from_next(h[0], NEGBIG);
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)n) {
+        int cinv = 4095 - c;
+        int diag = upPrev, up = recv;
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+          int x = diag + ((a[i] == b) ? (2 << SCALE_SHIFT) : 0);
+          int z = h[i] + hg[i];
+          int nv = max3i(x, up, z);
+          diag = h[i];
+          up = nv;
+          h[i] = nv;
+          bm[i] = max(bm[i], nv);
+          int delta = (int)((dw[i] >> (2 * f)) & 3u);
+          g[i] = g[i] - (delta << SCALE_SHIFT);
+          bestkey[i] = max(bestkey[i], bm[i] + g[i] + cinv);
+        }
+      }
+      upPrev = recv;
+    }
+  }
+  hrow_m = h[0];  // meaningful in lane 0 (slot 0 = row m)
+}
+
+// Direction pass: recomputes rows 0..rmax x columns 1..ncols of a needle
+// matrix (natural slots: slot s = row s) and stores 2-bit direction codes
+// (1 = vertical first, 2 = horizontal, 0 = diagonal: needle.h:160-170).
+template <int K>
+__device__ __forceinline__ void pass_dir(const uint8_t* rowstr, const uint8_t* colstr, int m, int rmax, int ncols,
+                                         uint32_t* dirs, int lane) {
+  int a[K], hg[K], h[K];
+  uint32_t acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    int s = lane * K + i;
+    a[i] = (s >= 1 && s <= m) ? (int)rowstr[s - 1] : NOMATCH;
+    hg[i] = (s >= 1 && s < m) ? -1 : 0;
+    h[i] = 0;
+    acc[i] = 0;
+  }
+  const int T = ncols + rmax / K;
+  const int nblk = (T + 15) >> 4;
+  int upPrev = NEGBIG;
+  int b = NOMATCH;
+  int c = -lane;
+  for (int blk = 0; blk < nblk; ++blk) {
+    int ci = blk * 16 + (lane & 15);
+    int chunk = (ci < ncols) ? (int)colstr[ci] : NOMATCH;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      int newc = __builtin_amdgcn_readlane(chunk, f);
+      b = dpp_from_prev(b, newc);
+      int recv = dpp_from_prev(h[K - 1], NEGBIG);
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)ncols) {
+        int diag = upPrev, up = recv;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          int x = diag + ((a[i] == b) ? 2 : 0);
+          int z = h[i] + hg[i];
+          int nv = max3i(x, up, z);
+          uint32_t code = (nv == up) ? 1u : ((nv == z) ? 2u : 0u);
+          diag = h[i];
+          up = nv;
+          h[i] = nv;
+          acc[i] |= code << (2 * f);
+        }
+      }
+      upPrev = recv;
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      dirs[((size_t)blk * K + i) * WAVE + lane] = acc[i];
+      acc[i] = 0;
+    }
+  }
+}
+
+// Serial traceback over the stored direction codes (uniform across the wave).
+// Pushes ops (0 's', 1 'v', 2 'h') until a border is reached; the remaining
+// straight run is returned as tailV / tailH.  Returns the number of pushed ops.
+template <int K>
+__device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, uint8_t* tr, int lane, int& tailV,
+                                         int& tailH) {
+  int tl = 0;
+  while (rr > 0 && cc > 0) {
+    int l = rr / K, i = rr - l * K;
+    int t = cc + l - 1;
+    uint32_t w = ld_scratch(&dirs[((size_t)(t >> 4) * K + i) * WAVE + l]);
+    w = (uint32_t)rfl((int)w);
+    uint32_t code = (w >> (2 * (t & 15))) & 3u;
+    if (lane == 0) tr[tl] = (uint8_t)code;
+    ++tl;
+    if (code == 1) --rr;
+    else if (code == 2) --cc;
+    else {
+      --rr;
+      --cc;
+    }
+  }
+  tailV = rr;  // column 0: only vertical moves remain
+  tailH = cc;  // row 0: only horizontal moves remain
+  return tl;
+}
+
+// ---- column-mask stream -----------------------------------------------------
+
+// appends `cnt` (<=64) bits of (v, r) at bit position pos of the LDS masks
+__device__ __forceinline__ void mask_append(WaveLds& L, int pos, int cnt, unsigned long long v, unsigned long long r,
+                                            int lane) {
+  if (cnt <= 0) return;
+  unsigned long long keep = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);
+  v &= keep;
+  r &= keep;
+  int w = pos >> 6, o = pos & 63;
+  if (lane == 0) {
+    L.mV[w] |= v << o;
+    L.mR[w] |= r << o;
+    if (o && (o + cnt > 64)) {
+      L.mV[w + 1] |= v >> (64 - o);
+      L.mR[w + 1] |= r >> (64 - o);
+    }
+  }
+}
+
+__device__ __forceinline__ int cnt_before(const unsigned long long* mk, const int32_t* cum, int pos) {
+  int w = pos >> 6, o = pos & 63;
+  unsigned long long x = mk[w] & ((o == 0) ? 0ull : (~0ull >> (64 - o)));
+  return cum[w] + __popcll(x);
+}
+// next position >= pos (< total) whose bit in (mk ^ inv) is set; returns total if none
+__device__ __forceinline__ int next_set(const unsigned long long* mk, unsigned long long inv, int pos, int total) {
+  while (pos < total) {
+    int w = pos >> 6, o = pos & 63;
+    unsigned long long x = (mk[w] ^ inv) >> o;
+    if (x) {
+      int p = pos + __builtin_ctzll(x);
+      return p < total ? p : total;
+    }
+    pos = (w + 1) << 6;
+  }
+  return total;
+}
+// position of the k-th (1-based) set bit of mk, or total if fewer
+__device__ __forceinline__ int select_bit(const unsigned long long* mk, const int32_t* cum, int k, int total) {
+  int nw = (total + 63) >> 6;
+  for (int w = 0; w < nw; ++w) {
+    if (cum[w + 1] >= k) {
+      unsigned long long x = mk[w];
+      int need = k - cum[w];
+      for (int q = 1; q < need; ++q) x &= x - 1;
+      return (w << 6) + __builtin_ctzll(x);
+    }
+  }
+  return total;
+}
+
+// longestHomology(s1, s2, -1)  src/needle.h:13-42 (band k = 1) on strided views
+// a[i] = A[ia + i*da], b[j] = B[ib + j*db]; m, n lengths.  Uniform serial code.
+__device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da, int m, const uint8_t* B, int ib,
+                                                int db, int n) {
+  // rolling band: prev row values at columns row-2..row (relative), cur row
+  // mat[row][col] valid for |row-col| <= 1; everything else is never read.
+  // prev[] indexed by h+1 (h = col-row in -1..1)
+  int pm1 = 0, p0 = 0, pp1 = 0;  // row-1: cols row-2, row-1, row   (h = -1,0,1 of row-1)
+  // row 0: mat[0][0] = 0, mat[0][1] = -1
+  p0 = 0;     // mat[0][0]   (h=0 of row 0)
+  pp1 = -1;   // mat[0][1]   (h=1 of row 0)
+  pm1 = 0;    // unused for row 0
+  for (int row = 1; row <= m; ++row) {
+    int best = -2;
+    int cm1 = 0, c0 = 0, cp1 = 0;
+    bool vm1 = false, v0 = false;
+    int ach = A[ia + (row - 1) * da];
+    // h = -1 : col = row-1
+    {
+      int col = row - 1;
+      if (col >= 1 && col <= n) {
+        // diag = mat[row-1][col-1] = (row-1, h=-1) -> pm1 ; for row==1,col==0 skipped
+        int v = pm1 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        // vertical: mat[row-1][col]: row-1-col = 0 in band -> p0
+        v = max(v, p0 - 1);
+        // horizontal: row-col+1 = 2 > k : not allowed
+        cm1 = v;
+        vm1 = true;
+        if (v > best) best = v;
+      } else if (col == 0 && row == 1) {
+        cm1 = -1;  // mat[1][0] initialised by needle.h:25
+        vm1 = true;
+      }
+    }
+    // h = 0 : col = row
+    {
+      int col = row;
+      if (col >= 1 && col <= n) {
+        int v = p0 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        v = max(v, pp1 - 1);                 // vertical: row-1-col = -1 in band
+        if (vm1) v = max(v, cm1 - 1);        // horizontal: row-col+1 = 1 in band
+        else v = max(v, 0 - 1);              // mat[row][col-1] never written: value-initialised 0
+        c0 = v;
+        v0 = true;
+        if (v > best) best = v;
+      }
+    }
+    // h = +1 : col = row+1
+    {
+      int col = row + 1;
+      if (col >= 1 && col <= n) {
+        int v = pp1 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        // vertical: row-1-col = -2 : not allowed
+        if (v0) v = max(v, c0 - 1);  // horizontal: row-col+1 = 0 in band
+        else v = max(v, 0 - 1);
+        cp1 = v;
+        if (v > best) best = v;
+      }
+    }
+    if (best < -1) return row - 1;
+    pm1 = cm1;
+    p0 = c0;
+    pp1 = cp1;
+  }
+  return 0;
+}
+
+}  // namespace dh

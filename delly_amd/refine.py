@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference's interface for the split-read refinement
+path, on top of the C-ABI in include/dellyhip.h (libdellyhip.so, hand-written
+HIP for gfx950).  Names follow the reference:
+
+    msa(c, sps, cs)                      src/msa.h:185-239
+    alignConsensus(c, hdr, seq, ...)     src/split.h:644-672
+    longNeedle(s1, s2, align, ...)       src/needle.h:45-222
+    gotoh(a1, a2, align, ...)            src/gotoh.h:71-174
+    lcs(s1, s2)                          src/msa.h:10-30
+
+There is no CPU path here: if the shared library or a gfx950 device is missing
+every call raises DellyHipError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdellyhip.so")
+
+EXPORTS = [
+    "dellyhip_create", "dellyhip_destroy", "dellyhip_last_error", "dellyhip_default_params_sr",
+    "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
+    "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
+    "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_long_needle",
+    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa",
+]
+
+
+class DellyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dellyhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DellyHipError(abi.E_NODEVICE, "libdellyhip.so is not built (run __graft_entry__.build())")
+        lib = C.CDLL(LIB_PATH)
+        lib.dellyhip_last_error.restype = C.c_char_p
+        lib.dellyhip_batch_free.restype = None
+        lib.dellyhip_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+def _u8(a):
+    if isinstance(a, (bytes, bytearray)):
+        return np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _p(a, typ=C.c_char_p):
+    return a.ctypes.data_as(typ)
+
+
+class Context:
+    """One context per GPU (per process rank): replaces the ThreadPool of src/shortpe.h:80."""
+
+    def __init__(self, params=None, device=0):
+        self.lib = load_library()
+        self.params = params if params is not None else abi.params_sr()
+        self._ctx = C.c_void_p()
+        rc = self.lib.dellyhip_create(C.byref(self.params), int(device), C.byref(self._ctx))
+        self._check(rc)
+        self._chroms = []
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DellyHipError(rc, self.lib.dellyhip_last_error().decode())
+
+    def close(self):
+        if self._ctx:
+            self.lib.dellyhip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # hdr->target_len[chr] + faidx_fetch_seq buffer (src/shortpe.h:88)
+    def set_chromosome(self, chr_index, seq):
+        seq = _u8(seq)
+        self._check(self.lib.dellyhip_set_chromosome(self._ctx, int(chr_index), _p(seq), C.c_int64(seq.size)))
+
+    def set_chromosomes(self, chroms):
+        for i, s in enumerate(chroms):
+            self.set_chromosome(i, s)
+
+    # ---- batched hot path ---------------------------------------------------
+    def _run_host(self, fn, junctions, seq_blob, seq_off, want_alignment):
+        n = int(junctions.shape[0])
+        junc = np.ascontiguousarray(junctions)
+        blob = _u8(seq_blob)
+        off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        res = np.zeros(n, dtype=abi.result_dtype())
+        cap = n * (6000 if want_alignment else 3100) + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        rc = fn(self._ctx, n, _p(junc, C.c_void_p), _p(blob), _p(off, C.POINTER(C.c_uint64)),
+                C.c_uint64(off.size - 1), _p(res, C.c_void_p), _p(out), C.c_uint64(cap), C.byref(used),
+                int(bool(want_alignment)))
+        self._check(rc)
+        return res, out[:used.value]
+
+    def align_consensus_batch(self, junctions, seq_blob, seq_off, want_alignment=False):
+        """alignConsensus(c, hdr, seq, sndSeq, sv) for every junction (unit U)."""
+        return self._run_host(self.lib.dellyhip_align_consensus_batch, junctions, seq_blob, seq_off, want_alignment)
+
+    def refine_batch(self, junctions, seq_blob, seq_off, want_alignment=False):
+        """msa() + alignConsensus() for every junction: loop body of src/shortpe.h:183-197."""
+        return self._run_host(self.lib.dellyhip_refine_batch, junctions, seq_blob, seq_off, want_alignment)
+
+    def refine(self, batch, want_alignment=False):
+        """Convenience for a synth.Batch."""
+        fn = self.refine_batch if batch.with_msa else self.align_consensus_batch
+        return fn(batch.junctions, batch.seq_blob, batch.seq_off, want_alignment)
+
+    # ---- device-resident batches --------------------------------------------
+    def upload(self, batch):
+        return ResidentBatch(self, batch)
+
+    # ---- single-item wrappers -------------------------------------------------
+    def long_needle(self, s1, s2):
+        """-> (found, row0, row1)"""
+        s1, s2 = _u8(s1), _u8(s2)
+        cap = s1.size + s2.size + 8
+        rows = np.zeros(2 * cap, dtype=np.uint8)
+        ln, found = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.dellyhip_long_needle(self._ctx, _p(s1), s1.size, _p(s2), s2.size, _p(rows), cap,
+                                                  C.byref(ln), C.byref(found)))
+        L = ln.value if found.value else 0
+        return bool(found.value), rows[:L].tobytes(), rows[cap:cap + L].tobytes()
+
+    def lcs(self, a, b):
+        a, b = _u8(a), _u8(b)
+        out = C.c_int32(0)
+        self._check(self.lib.dellyhip_lcs(self._ctx, _p(a), a.size, _p(b), b.size, C.byref(out)))
+        return out.value
+
+    def gotoh(self, a1, a2):
+        r1, m = len(a1), len(a1[0])
+        r2, n = len(a2), len(a2[0])
+        A1, A2 = _u8(b"".join(a1)), _u8(b"".join(a2))
+        cap = m + n + 8
+        out = np.zeros((r1 + r2) * cap, dtype=np.uint8)
+        ln, score = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.dellyhip_gotoh(self._ctx, _p(A1), r1, m, _p(A2), r2, n, _p(out), cap, C.byref(ln),
+                                            C.byref(score)))
+        L = ln.value
+        return score.value, [out[i * cap:i * cap + L].tobytes() for i in range(r1 + r2)]
+
+    def msa(self, reads):
+        """-> (rows, consensus)"""
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        blob = _u8(b"".join(reads))
+        cap = int(off[-1]) + 8
+        cs = np.zeros(cap, dtype=np.uint8)
+        ln, rows = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.dellyhip_msa(self._ctx, len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)), _p(cs), cap,
+                                          C.byref(ln), C.byref(rows)))
+        return rows.value, cs[:ln.value].tobytes()
+
+
+class ResidentBatch:
+    """Junction batch kept in HBM (bench / pipelined callers)."""
+
+    def __init__(self, ctx, batch):
+        self.ctx = ctx
+        self.n = batch.n
+        self._b = C.c_void_p()
+        junc = np.ascontiguousarray(batch.junctions)
+        blob = _u8(batch.seq_blob)
+        off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
+        rc = ctx.lib.dellyhip_batch_upload(ctx._ctx, self.n, _p(junc, C.c_void_p), _p(blob),
+                                           _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1),
+                                           int(bool(batch.with_msa)), C.byref(self._b))
+        ctx._check(rc)
+
+    def run(self, stream=None):
+        self.ctx._check(self.ctx.lib.dellyhip_batch_run(self.ctx._ctx, self._b, C.c_void_p(stream or 0)))
+
+    def sync(self):
+        self.ctx._check(self.ctx.lib.dellyhip_batch_sync(self.ctx._ctx, self._b))
+
+    def kernel_ms(self):
+        a, b, l = C.c_double(0), C.c_double(0), C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_batch_kernel_ms(self.ctx._ctx, self._b, C.byref(a), C.byref(b), C.byref(l)))
+        return a.value, b.value, l.value
+
+    def fetch(self):
+        res = np.zeros(self.n, dtype=abi.result_dtype())
+        cap = self.n * 3100 + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        self.ctx._check(self.ctx.lib.dellyhip_batch_fetch(self.ctx._ctx, self._b, _p(res, C.c_void_p), _p(out),
+                                                          C.c_uint64(cap), C.byref(used)))
+        return res, out[:used.value]
+
+    def free(self):
+        if self._b:
+            self.ctx.lib.dellyhip_batch_free(self.ctx._ctx, self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

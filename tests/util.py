@@ -1,0 +1,32 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+import pyoracle
+
+# fields that every implementation must agree on bit-for-bit
+CORE = ["svid", "ok", "sv_start", "sv_end", "ci_wiggle", "ins_len", "cons_bp", "hom_len", "sr_support",
+        "sr_align_quality", "c_start", "c_end", "r_start", "r_end", "hom_left", "hom_right", "cons_len",
+        "ref_len", "allele_len", "aln_len", "status"]
+# internals the reference API does not expose (port vs HIP only)
+INTERNAL = ["score_unsplit", "matches", "mismatches"]
+INTERNAL_FOUND = ["score_best", "cons_left", "ref_left", "ref_right"]
+
+
+def compare(res_a, blob_a, res_b, blob_b, fields=CORE, blobs=("cons", "allele", "aln"), label=""):
+    bad = []
+    assert res_a.shape == res_b.shape
+    for f in fields:
+        x, y = res_a[f], res_b[f]
+        if x.dtype.kind == "f":
+            neq = ~((x == y) | (np.isnan(x) & np.isnan(y)))
+        else:
+            neq = x != y
+        for i in np.nonzero(neq)[0][:5]:
+            bad.append("%s junction %d field %s: %r vs %r" % (label, i, f, x[i], y[i]))
+    for i in range(res_a.shape[0]):
+        for w in blobs:
+            if pyoracle.blob_field(res_a[i], blob_a, w) != pyoracle.blob_field(res_b[i], blob_b, w):
+                bad.append("%s junction %d blob %s differs" % (label, i, w))
+                if len(bad) > 20:
+                    break
+    assert not bad, "\n".join(bad[:20])
