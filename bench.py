@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: candidate split-read alignments/sec
+(DEL, 150 bp consensus, 1 kb reference window) on N MI355X.
+
+A "step" is one pass of the hot path (alignConsensus: window construction,
+longNeedle, split detection, coordinates) over one resident batch of synthetic
+junctions (BASELINE config 2: 10 000 junctions per GPU).  Inputs
+are in HBM before the timed region; result records stay in HBM and, for N > 1,
+are gathered to every rank with one RCCL all_gather per step (junctions shard
+across ranks, no other exchange).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task description) with the
+`roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_U = 1214        # SURVEY.md 8d / BASELINE.md 4: m + n + 64 B record at C2
+CELLS_PER_U = 2 * 151 * 1001  # fwd + rev DP cells
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+class _DevPtr:
+    """Wraps a raw device pointer for torch.as_tensor (RCCL needs a tensor)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(batch, budget_s=12.0):
+    """The reference's CPU path (oracle/_ref: its own headers) or the C port,
+    timed on this box's host cores with the reference's threading model
+    (src/shortpe.h:175-201) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    kind = "reference" if pyoracle.have_reference() else "port"
+    orc = pyoracle.Oracle(kind)
+    cores = os.cpu_count() or 1
+    from delly_amd import synth
+    # calibrate single-thread rate on a small sample
+    cal = _subbatch(batch, 64)
+    t0 = time.perf_counter()
+    orc.refine_batch(cal, want_alignment=False, n_threads=1)
+    t1 = time.perf_counter() - t0
+    per = t1 / cal.n
+    sub = _subbatch(batch, min(batch.n, max(cores * 8, 2000)))
+    t0 = time.perf_counter()
+    orc.refine_batch(sub, want_alignment=False, n_threads=cores)
+    first = time.perf_counter() - t0
+    reps = int(max(1, min(200, budget_s / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.refine_batch(sub, want_alignment=False, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": reps * sub.n / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
+            "sample": "%d x the first %d of the %d C2 junctions, %d std::thread workers on an atomic counter "
+                      "(src/shortpe.h:175-201 model, %.1f s); single-thread %.0f alignments/s"
+                      % (reps, sub.n, batch.n, cores, dt, 1.0 / per)}
+
+
+def _subbatch(batch, n):
+    from delly_amd import synth
+    n = min(n, batch.n)
+    first = int(batch.junctions["seq_first"][0])
+    last = int(batch.junctions["seq_first"][n - 1] + batch.junctions["n_seq"][n - 1])
+    return synth.Batch(batch.chroms, batch.junctions[:n].copy(), batch.seq_blob, batch.seq_off[:last + 1].copy(),
+                       batch.with_msa, batch.truth[:n])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--junctions", type=int, default=10000, help="junctions per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+
+    from delly_amd import build as dbuild
+    from delly_amd import abi, refine, synth
+    if rank == 0:
+        dbuild.build_lib()
+    if world > 1:
+        dist.barrier()
+
+    n = args.junctions
+    batch = synth.make_batch(n, mode="c2", first=rank * n)  # weak scaling: shard by junction index
+    ctx = refine.Context(device=local)
+    ctx.set_chromosomes(batch.chroms)
+    rb = ctx.upload(batch)
+    side = torch.cuda.Stream(device=local)  # kernels and the RCCL gather are ordered on this stream
+    stream = side.cuda_stream
+    ptr, nbytes = rb.device_results()
+    res_t = gathered = None
+    if world > 1:
+        res_t = torch.as_tensor(_DevPtr(ptr, nbytes), device="cuda:%d" % local)
+        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda:%d" % local)
+
+    def step():
+        with torch.cuda.stream(side):
+            rb.run(stream)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, res_t)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    rb.kernel_ms()  # reset the kernel timers
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_split, ms_msa, launches = rb.kernel_ms()
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # sanity: the timed work is the real work (every junction refined, parity spot check vs oracle in smoke())
+    res, _ = rb.fetch()
+    n_ok = int(res["ok"].sum())
+
+    if rank == 0:
+        total_units = world * n * args.steps
+        value = total_units / dt
+        ach = n * ALG_BYTES_PER_U / (ms_split * 1e-3) / 1e9 if ms_split > 0 else 0.0
+        out = {
+            "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
+            "value": value,
+            "unit": "alignments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU, 150 bp consensus x 1 kb "
+                                   "ref window, alignConsensus (longNeedle + split detection), bit-exact" % n,
+                       "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "split_align_kernel<3>", "kernel_ms": ms_split,
+                         "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
+                         "gcups": n * CELLS_PER_U / (ms_split * 1e-3) / 1e9 if ms_split > 0 else 0.0,
+                         "note": "path is integer-VALU bound with DP state on chip; HBM fraction is reported because "
+                                 "BASELINE asks for it (SURVEY.md 8d)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batch)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    rb.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 """ctypes mirror of include/dellyhip.h (the C-ABI of the MI355X split-read
 refinement path).  Pure declarations: the structs are shared by the product
-bindings (delly_amd.refine) and by the test-only oracle bindings
-(oracle/pyoracle.py), so parity tests compare identical record layouts.
+bindings (delly_amd.refine) and by the test-only checker bindings under oracle/,
+so parity tests compare identical record layouts.
 
 Reference types mirrored: the duck-typed TConfig fields (SURVEY.md 8b,
 src/delly.h:49-82), torali::StructuralVariantRecord (src/tags.h:93-130) and

@@ -45,7 +45,7 @@ struct DevBuf {
     return 0;
   }
   void release() {
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
   }
@@ -96,7 +96,8 @@ struct dellyhip_batch {
   DevBuf<uint8_t> msa_ws;
   uint64_t msa_ws_stride = 0;
   // timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  std::vector<hipEvent_t> ev;        // 3 events per launch since the last kernel_ms()
+  hipEvent_t last = nullptr;
   double ms_split = 0, ms_msa = 0;
   int launches = 0;
   bool pending = false;
@@ -209,6 +210,13 @@ extern "C" {
 
 const char* dellyhip_last_error(void) { return g_err.c_str(); }
 
+void dellyhip_abi_info(int32_t out[4]) {
+  out[0] = DELLYHIP_VERSION;
+  out[1] = (int32_t)sizeof(dellyhip_params);
+  out[2] = (int32_t)sizeof(dellyhip_junction);
+  out[3] = (int32_t)sizeof(dellyhip_result);
+}
+
 void dellyhip_default_params_sr(dellyhip_params* p) {
   *p = dellyhip_params{5, -4, -10, -1, 2, 13, 1000, 100, 0.95f, 0};
 }
@@ -242,14 +250,14 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
 
 void dellyhip_destroy(dellyhip_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   for (auto p : c->chr_dev)
-    if (p) hipFree(p);
+    if (p) (void)hipFree(p);
   c->d_chr_ptr.release();
   c->d_chr_len.release();
   c->scratch.release();
   c->counters.release();
-  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -260,7 +268,7 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
     c->chr_dev.resize(chr + 1, nullptr);
     c->chr_len.resize(chr + 1, 0);
   }
-  if (c->chr_dev[chr]) hipFree(c->chr_dev[chr]);
+  if (c->chr_dev[chr]) (void)hipFree(c->chr_dev[chr]);
   uint8_t* d = nullptr;
   hipError_t e = hipMalloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
   if (e != hipSuccess) return fail(DELLYHIP_E_NOMEM, "hipMalloc(chromosome)", e);
@@ -273,14 +281,12 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
 
 void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!b) return;
-  if (c) hipSetDevice(c->device);
-  if (b->pending && c) hipStreamSynchronize(c->stream);
+  if (c) (void)hipSetDevice(c->device);
+  if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
   b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release();
-  if (b->ev0) hipEventDestroy(b->ev0);
-  if (b->ev1) hipEventDestroy(b->ev1);
-  if (b->ev2) hipEventDestroy(b->ev2);
+  for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -354,9 +360,6 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
     if ((rc = b->work.alloc(std::max(n, 1)))) return bail(rc);
   }
-  hipEventCreate(&b->ev0);
-  hipEventCreate(&b->ev1);
-  hipEventCreate(&b->ev2);
   *out = b;
   return 0;
 }
@@ -372,7 +375,10 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   if (b->n == 0) return 0;
   int rc;
-  HIPCHK(hipEventRecord(b->ev0, s));
+  hipEvent_t e3[3];
+  for (int q = 0; q < 3; ++q) HIPCHK(hipEventCreate(&e3[q]));
+  for (int q = 0; q < 3; ++q) b->ev.push_back(e3[q]);
+  HIPCHK(hipEventRecord(e3[0], s));
   if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
     HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(int32_t), s));
@@ -397,9 +403,10 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     HIPCHK(hipStreamSynchronize(s));
     if ((rc = build_bins(b))) return rc;
   }
-  HIPCHK(hipEventRecord(b->ev1, s));
+  HIPCHK(hipEventRecord(e3[1], s));
   if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
-  HIPCHK(hipEventRecord(b->ev2, s));
+  HIPCHK(hipEventRecord(e3[2], s));
+  b->last = e3[2];
   b->pending = true;
   b->launches++;
   return 0;
@@ -408,15 +415,26 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
 int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
   if (!b->pending) return 0;
-  HIPCHK(hipEventSynchronize(b->ev2));
-  float a = 0, d = 0;
-  HIPCHK(hipEventElapsedTime(&a, b->ev0, b->ev1));
-  HIPCHK(hipEventElapsedTime(&d, b->ev1, b->ev2));
-  b->ms_msa += a;
-  b->ms_split += d;
+  HIPCHK(hipEventSynchronize(b->last));
+  for (size_t q = 0; q + 2 < b->ev.size(); q += 3) {
+    float a = 0, d = 0;
+    HIPCHK(hipEventElapsedTime(&a, b->ev[q], b->ev[q + 1]));
+    HIPCHK(hipEventElapsedTime(&d, b->ev[q + 1], b->ev[q + 2]));
+    b->ms_msa += a;
+    b->ms_split += d;
+  }
+  for (auto e : b->ev) (void)hipEventDestroy(e);
+  b->ev.clear();
   b->pending = false;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "kernel execution", e);
+  return 0;
+}
+
+int dellyhip_batch_device_results(dellyhip_ctx* c, dellyhip_batch* b, void** dptr, uint64_t* bytes) {
+  if (!c || !b || !dptr || !bytes) return fail(DELLYHIP_E_ARG, "null argument");
+  *dptr = b->res.p;
+  *bytes = (uint64_t)b->n * sizeof(dellyhip_result);
   return 0;
 }
 
@@ -513,16 +531,15 @@ int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char*
       (rc = b->cons_len.alloc(1)) || (rc = b->res.alloc(1)) || (rc = b->out_blob.alloc(b->out_stride)) ||
       (rc = b->ref_blob.alloc(std::max(n, 1))) || (rc = b->ref_off.alloc(1)) || (rc = b->ref_len.alloc(1)))
     return bail(rc);
-  hipMemcpy(b->junc.p, &J, sizeof J, hipMemcpyHostToDevice);
-  hipMemcpy(b->seq_blob.p, s1, m, hipMemcpyHostToDevice);
-  hipMemcpy(b->cons_off.p, &zero, 8, hipMemcpyHostToDevice);
-  hipMemcpy(b->cons_len.p, &m, 4, hipMemcpyHostToDevice);
-  hipMemcpy(b->ref_blob.p, s2, n, hipMemcpyHostToDevice);
-  hipMemcpy(b->ref_off.p, &zero, 8, hipMemcpyHostToDevice);
-  hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
-  hipMemset(b->res.p, 0, sizeof(dellyhip_result));
+  (void)hipMemcpy(b->junc.p, &J, sizeof J, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->seq_blob.p, s1, m, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->cons_off.p, &zero, 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->cons_len.p, &m, 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->ref_blob.p, s2, n, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->ref_off.p, &zero, 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
+  (void)hipMemset(b->res.p, 0, sizeof(dellyhip_result));
   if ((rc = build_bins(b))) return bail(rc);
-  hipEventCreate(&b->ev0); hipEventCreate(&b->ev1); hipEventCreate(&b->ev2);
   rc = dellyhip_batch_run(c, b, nullptr);
   dellyhip_result R;
   std::vector<char> blob(b->out_stride);

@@ -112,6 +112,9 @@ typedef struct dellyhip_ctx dellyhip_ctx;
 int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** out);
 void dellyhip_destroy(dellyhip_ctx* ctx);
 const char* dellyhip_last_error(void);
+/* out[0..3] = DELLYHIP_VERSION, sizeof(dellyhip_params), sizeof(dellyhip_junction),
+ * sizeof(dellyhip_result): lets a binding verify its struct layout without a GPU. */
+void dellyhip_abi_info(int32_t out[4]);
 /* Default parameters of `delly sr` (src/delly.h:393-398) and `delly lr`
  * (src/tegua.h:237-241). */
 void dellyhip_default_params_sr(dellyhip_params* p);
@@ -165,6 +168,10 @@ int dellyhip_batch_sync(dellyhip_ctx* ctx, dellyhip_batch* b);
 int dellyhip_batch_fetch(dellyhip_ctx* ctx, dellyhip_batch* b, dellyhip_result* results,
                          char* out_blob, uint64_t out_blob_cap, uint64_t* out_blob_len);
 void dellyhip_batch_free(dellyhip_ctx* ctx, dellyhip_batch* b);
+/* Device pointer / byte size of the result records (n x dellyhip_result) left in
+ * HBM by dellyhip_batch_run: lets a multi-GPU caller hand them to an RCCL
+ * gather without a host round trip. */
+int dellyhip_batch_device_results(dellyhip_ctx* ctx, dellyhip_batch* b, void** dptr, uint64_t* bytes);
 /* Average duration in milliseconds of the dominant kernel (split alignment)
  * over the launches since the last call, measured with hipEvents on the
  * launch stream; also returns the launch count. */

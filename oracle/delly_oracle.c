@@ -537,7 +537,7 @@ int dor_consensus(const dellyhip_params* p, const char* a, int r, int m, char* c
 /* guide tree: distanceMatrix + upgma  src/msa.h:32-89                        */
 
 static int guide_tree(int num, const char* blob, const uint64_t* off, int* d /* (2num+1)^2 */,
-                      int* p /* (2num+1) x 3 */) {
+                      int* p /* (2num+1) x 3 */, int* dcopy /* distance matrix before UPGMA, or NULL */) {
   int D = 2 * num + 1;
   for (int i = 0; i < D; ++i)
     for (int j = 0; j < D; ++j) d[i * D + j] = (j > i) ? -1 : 0; /* msa.h:192-195 (rest value-init 0) */
@@ -548,6 +548,7 @@ static int guide_tree(int num, const char* blob, const uint64_t* off, int* d /* 
       uint64_t mn = (uint64_t)(li < lj ? li : lj);
       d[i * D + j] = (int)(((uint64_t)(int64_t)(l * 100)) / mn); /* msa.h:41: int*100 / size_t */
     }
+  if (dcopy) memcpy(dcopy, d, sizeof(int) * (size_t)D * D);
   for (int i = 0; i < D; ++i) p[i * 3 + 0] = p[i * 3 + 1] = p[i * 3 + 2] = -1;
   int nn = num;
   for (; nn < 2 * num + 1; ++nn) {
@@ -579,9 +580,9 @@ static int guide_tree(int num, const char* blob, const uint64_t* off, int* d /* 
 
 int dor_guide_tree(int n_reads, const char* blob, const uint64_t* off, int* dflat, int* pflat) {
   int D = 2 * n_reads + 1;
-  int* d = dflat ? dflat : (int*)malloc(sizeof(int) * (size_t)D * D);
-  int root = guide_tree(n_reads, blob, off, d, pflat);
-  if (!dflat) free(d);
+  int* d = (int*)malloc(sizeof(int) * (size_t)D * D);
+  int root = guide_tree(n_reads, blob, off, d, pflat, dflat);
+  free(d);
   return root;
 }
 
@@ -609,7 +610,7 @@ static int msa_core(const dellyhip_params* p, int n_reads, const char* blob, con
   int D = 2 * n_reads + 1;
   int* d = (int*)malloc(sizeof(int) * (size_t)D * D);
   int* ph = (int*)malloc(sizeof(int) * (size_t)D * 3);
-  int root = guide_tree(n_reads, blob, off, d, ph);
+  int root = guide_tree(n_reads, blob, off, d, ph, NULL);
   amat al = palign(p, blob, off, ph, root);
   *cs = (char*)malloc((size_t)al.cols + 1);
   *cs_len = consensus_core(p, &al, *cs);

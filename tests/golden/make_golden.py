@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz from THE REFERENCE ITSELF (oracle/_ref: the
+reference's own headers compiled against oracle/shim).  The reference ships no
+tests or golden vectors, so these seeded inputs + reference
+outputs are the pinned vectors for the path.  Runs only where /root/reference
+exists; the .npz files are committed and travel.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import pyoracle  # noqa: E402
+from delly_amd import synth  # noqa: E402
+
+BATCHES = {
+    # name: (n, kwargs)
+    "u_c2": (96, dict(mode="c2", seed=42, first=0)),
+    "u_mixed": (120, dict(mode="mixed", seed=42, first=0)),
+    "full_c2_n8": (24, dict(mode="c2", seed=43, first=0, n_reads=8)),
+    "full_mixed_n5": (36, dict(mode="mixed", seed=44, first=0, n_reads=5)),
+    "full_c2_n20": (6, dict(mode="c2", seed=45, first=0, n_reads=20)),
+}
+
+
+def random_seq(rng, n, alphabet=b"ACGT"):
+    return bytes(rng.choice(list(alphabet), n).astype(np.uint8))
+
+
+def main():
+    pyoracle.build()
+    ref = pyoracle.Oracle("reference")
+    # --- batches ---------------------------------------------------------------
+    for name, (n, kw) in BATCHES.items():
+        b = synth.make_batch(n, **kw)
+        res, blob = ref.refine_batch(b, want_alignment=True)
+        np.savez_compressed(os.path.join(HERE, "batch_%s.npz" % name), n=n, kwargs=repr(kw), results=res, blob=blob)
+        print(name, "ok=%d/%d" % (int(res["ok"].sum()), n))
+    # --- primitives ------------------------------------------------------------
+    rng = np.random.default_rng(20260925)
+    prim = {}
+    # lcs
+    a = [random_seq(rng, int(rng.integers(1, 200))) for _ in range(40)]
+    b = [random_seq(rng, int(rng.integers(1, 200))) for _ in range(40)]
+    for i in range(0, 40, 4):  # related pairs
+        x = bytearray(a[i])
+        for k in rng.integers(0, len(x), max(1, len(x) // 20)):
+            x[k] = rng.choice(list(b"ACGT"))
+        b[i] = bytes(x)
+    prim["lcs_a"], prim["lcs_b"] = np.array(a, dtype=object), np.array(b, dtype=object)
+    prim["lcs_out"] = np.array([ref.lcs(x, y) for x, y in zip(a, b)], dtype=np.int32)
+    # reverseComplement incl. lower case / IUPAC quirk (util.h:549-563)
+    rc_in = [random_seq(rng, int(rng.integers(1, 60)), b"ACGTNacgtnRYKM-") for _ in range(30)]
+    prim["rc_in"] = np.array(rc_in, dtype=object)
+    prim["rc_out"] = np.array([ref.reverse_complement(x) for x in rc_in], dtype=object)
+    # longestHomology
+    ha, hb = [], []
+    for _ in range(60):
+        L = int(rng.integers(0, 40))
+        x = random_seq(rng, L)
+        y = bytearray(x + random_seq(rng, int(rng.integers(0, 10))))
+        for k in range(len(y)):
+            if rng.random() < 0.15:
+                y[k] = rng.choice(list(b"ACGT"))
+        if rng.random() < 0.3 and len(y) > 2:
+            del y[int(rng.integers(0, len(y)))]
+        ha.append(x)
+        hb.append(bytes(y))
+    prim["hom_a"], prim["hom_b"] = np.array(ha, dtype=object), np.array(hb, dtype=object)
+    prim["hom_out"] = np.array([ref.longest_homology(x, y) for x, y in zip(ha, hb)], dtype=np.int32)
+    # longNeedle on raw strings
+    ln_s1, ln_s2, ln_found, ln_r0, ln_r1 = [], [], [], [], []
+    for it in range(48):
+        n = int(rng.integers(40, 700))
+        m = int(rng.integers(10, 200))
+        alpha = b"ACGT" if it % 6 else b"ACGTNRacgt"
+        s2 = random_seq(rng, n, alpha)
+        if it % 5 == 4:
+            s1 = random_seq(rng, m, alpha)
+        else:
+            p = int(rng.integers(0, max(1, n // 2 - m // 2)))
+            q = int(rng.integers(n // 2, max(n // 2 + 1, n - m // 2)))
+            s1 = bytearray(s2[p:p + m // 2] + s2[q:q + (m - m // 2)])
+            for k in rng.integers(0, max(1, len(s1)), max(1, len(s1) // 40)):
+                if len(s1):
+                    s1[k] = rng.choice(list(b"ACGT"))
+            s1 = bytes(s1)
+        f, r0, r1, _ = ref.long_needle(s1, s2)
+        ln_s1.append(s1); ln_s2.append(s2); ln_found.append(int(f)); ln_r0.append(r0); ln_r1.append(r1)
+    prim["ln_s1"], prim["ln_s2"] = np.array(ln_s1, dtype=object), np.array(ln_s2, dtype=object)
+    prim["ln_found"] = np.array(ln_found, dtype=np.int32)
+    prim["ln_r0"], prim["ln_r1"] = np.array(ln_r0, dtype=object), np.array(ln_r1, dtype=object)
+    # msa / guide tree / gotoh / consensus on read sets
+    sets, msa_rows, msa_cs, roots, ds, ps = [], [], [], [], [], []
+    for it in range(16):
+        nr = int(rng.integers(2, 13))
+        base = random_seq(rng, 260)
+        reads = []
+        while len(reads) < nr:
+            o = int(rng.integers(0, 110))
+            L = int(rng.integers(90, 151))
+            x = bytearray(base[o:o + L])
+            for k in range(len(x)):
+                if rng.random() < 0.01:
+                    x[k] = rng.choice(list(b"ACGT"))
+            if it % 4 == 3 and rng.random() < 0.5 and len(x) > 20:  # an indel
+                del x[int(rng.integers(5, len(x) - 5))]
+            if bytes(x) not in reads:
+                reads.append(bytes(x))
+        rows, cs = ref.msa(reads)
+        root, d, p = ref.guide_tree(reads)
+        sets.append(np.array(reads, dtype=object)); msa_rows.append(rows); msa_cs.append(cs)
+        roots.append(root); ds.append(d); ps.append(p)
+    prim["msa_sets"] = np.array(sets, dtype=object)
+    prim["msa_rows"] = np.array(msa_rows, dtype=np.int32)
+    prim["msa_cs"] = np.array(msa_cs, dtype=object)
+    prim["tree_root"] = np.array(roots, dtype=np.int32)
+    prim["tree_d"] = np.array(ds, dtype=object)
+    prim["tree_p"] = np.array(ps, dtype=object)
+    # gotoh: leaf x leaf and profile x profile
+    g_a1, g_a2, g_score, g_rows = [], [], [], []
+    for it in range(12):
+        base = random_seq(rng, 200)
+        def var(o, L):
+            x = bytearray(base[o:o + L])
+            for k in range(len(x)):
+                if rng.random() < 0.02:
+                    x[k] = rng.choice(list(b"ACGT"))
+            return bytes(x)
+        x1, x2, x3, x4 = var(0, 120), var(20, 130), var(40, 120), var(10, 150)
+        if it % 2 == 0:
+            a1, a2 = [x1], [x2]
+        else:
+            _, a1 = ref.gotoh([x1], [x2])
+            _, a2 = ref.gotoh([x3], [x4])
+        sc, rows = ref.gotoh(a1, a2)
+        g_a1.append(np.array(a1, dtype=object)); g_a2.append(np.array(a2, dtype=object))
+        g_score.append(sc); g_rows.append(np.array(rows, dtype=object))
+    prim["gotoh_a1"] = np.array(g_a1, dtype=object)
+    prim["gotoh_a2"] = np.array(g_a2, dtype=object)
+    prim["gotoh_score"] = np.array(g_score, dtype=np.int32)
+    prim["gotoh_rows"] = np.array(g_rows, dtype=object)
+    prim["gotoh_cons"] = np.array([ref.consensus(list(r)) for r in g_rows], dtype=object)
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **prim)
+    print("primitives ok")
+
+
+if __name__ == "__main__":
+    main()

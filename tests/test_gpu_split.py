@@ -74,3 +74,50 @@ def test_edge_characters(gpu_ctx, port):
         f1, a0, a1 = gpu_ctx.long_needle(cons.tobytes(), ref.tobytes())
         f2, b0, b1, _ = port.long_needle(cons.tobytes(), ref.tobytes())
         assert (f1, a0, a1) == (f2, b0, b1), it
+
+
+def test_hip_reproduces_reference_golden_vectors(gpu_ctx):
+    """HIP path vs the committed outputs of the reference itself (tests/golden)."""
+    import glob
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    n_checked = 0
+    for path in sorted(glob.glob(os.path.join(gold, "batch_u_*.npz"))):
+        g = np.load(path, allow_pickle=True)
+        b = synth.make_batch(int(g["n"]), **eval(str(g["kwargs"])))
+        gr, gb = _run(gpu_ctx, b)
+        compare(gr, gb, g["results"], g["blob"], label=os.path.basename(path))
+        n_checked += b.n
+    assert n_checked >= 200
+    g = np.load(os.path.join(gold, "primitives.npz"), allow_pickle=True)
+    for s1, s2, f, r0, r1 in zip(g["ln_s1"], g["ln_s2"], g["ln_found"], g["ln_r0"], g["ln_r1"]):
+        hf, h0, h1 = gpu_ctx.long_needle(s1, s2)
+        assert (int(hf), h0, h1) == (int(f), r0, r1)
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE config-2 size (10 000 junctions): size-independent properties --
+    every planted deletion is recovered at single-nucleotide resolution up to
+    its micro-homology, results do not depend on batch composition/order."""
+    n = 10000
+    b = synth.make_batch(n, mode="c2")
+    gpu_ctx.set_chromosomes(b.chroms)
+    res, _ = gpu_ctx.refine(b, want_alignment=False)
+    kinds = np.array([t["kind"] for t in b.truth])
+    start = np.array([t["start"] for t in b.truth])
+    end = np.array([t["end"] for t in b.truth])
+    dele = kinds != "noref"
+    assert int(res["ok"][dele].sum()) >= int(0.995 * dele.sum())
+    assert int(res["ok"][~dele].sum()) == 0
+    okd = dele & (res["ok"] == 1)
+    # reported breakpoints bracket the truth within the homology wiggle (+1 for the 1-based end)
+    assert np.all(np.abs(res["sv_start"][okd] - start[okd]) <= res["ci_wiggle"][okd] + 1)
+    assert np.all(np.abs(res["sv_end"][okd] - end[okd]) <= res["ci_wiggle"][okd] + 1)
+    # idempotence / order independence: a permuted sub-batch gives identical records
+    sub = synth.make_batch(512, mode="c2", first=4096)
+    gpu_ctx.set_chromosomes(sub.chroms)
+    r2, _ = gpu_ctx.refine(sub, want_alignment=False)
+    base = 4096 * synth.WINDOW
+    for f in ("ok", "ci_wiggle", "hom_len", "cons_bp", "sr_align_quality", "matches", "mismatches"):
+        assert np.array_equal(r2[f], res[f][4096:4096 + 512]), f
+    assert np.array_equal(r2["sv_start"] + base, res["sv_start"][4096:4096 + 512])

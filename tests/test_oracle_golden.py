@@ -1,0 +1,81 @@
+"""CPU: the C restatement (oracle/liboracle.so) against the golden vectors that
+tests/golden/make_golden.py produced from the reference's own headers
+(oracle/_ref), and -- when oracle/_ref is present -- against the reference
+directly on fresh seeds.  Integer / byte outputs: bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle
+from delly_amd import synth
+from util import CORE, compare
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _batches():
+    return sorted(glob.glob(os.path.join(GOLD, "batch_*.npz")))
+
+
+@pytest.mark.parametrize("path", _batches(), ids=lambda p: os.path.basename(p))
+def test_port_reproduces_golden_batches(port, path):
+    g = np.load(path, allow_pickle=True)
+    kw = eval(str(g["kwargs"]))
+    b = synth.make_batch(int(g["n"]), **kw)
+    res, blob = port.refine_batch(b, want_alignment=True)
+    compare(res, blob, g["results"], g["blob"], label=os.path.basename(path))
+
+
+def test_port_reproduces_golden_primitives(port):
+    g = np.load(os.path.join(GOLD, "primitives.npz"), allow_pickle=True)
+    for a, b, o in zip(g["lcs_a"], g["lcs_b"], g["lcs_out"]):
+        assert port.lcs(a, b) == o
+    for x, y in zip(g["rc_in"], g["rc_out"]):
+        assert port.reverse_complement(x) == y
+    for a, b, o in zip(g["hom_a"], g["hom_b"], g["hom_out"]):
+        assert port.longest_homology(a, b) == o
+    for s1, s2, f, r0, r1 in zip(g["ln_s1"], g["ln_s2"], g["ln_found"], g["ln_r0"], g["ln_r1"]):
+        pf, p0, p1, _ = port.long_needle(s1, s2)
+        assert (int(pf), p0, p1) == (int(f), r0, r1)
+    for reads, rows, cs, root, d, p in zip(g["msa_sets"], g["msa_rows"], g["msa_cs"], g["tree_root"], g["tree_d"],
+                                           g["tree_p"]):
+        reads = list(reads)
+        assert port.msa(reads) == (int(rows), cs)
+        r2, d2, p2 = port.guide_tree(reads)
+        assert r2 == root and np.array_equal(d2, d) and np.array_equal(p2, p)
+    for a1, a2, sc, rows, cons in zip(g["gotoh_a1"], g["gotoh_a2"], g["gotoh_score"], g["gotoh_rows"],
+                                      g["gotoh_cons"]):
+        s2, r2 = port.gotoh(list(a1), list(a2))
+        assert s2 == sc and r2 == list(rows)
+        assert port.consensus(list(rows)) == cons
+
+
+@pytest.mark.parametrize("mode,n_reads,n", [("c2", 0, 150), ("mixed", 0, 180), ("mixed", 7, 36), ("c2", 12, 12)])
+def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
+    b = synth.make_batch(n, mode=mode, n_reads=n_reads, seed=777, first=5000)
+    rr, rb = reference.refine_batch(b)
+    pr, pb = port.refine_batch(b)
+    compare(pr, pb, rr, rb, label="port-vs-reference")
+
+
+def test_port_multithreaded_matches_single(port):
+    b = synth.make_batch(64, mode="mixed", seed=5)
+    r1, b1 = port.refine_batch(b, n_threads=1, want_alignment=False)
+    r4, b4 = port.refine_batch(b, n_threads=4, want_alignment=False)
+    compare(r1, b1, r4, b4, blobs=("cons", "allele"), label="threads")
+
+
+def test_edge_cases(port, reference):
+    """too-short consensus (split.h:647), single read (shortpe.h:166), N runs."""
+    b = synth.make_batch(8, mode="c2", cons_flank=10)   # 20 bp consensus < 2*13
+    rr, rb = reference.refine_batch(b)
+    pr, pb = port.refine_batch(b)
+    compare(pr, pb, rr, rb)
+    assert int(rr["ok"].sum()) == 0
+    b = synth.make_batch(6, mode="c2", n_reads=1)
+    rr, rb = reference.refine_batch(b)
+    pr, pb = port.refine_batch(b)
+    compare(pr, pb, rr, rb)
+    assert int(rr["sr_support"].sum()) == 0
