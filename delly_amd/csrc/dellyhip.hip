@@ -95,6 +95,7 @@ struct dellyhip_batch {
   // MSA stage
   DevBuf<uint8_t> msa_ws;
   uint64_t msa_ws_stride = 0;
+  int msa_nmax = 2;
   // timing
   std::vector<hipEvent_t> ev;        // 3 events per launch since the last kernel_ms()
   hipEvent_t last = nullptr;
@@ -356,7 +357,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
     }
-    if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride))) return bail(fail(rc, "msa_prepare: junction exceeds MSA kernel limits"));
+    if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
     if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
     if ((rc = b->work.alloc(std::max(n, 1)))) return bail(rc);
   }
@@ -396,7 +397,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.n_work = b->n;
     ma.work_counter = c->counters.p;
     int grid = std::min(b->n, c->n_cu * 8);
-    if ((rc = dh::msa_launch(ma, grid, s))) return fail(rc, "msa_launch");
+    if ((rc = dh::msa_launch(ma, grid, b->msa_nmax, s))) return fail(rc, "msa_launch");
     HIPCHK(hipGetLastError());
     // consensus lengths decide the K bin of the split kernel
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -581,7 +582,7 @@ int dellyhip_msa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, const u
                  int32_t cs_cap, int32_t* cs_len, int32_t* rows) {
   if (!c || !cs_len || !rows || n_reads < 0) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  int rc = dh::msa_single(c->stream, c->params, c->n_cu, n_reads, seq_blob, seq_off, cs, cs_cap, cs_len, rows);
+  int rc = dh::msa_single(c->stream, c->params, n_reads, seq_blob, seq_off, cs, cs_cap, cs_len, rows);
   return rc ? fail(rc, "msa") : 0;
 }
 

@@ -58,7 +58,12 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
   dellyhip_result* out = &A.res[j];
 
   bool go = true;
-  if (m < 0 || m > MMAX || m + 1 > WAVE * K) {
+  const int prior = A.res[j].status;  // set by the MSA stage (kernel limit exceeded there)
+  if (prior) {
+    R.status = prior;
+    R.cons_len = 0;
+    go = false;
+  } else if (m < 0 || m > MMAX || m + 1 > WAVE * K) {
     R.status = DELLYHIP_E_LIMIT;
     R.cons_len = 0;
     go = false;
