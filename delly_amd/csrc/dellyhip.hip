@@ -7,12 +7,15 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
 #include "../../include/dellyhip.h"
 #include "msa_kernel.hpp"
 #include "split_main.hpp"
+#include "split_pk.hpp"
 
 namespace {
 
@@ -86,7 +89,7 @@ struct dellyhip_batch {
   DevBuf<dellyhip_result> res;
   DevBuf<uint8_t> out_blob;
   uint64_t out_stride = 0;
-  DevBuf<int32_t> work;              // K-binned work lists, concatenated
+  DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   // direct (single longNeedle) mode
   DevBuf<uint8_t> ref_blob;
@@ -122,16 +125,29 @@ int ensure_chr_table(dellyhip_ctx* c) {
 int ensure_scratch(dellyhip_ctx* c) {
   if (c->scratch.p) return 0;
   const uint64_t nblk = (dh::NMAX + 63 + 15) / 16 + 1;
-  c->scratch_words = nblk * dh::KMAX * dh::WAVE;
-  c->scratch_blocks = c->n_cu * 14;  // LDS-limited residency of the split kernel
+  c->scratch_words = nblk * 2 * dh::KMAX * dh::WAVE;  // packed pair stack: 2 dwords per 16 steps per slot
+  c->scratch_blocks = c->n_cu * 20;  // 5 waves per SIMD resident
   int rc = c->scratch.alloc((size_t)c->scratch_words * c->scratch_blocks);
   if (rc) return rc;
-  return c->counters.alloc(16);
+  return c->counters.alloc(32);
 }
 
+// three launches per K bin: packed DP over pairs, 32-bit kernel for deferred junctions,
+// post-processing (tracebacks, split detection) one junction per wavefront
 template <int K>
-void launch_split(const dh::SplitArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(grid), dim3(dh::WAVE), 0, s, a);
+void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters, hipStream_t s) {
+  // equal number of work items per block (static striding): a grid of `max_blocks` with a
+  // remainder would leave most of the chip idle during the last partial round
+  auto balanced = [&](int items) {
+    int rounds = (items + max_blocks - 1) / max_blocks;
+    return (items + rounds - 1) / rounds;
+  };
+  a.n_work = pairs;
+  a.work_counter = counters + K;
+  hipLaunchKernelGGL(dh::split_pair_kernel<K>, dim3(balanced(pairs)), dim3(dh::WAVE), 0, s, a);
+  a.n_work = 2 * pairs;  // same counter: number of deferred pairs (0 -> the kernel returns at once)
+  hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(std::min(2 * pairs, 1024)), dim3(dh::WAVE), 0, s, a);
+  hipLaunchKernelGGL(dh::split_post_kernel<K>, dim3(balanced(2 * pairs)), dim3(dh::WAVE), 0, s, a);
 }
 
 // Launches the split-alignment kernels for every K bin of the batch.
@@ -139,7 +155,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   int rc;
   if (!direct && (rc = ensure_chr_table(c))) return rc;
   if ((rc = ensure_scratch(c))) return rc;
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(int32_t), s));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(int32_t), s));
   dh::SplitArgs a{};
   a.junc = b->junc.p;
   a.cons_off = b->cons_off.p;
@@ -155,6 +171,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   a.scratch = c->scratch.p;
   a.scratch_words = c->scratch_words;
   a.want_alignment = b->want_alignment;
+  a.pair_mode = 1;
   if (direct) {
     a.ref_base = b->ref_blob.p;
     a.ref_off = b->ref_off.p;
@@ -163,45 +180,52 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   for (int K = 1; K <= dh::KMAX; ++K) {
     int cnt = b->bin_count[K];
     if (cnt == 0) continue;
-    a.work_list = b->work.p + b->bin_first[K];
-    a.n_work = cnt;
-    a.work_counter = c->counters.p + K;
-    int grid = std::min(cnt, c->scratch_blocks);
+    a.work_list = b->work.p + 2 * b->bin_first[K];
     switch (K) {
-      case 1: launch_split<1>(a, grid, s); break;
-      case 2: launch_split<2>(a, grid, s); break;
-      case 3: launch_split<3>(a, grid, s); break;
-      case 4: launch_split<4>(a, grid, s); break;
-      default: launch_split<5>(a, grid, s); break;
+      case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
+      case 2: launch_split<2>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
+      case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
+      case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
+      default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
     }
     HIPCHK(hipGetLastError());
   }
   return 0;
 }
 
-// K-bins junctions by consensus length; junctions beyond the kernel limit go to
-// the KMAX bin, where the kernel flags them with DELLYHIP_E_LIMIT.
-int build_bins(dellyhip_batch* b) {
+// K-bins junctions by consensus length and pairs them (two junctions per wavefront, packed
+// 16-bit DP).  Within a bin junctions are sorted by their approximate reference-window length
+// so that partners need (almost) the same number of DP steps.  bin_count[] counts PAIRS; a
+// leftover junction is paired with -1.  Junctions beyond the kernel limit go to the KMAX bin,
+// where the kernel flags them with DELLYHIP_E_LIMIT.
+int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
-  std::vector<int32_t> k(b->n);
+  std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
     int kk = (m + 1 + dh::WAVE - 1) / dh::WAVE;
     kk = std::max(1, std::min(kk, dh::KMAX));
-    k[i] = kk;
-    b->bin_count[kk]++;
+    const dellyhip_junction& J = b->h_junc[i];
+    long span = (long)J.sv_end - (long)J.sv_start;
+    int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
+    bins[kk].push_back(std::make_pair(approx, i));
   }
-  int acc = 0;
+  std::vector<int32_t> work;
+  work.reserve(b->n + 2 * dh::KMAX);
   for (int K = 1; K <= dh::KMAX; ++K) {
-    b->bin_first[K] = acc;
-    acc += b->bin_count[K];
+    auto& v = bins[K];
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+    b->bin_first[K] = (int)work.size() / 2;
+    for (size_t q = 0; q < v.size(); q += 2) {
+      work.push_back(v[q].second);
+      work.push_back(q + 1 < v.size() ? v[q + 1].second : -1);
+    }
+    b->bin_count[K] = (int)work.size() / 2 - b->bin_first[K];
   }
-  std::vector<int32_t> fill(dh::KMAX + 2, 0), work(b->n);
-  for (int i = 0; i < b->n; ++i) work[b->bin_first[k[i]] + fill[k[i]]++] = i;
-  int rc = b->work.alloc(b->n);
+  int rc = b->work.alloc(std::max<size_t>(work.size(), 2));
   if (rc) return rc;
-  HIPCHK(hipMemcpy(b->work.p, work.data(), b->n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -348,7 +372,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       e = hipMemcpy(b->cons_len.p, b->h_cons_len.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
     }
-    if ((rc = build_bins(b))) return bail(rc);
+    if ((rc = build_bins(b, c->params))) return bail(rc);
   } else {
     // consensus is produced on the device at out_blob + i*stride
     std::vector<uint64_t> coff(n);
@@ -359,7 +383,6 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     }
     if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
     if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
-    if ((rc = b->work.alloc(std::max(n, 1)))) return bail(rc);
   }
   *out = b;
   return 0;
@@ -382,7 +405,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   HIPCHK(hipEventRecord(e3[0], s));
   if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
-    HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(int32_t), s));
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(int32_t), s));
     dh::MsaArgs ma{};
     ma.junc = b->junc.p;
     ma.seq_blob = b->seq_blob.p;
@@ -402,7 +425,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     // consensus lengths decide the K bin of the split kernel
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if ((rc = build_bins(b))) return rc;
+    if ((rc = build_bins(b, c->params))) return rc;
   }
   HIPCHK(hipEventRecord(e3[1], s));
   if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
@@ -416,6 +439,30 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
 int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
   if (!b->pending) return 0;
+  if (getenv("DELLYHIP_DEBUG_POSTMORTEM")) {  // bring-up aid: inspect device state of a stuck launch
+    bool done = false;
+    for (int it = 0; it < 50 && !done; ++it) {
+      struct timespec ts = {0, 100000000};
+      nanosleep(&ts, nullptr);
+      done = hipEventQuery(b->last) == hipSuccess;
+    }
+    if (!done) {
+      hipStream_t s2;
+      (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+      int32_t cnt[32];
+      (void)hipMemcpyAsync(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost, s2);
+      std::vector<dellyhip_result> r(std::min(b->n, 16));
+      (void)hipMemcpyAsync(r.data(), b->res.p, r.size() * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s2);
+      (void)hipStreamSynchronize(s2);
+      fprintf(stderr, "[postmortem] counters:");
+      for (int q = 0; q < 24; ++q) fprintf(stderr, " %d", cnt[q]);
+      fprintf(stderr, "\n");
+      for (size_t q = 0; q < r.size(); ++q)
+        fprintf(stderr, "[postmortem] j%zu status=%d unsplit=%d best=%d cl=%d rl=%d rr=%d ok=%d clen=%d rlen=%d\n", q, r[q].status,
+                r[q].score_unsplit, r[q].score_best, r[q].cons_left, r[q].ref_left, r[q].ref_right, r[q].ok, r[q].cons_len, r[q].ref_len);
+      _exit(3);
+    }
+  }
   HIPCHK(hipEventSynchronize(b->last));
   for (size_t q = 0; q + 2 < b->ev.size(); q += 3) {
     float a = 0, d = 0;
@@ -540,7 +587,7 @@ int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char*
   (void)hipMemcpy(b->ref_off.p, &zero, 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
   (void)hipMemset(b->res.p, 0, sizeof(dellyhip_result));
-  if ((rc = build_bins(b))) return bail(rc);
+  if ((rc = build_bins(b, c->params))) return bail(rc);
   rc = dellyhip_batch_run(c, b, nullptr);
   dellyhip_result R;
   std::vector<char> blob(b->out_stride);

@@ -65,7 +65,10 @@ struct SplitArgs {
   int32_t n_work;
   int32_t* work_counter;        // zeroed before launch (the atomic of shortpe.h:181)
   int32_t want_alignment;
+  int32_t pair_mode;            // 1: split_align_kernel runs behind the packed kernel (deferred junctions only)
 };
+
+constexpr int DH_DEFERRED = 1;  // transient result.status: not representable in the packed kernel
 
 constexpr int OUT_CONS_CAP = MMAX + 1;
 constexpr int OUT_ALLELE_CAP = NMAX + MMAX + 8;
@@ -90,17 +93,33 @@ __device__ __forceinline__ uint8_t upc(uint8_t c) { return (c >= 'a' && c <= 'z'
 __device__ __forceinline__ uint8_t comp_acgtn(uint8_t u) {
   return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : u == 'N' ? 'N' : 0;
 }
+// byte i of reverseComplement(str) (util.h:549-563): complement of the upper-cased mirrored
+// byte, or the ORIGINAL byte i when that is not one of ACGTN
+__device__ __forceinline__ uint8_t rc_at(const uint8_t* str, int len, int i) {
+  uint8_t r = comp_acgtn(upc(str[len - 1 - i]));
+  return r ? r : str[i];
+}
 // the output switch of needle.h:209-217 (adds '-' -> '-', everything else -> 0)
 __device__ __forceinline__ uint8_t outmap(uint8_t ch) {
   return ch == '-' ? '-' : comp_acgtn(ch);
 }
 
-// per-wave LDS image
-struct __attribute__((aligned(16))) WaveLds {
+// forward strings only (packed DP kernel: reverse complements are derived on the fly)
+struct __attribute__((aligned(16))) StrLdsFwd {
+  static constexpr bool has_rc = false;
+  uint8_t cons[MMAX + 1];   // s1
+  uint8_t ref[NMAX];        // s2 = svRefStr
+};
+// strings of one junction (LDS)
+struct __attribute__((aligned(16))) StrLds {
+  static constexpr bool has_rc = true;
   uint8_t cons[MMAX + 1];   // s1
   uint8_t rcons[MMAX + 1];  // reverseComplement(s1), util.h:549-563 semantics
   uint8_t ref[NMAX];        // s2 = svRefStr
   uint8_t rref[NMAX];       // reverseComplement(s2)
+};
+// scratch of the post-processing stage (one junction at a time, LDS)
+struct __attribute__((aligned(16))) PostLds {
   uint8_t trF[TRACE_CAP];   // forward traceback ops in push order (0 's',1 'v',2 'h')
   uint8_t trR[TRACE_CAP];
   unsigned long long mV[MASKW], mR[MASKW], mE[MASKW];  // column masks: var/ref present, equal
@@ -120,7 +139,7 @@ struct Seg {
 // Pushes (steps+15)/16 blocks of K*64 dwords.  Returns per-slot final V' and
 // running max.
 template <int K>
-__device__ __forceinline__ void pass_R(const WaveLds& L, int m, int n, uint32_t* stack, int lane,
+__device__ __forceinline__ void pass_R(const StrLds& L, int m, int n, uint32_t* stack, int lane,
                                        int (&hfin)[K], int (&brfin)[K]) {
   int a[K], hg[K], h[K], br[K];
   uint32_t acc[K];
@@ -183,7 +202,7 @@ __device__ __forceinline__ void pass_R(const WaveLds& L, int m, int n, uint32_t*
 // brfin[] = final running maxima of the R-pass (same slots).  Outputs: the
 // per-slot best join key ((sum' << 12) | (4095 - c)) and the final V' of row m.
 template <int K>
-__device__ __forceinline__ void pass_M(const WaveLds& L, int m, int n, const uint32_t* stack, int lane,
+__device__ __forceinline__ void pass_M(const StrLds& L, int m, int n, const uint32_t* stack, int lane,
                                        const int (&brfin)[K], int (&bestkey)[K], int& hrow_m) {
   int a[K], hg[K], h[K], bm[K], g[K];
   uint32_t dw[K];
@@ -330,7 +349,7 @@ __device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, u
 // ---- column-mask stream -----------------------------------------------------
 
 // appends `cnt` (<=64) bits of (v, r) at bit position pos of the LDS masks
-__device__ __forceinline__ void mask_append(WaveLds& L, int pos, int cnt, unsigned long long v, unsigned long long r,
+__device__ __forceinline__ void mask_append(PostLds& L, int pos, int cnt, unsigned long long v, unsigned long long r,
                                             int lane) {
   if (cnt <= 0) return;
   unsigned long long keep = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);

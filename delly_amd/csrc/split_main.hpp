@@ -1,5 +1,11 @@
-// split_main.hpp -- per-junction driver of the split-alignment kernel:
-// alignConsensus() of src/split.h:644-666 for svt != 4, one junction per wave.
+// split_main.hpp -- per-junction stages of the split-alignment kernels:
+// alignConsensus() of src/split.h:644-666 for svt != 4.
+//   junction_setup   : result defaults, consensus, _initBreakpoint/_getSVRef window, reverse complements
+//   junction_finish  : score checks, join winner, refRight (needle.h:83-123,152)
+//   junction_post    : tracebacks on recomputed direction codes, column masks, _findSplit,
+//                      _percentIdentity, _findHomology, _coordTransform, alleles (split.h:166-375,596-637)
+// The DP passes between setup and finish are either the one-junction-per-wave passes of
+// split_kernel.hpp or the packed two-junctions-per-wave passes of split_pk.hpp.
 #pragma once
 #include "split_kernel.hpp"
 
@@ -31,68 +37,92 @@ __device__ __forceinline__ void fill_segment(uint8_t* dst, const Seg& sg, int la
 
 __device__ __forceinline__ bool is_tra(int svt) { return svt >= 5 && svt < 9; }
 
-template <int K>
-__device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t* scratch, int lane) {
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) {
+  return ((uint64_t)(uint32_t)rfl((int)(v >> 32)) << 32) | (uint32_t)rfl((int)(v & 0xffffffffull));
+}
+
+// per-junction uniform state carried between the stages.  Every field is passed through
+// v_readfirstlane (uniformize()) so that hipcc sees the stage-level control flow as
+// wave-uniform and emits scalar branches: its exec-mask structurization of this (uniform, but
+// not provably so) control flow produced a non-terminating loop on gfx950.
+struct JCtx {
+  int j;
+  int m, n;
+  int svt, svS, svE;
+  int sBeg, sEnd, eBeg, eEnd;
+  bool go, direct;
+  uint8_t* ob;
+  uint64_t ob_off;
+  dellyhip_result* out;
+  int consLeft, refLeft, refRight, consRight;
+  __device__ __forceinline__ void uniformize() {
+    j = rfl(j); m = rfl(m); n = rfl(n); svt = rfl(svt); svS = rfl(svS); svE = rfl(svE);
+    sBeg = rfl(sBeg); sEnd = rfl(sEnd); eBeg = rfl(eBeg); eEnd = rfl(eEnd);
+    go = rfl((int)go) != 0; direct = rfl((int)direct) != 0;
+    ob = reinterpret_cast<uint8_t*>(rfl64(reinterpret_cast<uint64_t>(ob)));
+    ob_off = rfl64(ob_off);
+    out = reinterpret_cast<dellyhip_result*>(rfl64(reinterpret_cast<uint64_t>(out)));
+    consLeft = rfl(consLeft); refLeft = rfl(refLeft); refRight = rfl(refRight); consRight = rfl(consRight);
+  }
+};
+
+// ---- stage 1 ---------------------------------------------------------------------
+template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds>
+__device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
-  dellyhip_result R;
-  // zero-initialise (uniform)
-  {
-    int* rp = reinterpret_cast<int*>(&R);
-#pragma unroll
-    for (unsigned q = 0; q < sizeof(R) / 4; ++q) rp[q] = 0;
-  }
-  R.svid = J.svid;
-  R.sv_start = J.sv_start;
-  R.sv_end = J.sv_end;
-  R.ins_len = J.ins_len;
-  R.score_unsplit = R.score_best = R.cons_left = R.ref_left = R.ref_right = -1;
-  R.matches = R.mismatches = -1;
-  uint8_t* ob = A.out_blob + (size_t)j * A.out_stride;
-  const uint64_t ob_off = (uint64_t)j * A.out_stride;
-  const int m = A.cons_len[j];
+  X.j = j;
+  X.out = &A.res[j];
+  X.ob = A.out_blob + (size_t)j * A.out_stride;
+  X.ob_off = (uint64_t)j * A.out_stride;
+  X.m = A.cons_len[j];
+  X.n = 0;
+  X.svt = J.svt;
+  X.svS = J.sv_start;
+  X.svE = J.sv_end;
+  X.sBeg = X.sEnd = X.eBeg = X.eEnd = 0;
+  X.direct = (A.ref_base != nullptr);
+  X.consLeft = X.refLeft = X.refRight = X.consRight = 0;
+  const int m = X.m;
   const uint8_t* cons_g = A.cons_base + A.cons_off[j];
-  R.cons_len = m;
-  R.cons_off = ob_off;
-  R.sr_support = A.res[j].sr_support;  // written by the MSA stage (0 otherwise)
-  dellyhip_result* out = &A.res[j];
-
+  // WRITE_DEFAULTS: first visit of this junction (status/sr_support come from the MSA stage);
+  // otherwise a later kernel re-derives the strings and must not touch the result record
+  const int prior = WRITE_DEFAULTS ? X.out->status : 0;
+  const int support = WRITE_DEFAULTS ? X.out->sr_support : 0;
+  int status = 0;
   bool go = true;
-  const int prior = A.res[j].status;  // set by the MSA stage (kernel limit exceeded there)
+  bool mlimit = false;
   if (prior) {
-    R.status = prior;
-    R.cons_len = 0;
+    status = prior;
+    mlimit = true;
     go = false;
   } else if (m < 0 || m > MMAX || m + 1 > WAVE * K) {
-    R.status = DELLYHIP_E_LIMIT;
-    R.cons_len = 0;
+    status = DELLYHIP_E_LIMIT;
+    mlimit = true;
     go = false;
   }
   if (go) {
     for (int i = lane; i < m; i += WAVE) {
       uint8_t ch = cons_g[i];
-      L.cons[i] = ch;
-      if (cons_g != ob) ob[i] = ch;
+      S.cons[i] = ch;
+      if (WRITE_DEFAULTS && cons_g != X.ob) X.ob[i] = ch;
     }
   }
-  const bool direct = (A.ref_base != nullptr);
-  if (go && !direct && J.svt == 4) {  // splitAlign/edlib path: not in this kernel
-    R.status = DELLYHIP_E_LIMIT;
+  if (go && !X.direct && J.svt == 4) {  // splitAlign/edlib path: not in this kernel
+    status = DELLYHIP_E_LIMIT;
     go = false;
   }
-  if (go && !direct && m < 2 * P.minimum_flank_size + J.ins_len) go = false;  // split.h:647
+  if (go && !X.direct && m < 2 * P.minimum_flank_size + J.ins_len) go = false;  // split.h:647
 
-  // ---- _initBreakpoint (tags.h:151-172) + _getSVRef segments (split.h:70-163)
-  int sBeg = 0, sEnd = 0, eBeg = 0, eEnd = 0;
+  // _initBreakpoint (tags.h:151-172) + _getSVRef segments (split.h:70-163)
   Seg seg[3];
   int nseg = 0, n = 0;
-  if (go && direct) {
+  if (go && X.direct) {
     n = A.ref_len[j];
-    R.ref_len = n;
-    if (n > NMAX || n < 0) { R.status = DELLYHIP_E_LIMIT; go = false; }
+    if (n > NMAX || n < 0) { status = DELLYHIP_E_LIMIT; go = false; }
     else {
       const uint8_t* rg = A.ref_base + A.ref_off[j];
-      for (int i = lane; i < n; i += WAVE) L.ref[i] = rg[i];
+      for (int i = lane; i < n; i += WAVE) S.ref[i] = rg[i];
     }
   } else if (go) {
     const int boundary = m;
@@ -100,6 +130,7 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
     const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
     const uint8_t* c1 = A.chr_seq[J.chr];
     const uint8_t* c2 = A.chr_seq[J.chr2];
+    int sBeg, sEnd, eBeg, eEnd;
     if (is_tra(J.svt)) {
       sBeg = max(0, svS - boundary);
       sEnd = min(len1, svS + boundary);
@@ -145,131 +176,172 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
           nseg = 3;
         }
       } else {
-        go = false;  // unknown svt: _getSVRef returns "" -> longNeedle on empty ref finds nothing
+        go = false;  // unknown svt: _getSVRef returns ""
       }
     }
+    X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     for (int q = 0; q < nseg; ++q) n += seg[q].len;
-    R.ref_len = n;
     if (go && n > NMAX) {
-      R.status = DELLYHIP_E_LIMIT;
+      status = DELLYHIP_E_LIMIT;
       go = false;
     }
-  }
-  if (go) {
-    int o = 0;
-    for (int q = 0; q < nseg; ++q) {
-      fill_segment(L.ref + o, seg[q], lane);
-      o += seg[q].len;
+    if (go) {
+      int o = 0;
+      for (int q = 0; q < nseg; ++q) {
+        fill_segment(S.ref + o, seg[q], lane);
+        o += seg[q].len;
+      }
     }
+  }
+  X.n = n;
+  X.go = go;
+  // result defaults (everything a later stage does not overwrite)
+  if (WRITE_DEFAULTS && lane == 0) {
+    dellyhip_result R;
+    int* rp = reinterpret_cast<int*>(&R);
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(R) / 4; ++q) rp[q] = 0;
+    R.svid = J.svid;
+    R.sv_start = J.sv_start;
+    R.sv_end = J.sv_end;
+    R.ins_len = J.ins_len;
+    R.score_unsplit = R.score_best = R.cons_left = R.ref_left = R.ref_right = -1;
+    R.matches = R.mismatches = -1;
+    R.cons_len = mlimit ? 0 : m;
+    R.cons_off = X.ob_off;
+    R.sr_support = support;
+    R.status = status;
+    R.ref_len = n;
+    *X.out = R;
   }
   __syncthreads();
-  if (go) {
-    // reverseComplement(s1), reverseComplement(s2): util.h:549-563
-    for (int i = lane; i < m; i += WAVE) {
-      uint8_t r = comp_acgtn(upc(L.cons[m - 1 - i]));
-      L.rcons[i] = r ? r : L.cons[i];
+  if constexpr (STR::has_rc) {
+    if (go) {
+      // reverseComplement(s1), reverseComplement(s2): util.h:549-563
+      for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
+      for (int i = lane; i < n; i += WAVE) S.rref[i] = rc_at(S.ref, n, i);
     }
-    for (int i = lane; i < n; i += WAVE) {
-      uint8_t r = comp_acgtn(upc(L.ref[n - 1 - i]));
-      L.rref[i] = r ? r : L.ref[i];
-    }
+    __syncthreads();
   }
-  __syncthreads();
+  X.uniformize();
+}
 
-  // ---- longNeedle: R-pass, M-pass + join (needle.h:52-123)
-  int consLeft = 0, refLeft = 0, refRight = 0, consRight = 0, best = 0, unsplit = 0;
-  if (go) {
-    int hfin[K], brfin[K], bestkey[K];
-    int hrow_m;
-    pass_R<K>(L, m, n, scratch, lane, hfin, brfin);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pass_M<K>(L, m, n, scratch, lane, brfin, bestkey, hrow_m);
-    // rev[m][n]: slot m of the R-pass
-    int revmn = 0;
-#pragma unroll
-    for (int i = 0; i < K; ++i)
-      if (lane * K + i == m) revmn = hfin[i];
-    revmn = __shfl(revmn, m / K) - m;
-    unsplit = __shfl(hrow_m, 0);
-    unsplit = (unsplit >> SCALE_SHIFT) - m;
-    // first (row, col) in row-major order that attains the maximum (needle.h:107-115):
-    // max sum', then max slot (= min row), then max cinv (= min col)
-    long long key = (long long)0x8000000000000000ll;
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-      int s = lane * K + i;
-      if (s <= m) {
-        long long kk = ((long long)(bestkey[i] >> SCALE_SHIFT) << 32) | ((long long)s << 12) | (bestkey[i] & 4095);
-        key = kk > key ? kk : key;
-      }
+// ---- stage 3: checks, join winner, refRight ------------------------------------------
+// unsplit = mat[m][n], revmn = rev[m][n]; key = (sum' << 32) | (slot << 12) | (4095 - col).
+// code_word(slot, t0) returns the group of 2-bit codes of row `slot` that holds zero-based
+// producer step t0 (fields_per_word steps per group, field index = t0 % fields); it is called
+// with a per-lane t0.
+template <int K, typename CodeWord>
+__device__ __forceinline__ void junction_finish(JCtx& X, int unsplit, int revmn, long long key, CodeWord code_word,
+                                                int fields_per_word, int lane) {
+  if (!X.go) return;
+  const int m = X.m, n = X.n;
+  // the key comes out of a shuffle reduction: make it provably wave-uniform so that the
+  // loop below is a scalar loop (hipcc's divergent-loop lowering of it around
+  // v_readfirstlane never terminated on gfx950)
+  const int khi = rfl((int)(key >> 32)), klo = rfl((int)(key & 0xffffffffll));
+  int best = khi - m;  // sum' = sum + m
+  int sstar = (int)(((unsigned)klo >> 12) & 0xfffffu);
+  int refLeft = 4095 - (klo & 4095);
+  unsplit = rfl(unsplit);
+  revmn = rfl(revmn);
+  int consRight = sstar, consLeft = m - sstar;
+  int refRight = 0;
+  bool found = false;
+  if (unsplit == revmn) {  // needle.h:83-85
+    if (best <= unsplit) {  // no improving join: bestScore stays mat[m][n]
+      best = unsplit;
+      consLeft = 0;
+      refLeft = 0;
+      consRight = m;
     }
-    key = wave_max64(key);
-    best = (int)(key >> 32) - m;  // sum' = sum + m
-    int sstar = (int)((key >> 12) & 0xfffff);
-    refLeft = 4095 - (int)(key & 4095);
-    consRight = sstar;
-    consLeft = m - sstar;
-    R.score_unsplit = unsplit;
-    if (unsplit != revmn) go = false;  // needle.h:83-85
-    else {
-      if (best <= unsplit) {  // no improving join: consLeft = refLeft = 0, bestScore = mat[m][n]
-        best = unsplit;
-        consLeft = 0;
-        refLeft = 0;
-        consRight = m;
-      }
-      // refRight: last t in [0, n-refLeft] with rev[consRight][t] == running max there (needle.h:119-123)
-      {
-        int ls = consRight / K, is = consRight - ls * K;
-        int X = n - refLeft;
-        refRight = 0;
-        int t = X + ls - 1;  // zero-based producer step of column X
-        bool hit = false;
-        while (!hit && X >= 1) {
-          uint32_t w = ld_scratch(&scratch[((size_t)(t >> 4) * K + is) * WAVE + ls]);
-          w = (uint32_t)rfl((int)w);
-          int f = t & 15;
-          // fields f, f-1, ... 0 of this word cover columns X, X-1, ...
-          uint32_t keep = (f == 15) ? 0xffffffffu : ((1u << (2 * f + 2)) - 1u);
-          uint32_t x = w & keep;
-          int ncols_here = min(f + 1, X);  // columns X .. X-ncols_here+1
-          if (ncols_here < f + 1) x &= ~((1u << (2 * (f + 1 - ncols_here))) - 1u);  // columns < 1 do not exist
-          if (x) {
-            int top = (31 - __builtin_clz(x)) >> 1;  // highest non-zero field
-            refRight = X - (f - top);
-            hit = true;
-          } else {
-            X -= ncols_here;
-            t -= ncols_here;
+    // refRight: last t in [0, n-refLeft] with rev[consRight][t] == running max there
+    // (needle.h:119-123) = the highest column <= Xc whose code is non-zero (new max or tie).
+    // Lane q inspects the q-th code word below the one that holds column Xc; no
+    // data-dependent loop exit (a serial scan with early exit was mis-lowered by hipcc:
+    // its divergent-loop form never terminated on gfx950).
+    {
+      const int F = fields_per_word;
+      const int ls = consRight / K;
+      const int Xc = n - refLeft;
+      const int t = Xc + ls - 1;             // zero-based producer step of column Xc
+      const int wtop = (t >= 0) ? t / F : -1;
+      const int rounds = (Xc >= 1) ? (Xc + F * WAVE - 1) / (F * WAVE) + 1 : 0;
+      int bestcol = 0;
+      for (int r = 0; r < rounds; ++r) {
+        const int widx = wtop - (r * WAVE + lane);
+        int cand = 0;
+        if (widx >= 0) {
+          const uint32_t w = code_word(consRight, widx * F);
+          const int fmax = min(F - 1, t - widx * F);   // column <= Xc
+          const int fmin = max(0, ls - widx * F);      // column >= 1
+          if (fmax >= fmin) {
+            uint32_t keep = (2 * fmax + 2 >= 32) ? 0xffffffffu : ((1u << (2 * fmax + 2)) - 1u);
+            keep &= ~((1u << (2 * fmin)) - 1u);
+            const uint32_t x = w & keep;
+            if (x) cand = widx * F + ((31 - __builtin_clz(x)) >> 1) - ls + 1;
           }
         }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
+        bestcol = max(bestcol, cand);
       }
-      R.score_best = best;
-      R.cons_left = consLeft;
-      R.ref_left = refLeft;
-      R.ref_right = refRight;
-      if (best == unsplit) go = false;  // needle.h:152
+      refRight = bestcol;
+    }
+    found = (best != unsplit);  // needle.h:152
+    if (lane == 0) {
+      X.out->score_best = best;
+      X.out->cons_left = consLeft;
+      X.out->ref_left = refLeft;
+      X.out->ref_right = refRight;
     }
   }
+  if (lane == 0) X.out->score_unsplit = unsplit;
+  X.consLeft = consLeft;
+  X.refLeft = refLeft;
+  X.refRight = refRight;
+  X.consRight = consRight;
+  X.go = found;
+  X.uniformize();
+}
 
-  // ---- tracebacks (needle.h:154-194) on recomputed direction codes
+// direction pass + traceback with the smallest rows-per-lane that covers rows 0..rmax
+template <int K>
+__device__ __forceinline__ int dir_and_trace(const uint8_t* rowstr, const uint8_t* colstr, int m, int rmax, int ncols,
+                                             uint32_t* scratch, uint8_t* tr, int lane, int& tailV, int& tailH) {
+  const int kd = (rmax + 1 + WAVE - 1) / WAVE;  // <= K
+  int n = 0;
+#define DH_DIR_CASE(KD)                                              \
+  if (KD <= K && kd == KD) {                                         \
+    pass_dir<KD>(rowstr, colstr, m, rmax, ncols, scratch, lane);     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    n = traceback<KD>(scratch, rmax, ncols, tr, lane, tailV, tailH); \
+  }
+  DH_DIR_CASE(1) DH_DIR_CASE(2) DH_DIR_CASE(3) DH_DIR_CASE(4) DH_DIR_CASE(5)
+#undef DH_DIR_CASE
+  return n;
+}
+
+// ---- stage 4: tracebacks + split detection -> result ----------------------------------
+template <int K>
+__device__ __noinline__ void junction_post(const SplitArgs& A, JCtx& X, StrLds& S, PostLds& L, uint32_t* scratch, int lane) {
+  const dellyhip_params& P = A.p;
+  const int m = X.m, n = X.n;
+  const int consLeft = X.consLeft, refLeft = X.refLeft, consRight = X.consRight, refRight = X.refRight;
+  uint8_t* ob = X.ob;
+  bool go = X.go;
+  // tracebacks (needle.h:154-194) on recomputed direction codes
   int nF = 0, tvF = 0, thF = 0, nR = 0, tvR = 0, thR = 0;
   if (go) {
     if (consLeft > 0 && refLeft > 0) {
-      pass_dir<K>(L.cons, L.ref, m, consLeft, refLeft, scratch, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      nF = traceback<K>(scratch, consLeft, refLeft, L.trF, lane, tvF, thF);
+      nF = dir_and_trace<K>(S.cons, S.ref, m, consLeft, refLeft, scratch, L.trF, lane, tvF, thF);
     } else {
       tvF = consLeft;
       thF = (consLeft > 0) ? 0 : refLeft;
-      if (consLeft > 0 && refLeft == 0) thF = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (consRight > 0 && refRight > 0) {
-      pass_dir<K>(L.rcons, L.rref, m, consRight, refRight, scratch, lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      nR = traceback<K>(scratch, consRight, refRight, L.trR, lane, tvR, thR);
+      nR = dir_and_trace<K>(S.rcons, S.rref, m, consRight, refRight, scratch, L.trR, lane, tvR, thR);
     } else {
       tvR = consRight;
       thR = (consRight > 0) ? 0 : refRight;
@@ -277,9 +349,9 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
   }
   __syncthreads();
 
-  // ---- alignment as column masks -------------------------------------------------
-  // column order (needle.h:196-219): [fwd tail][fwd ops reversed][ref gap][rev ops][rev tail]
-  int Ltot = 0, posGap = 0, posC = 0;
+  // alignment as column masks; column order (needle.h:196-219):
+  // [fwd tail][fwd ops reversed][ref gap][rev ops][rev tail]
+  int Ltot = 0, posC = 0;
   if (go) {
     for (int w = lane; w < MASKW; w += WAVE) {
       L.mV[w] = 0;
@@ -288,7 +360,6 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
     }
     __syncthreads();
     int pos = 0;
-    // forward tail: thF ref-only columns, or tvF cons-only columns
     for (int k = 0; k < thF; k += 64) { mask_append(L, pos, min(64, thF - k), 0ull, ~0ull, lane); pos += min(64, thF - k); }
     for (int k = 0; k < tvF; k += 64) { mask_append(L, pos, min(64, tvF - k), ~0ull, 0ull, lane); pos += min(64, tvF - k); }
     for (int k = 0; k < nF; k += 64) {
@@ -299,7 +370,6 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
       mask_append(L, pos, min(64, nF - k), v, r, lane);
       pos += min(64, nF - k);
     }
-    posGap = pos;
     int gapref = (n - refRight) - refLeft;
     for (int k = 0; k < gapref; k += 64) { mask_append(L, pos, min(64, gapref - k), 0ull, ~0ull, lane); pos += min(64, gapref - k); }
     posC = pos;
@@ -315,7 +385,6 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
     for (int k = 0; k < thR; k += 64) { mask_append(L, pos, min(64, thR - k), 0ull, ~0ull, lane); pos += min(64, thR - k); }
     Ltot = pos;
     __syncthreads();
-    // cumulative counts
     if (lane == 0) {
       int cv = 0, cr = 0;
       int nw = (Ltot + 63) >> 6;
@@ -342,15 +411,13 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
       uint8_t c0 = '-', c1 = '-';
       if (jcol < Ltot) {
         if (jcol < posC) {
-          if (v) c0 = L.cons[cv];
-          if (r) c1 = L.ref[cr];
+          if (v) c0 = S.cons[cv];
+          if (r) c1 = S.ref[cr];
         } else {
-          if (v) c0 = outmap(L.rcons[m - 1 - cv]);
-          if (r) c1 = outmap(L.rref[n - 1 - cr]);
+          if (v) c0 = outmap(S.rcons[m - 1 - cv]);
+          if (r) c1 = outmap(S.rref[n - 1 - cr]);
         }
       }
-      // presence is defined on the characters (a '\0' from outmap still counts as present,
-      // exactly like align[0][j] != '-')
       unsigned long long e = __ballot(jcol < Ltot && v && r && c0 == c1);
       if (lane == 0) L.mE[w] = e;
       if (A.want_alignment && jcol < Ltot) {
@@ -359,26 +426,23 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
       }
     }
     __syncthreads();
-    if (A.want_alignment) {
-      R.aln_off = ob_off + OUT_CONS_CAP + OUT_ALLELE_CAP;
-      R.aln_len = Ltot;
+    if (A.want_alignment && lane == 0) {
+      X.out->aln_off = X.ob_off + OUT_CONS_CAP + OUT_ALLELE_CAP;
+      X.out->aln_len = Ltot;
     }
   }
+  if (go && X.direct && lane == 0) X.out->ok = 1;  // longNeedle() returned true
 
-  if (go && direct) R.ok = 1;  // longNeedle() returned true
-  // ---- _findSplit (split.h:319-375) on the masks (uniform code)
-  if (go && !direct) {
-    const int svt = J.svt;
-    int nw = (Ltot + 63) >> 6;
+  // _findSplit (split.h:319-375) on the masks (uniform code)
+  if (go && !X.direct) {
+    const int svt = X.svt;
     int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
     int J0 = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
-    int cStart = 0, cEnd = 0, rStart = 0, rEnd = 0, gS = 0, gE = 0;
+    int cStart = 0, cEnd = 0, rStart = 0, rEnd = 0;
     int closedLen = 0, chosenLen = 0;
-    // gap columns: NOT (v & r), from J0 on.  Build on the fly: G = ~(mV & mR)
     int pos = J0;
     while (pos < Ltot) {
-      // next gap column
-      int a = pos;
+      int a = pos;  // next gap column: NOT (v & r)
       while (a < Ltot) {
         int w = a >> 6, o = a & 63;
         unsigned long long x = (~(L.mV[w] & L.mR[w])) >> o;
@@ -386,8 +450,7 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
         a = (w + 1) << 6;
       }
       if (a >= Ltot) break;
-      // end of the run: next non-gap column
-      int b1 = a;
+      int b1 = a;  // end of the run: next non-gap column
       while (b1 < Ltot) {
         int w = b1 >> 6, o = b1 & 63;
         unsigned long long x = (L.mV[w] & L.mR[w]) >> o;
@@ -402,12 +465,10 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
       bool better = (svt == 4) ? (varspan > (cEnd - cStart)) : (refspan > (rEnd - rStart));
       if (better) {
         rStart = ra; rEnd = ra + refspan; cStart = va; cEnd = va + varspan;
-        gS = a; gE = b1 - 1;
         chosenLen = b1 - a;
       }
       pos = b1 + 1;
     }
-    (void)nw;
     bool ok = rEnd > rStart;
     if (ok) {
       if (svt == 4) ok = ((rEnd - rStart) < 5) && ((cEnd - cStart) > 15);
@@ -429,20 +490,18 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
     int homLeft = 0, homRight = 0;
     if (ok) {
       // _findHomology split.h:262-280 (svt != 4 in this kernel)
-      homRight = longest_homology(L.cons, cEnd - 1, 1, m - (cEnd - 1), L.ref, rStart, 1, n - rStart);
-      homLeft = longest_homology(L.cons, cStart - 1, -1, min(cStart, m), L.ref, rEnd - 2, -1, min(rEnd - 1, n));
+      homRight = longest_homology(S.cons, cEnd - 1, 1, m - (cEnd - 1), S.ref, rStart, 1, n - rStart);
+      homLeft = longest_homology(S.cons, cStart - 1, -1, min(cStart, m), S.ref, rEnd - 2, -1, min(rEnd - 1, n));
       const int varIndex = m, refIndex = n;
       if ((homLeft + P.minimum_flank_size > cStart) || (varIndex < cEnd + homRight + P.minimum_flank_size)) ok = false;
       if ((homLeft + P.minimum_flank_size > rStart) || (refIndex < rEnd + homRight + P.minimum_flank_size)) ok = false;
     }
     if (ok) {
-      R.c_start = cStart; R.c_end = cEnd; R.r_start = rStart; R.r_end = rEnd;
-      R.hom_left = homLeft; R.hom_right = homRight;
-      R.matches = ma; R.mismatches = mm;
       // _coordTransform split.h:166-244
       uint32_t gs = 0, ge = 0;
       bool ct_ok = true;
-      const int svS = J.sv_start, svE = J.sv_end;
+      const int svS = X.svS, svE = X.svE;
+      const int sBeg = X.sBeg, sEnd = X.sEnd, eBeg = X.eBeg, eEnd = X.eEnd;
       if (is_tra(svt)) {
         int ct = svt - 5;
         int annealed = (ct == 3) ? (eEnd - eBeg) : (sEnd - sBeg);
@@ -471,7 +530,9 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
         if (rStart >= annealed || rEnd < annealed) ct_ok = false;
         else { gs = (uint32_t)(sBeg + (annealed - rStart) + 1); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
       }
-      if (ct_ok && (is_tra(svt) || gs < ge)) {
+      int allele_len = 0, status = 0;
+      const bool final_ok = ct_ok && (is_tra(svt) || gs < ge);
+      if (final_ok) {
         // exact alleles split.h:606-624
         if ((svE - svS <= P.indelsize) && (svt == 2 || svt == 4)) {
           int colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
@@ -491,31 +552,86 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
               int cr = L.cumR[w] + __popcll(mr & below);
               bool v = (mv >> lane) & 1ull, r = (mr >> lane) & 1ull;
               if (jcol >= colA && jcol < colB) {
-                if (v) al[nr + 1 + (cv - vA)] = (jcol < posC) ? L.cons[cv] : outmap(L.rcons[m - 1 - cv]);
-                if (r) al[cr - rA] = (jcol < posC) ? L.ref[cr] : outmap(L.rref[n - 1 - cr]);
+                if (v) al[nr + 1 + (cv - vA)] = (jcol < posC) ? S.cons[cv] : outmap(S.rcons[m - 1 - cv]);
+                if (r) al[cr - rA] = (jcol < posC) ? S.ref[cr] : outmap(S.rref[n - 1 - cr]);
               }
             }
             if (lane == 0) al[nr] = ',';
-            R.allele_off = ob_off + OUT_CONS_CAP;
-            R.allele_len = nr + na + 1;
+            allele_len = nr + na + 1;
           } else {
-            R.status = DELLYHIP_E_LIMIT;
+            status = DELLYHIP_E_LIMIT;
           }
         }
-        R.ok = 1;
-        R.sv_start = (int32_t)gs;
-        R.sv_end = (int32_t)ge;
-        R.sr_align_quality = percId;
-        R.ins_len = cEnd - cStart - 1;
-        R.cons_bp = cStart;
-        R.hom_len = max(0, homLeft + homRight - 2);
-        R.ci_wiggle = max(homLeft, homRight);
+      }
+      if (lane == 0) {
+        dellyhip_result* R = X.out;
+        R->c_start = cStart; R->c_end = cEnd; R->r_start = rStart; R->r_end = rEnd;
+        R->hom_left = homLeft; R->hom_right = homRight;
+        R->matches = ma; R->mismatches = mm;
+        if (final_ok) {
+          if (allele_len) {
+            R->allele_off = X.ob_off + OUT_CONS_CAP;
+            R->allele_len = allele_len;
+          }
+          if (status) R->status = status;
+          R->ok = 1;
+          R->sv_start = (int32_t)gs;
+          R->sv_end = (int32_t)ge;
+          R->sr_align_quality = percId;
+          R->ins_len = cEnd - cStart - 1;
+          R->cons_bp = cStart;
+          R->hom_len = max(0, homLeft + homRight - 2);
+          R->ci_wiggle = max(homLeft, homRight);
+        }
       }
     }
-    (void)gS; (void)gE; (void)posGap;
   }
-  if (lane == 0) *out = R;
   __syncthreads();
+}
+
+// ---- one junction per wavefront -----------------------------------------------------
+struct __attribute__((aligned(16))) WaveLds {
+  StrLds s;
+  PostLds p;
+};
+
+template <int K>
+__device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t* scratch, int lane) {
+  JCtx X;
+  junction_setup<K>(A, j, L.s, X, lane);
+  int unsplit = 0, revmn = 0;
+  long long key = 0;
+  if (X.go) {
+    const int m = X.m, n = X.n;
+    int hfin[K], brfin[K], bestkey[K];
+    int hrow_m;
+    pass_R<K>(L.s, m, n, scratch, lane, hfin, brfin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pass_M<K>(L.s, m, n, scratch, lane, brfin, bestkey, hrow_m);
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if (lane * K + i == m) revmn = hfin[i];
+    revmn = __shfl(revmn, m / K) - m;
+    unsplit = (__shfl(hrow_m, 0) >> SCALE_SHIFT) - m;
+    // first (row, col) in row-major order attaining the maximum (needle.h:107-115):
+    // max sum', then max slot (= min row), then max cinv (= min col)
+    key = (long long)0x8000000000000000ll;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      int s = lane * K + i;
+      if (s <= m) {
+        long long kk = ((long long)(bestkey[i] >> SCALE_SHIFT) << 32) | ((long long)s << 12) | (bestkey[i] & 4095);
+        key = kk > key ? kk : key;
+      }
+    }
+    key = wave_max64(key);
+  }
+  auto code_word = [&](int slot, int t) -> uint32_t {
+    int ls = slot / K, is = slot - ls * K;
+    return ld_scratch(&scratch[((size_t)(t >> 4) * K + is) * WAVE + ls]);
+  };
+  junction_finish<K>(X, unsplit, revmn, key, code_word, 16, lane);
+  junction_post<K>(A, X, L.s, L.p, scratch, lane);
 }
 
 template <int K>
@@ -523,12 +639,45 @@ __global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A) {
   __shared__ WaveLds L;
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
-  for (;;) {
-    int w = 0;
-    if (lane == 0) w = atomicAdd(A.work_counter, 1);
-    w = rfl(w);
-    if (w >= A.n_work) break;
-    process_junction<K>(A, A.work_list[w], L, scratch, lane);
+  if (A.pair_mode && *A.work_counter == 0) return;  // nothing was deferred by the packed kernel
+  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
+    const int j = A.work_list[w];
+    if (j < 0) continue;
+    if (A.pair_mode) {  // launched behind the packed kernel: only junctions it deferred
+      if (A.res[j].status != DH_DEFERRED) continue;
+      __syncthreads();
+      if (lane == 0) A.res[j].status = 0;
+      __syncthreads();
+    }
+    process_junction<K>(A, j, L, scratch, lane);
+    if (A.pair_mode && lane == 0) A.res[j].reserved = 1;  // post-processing already done
+  }
+}
+
+// post-processing kernel: one junction per wavefront, junctions the DP kernel marked JS_FOUND
+template <int K>
+__global__ __launch_bounds__(WAVE) void split_post_kernel(SplitArgs A) {
+  __shared__ WaveLds L;
+  const int lane = threadIdx.x;
+  uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
+    const int j = A.work_list[w];
+    if (j < 0) continue;
+    const dellyhip_result* r = &A.res[j];
+    const int st = r->status, rsv = r->reserved, sb = r->score_best, su = r->score_unsplit;
+    if (rsv) {  // finished by the 32-bit kernel
+      if (lane == 0) A.res[j].reserved = 0;
+      continue;
+    }
+    if (st != 0 || sb == -1 || sb == su) continue;  // longNeedle found no split (needle.h:83,152)
+    const int cl = r->cons_left, rl = r->ref_left, rr = r->ref_right;
+    JCtx X;
+    junction_setup<K, false>(A, j, L.s, X, lane);
+    X.consLeft = cl;
+    X.refLeft = rl;
+    X.refRight = rr;
+    X.consRight = X.m - cl;
+    junction_post<K>(A, X, L.s, L.p, scratch, lane);
   }
 }
 
