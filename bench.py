@@ -68,6 +68,18 @@ def cpu_baseline(batch, budget_s=12.0):
                       % (reps, sub.n, batch.n, cores, dt, 1.0 / per)}
 
 
+def _measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if not collected."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def _subbatch(batch, n):
     from delly_amd import synth
     n = min(n, batch.n)
@@ -141,6 +153,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_split, ms_msa, launches = rb.kernel_ms()
+    ms_dp = rb.dp_kernel_ms()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,7 +166,8 @@ def main():
     if rank == 0:
         total_units = world * n * args.steps
         value = total_units / dt
-        ach = n * ALG_BYTES_PER_U / (ms_split * 1e-3) / 1e9 if ms_split > 0 else 0.0
+        ach = n * ALG_BYTES_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0
+        traffic = _measured_traffic()
         out = {
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,
@@ -171,10 +185,11 @@ def main():
                                    "ref window, alignConsensus (longNeedle + split detection), bit-exact" % n,
                        "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "split_align_kernel<3>", "kernel_ms": ms_split,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "split_pair_kernel<3> (packed longNeedle DP, 2 junctions per wavefront)",
+                         "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
-                         "gcups": n * CELLS_PER_U / (ms_split * 1e-3) / 1e9 if ms_split > 0 else 0.0,
+                         "gcups": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
                          "note": "path is integer-VALU bound with DP state on chip; HBM fraction is reported because "
                                  "BASELINE asks for it (SURVEY.md 8d)"},
         }

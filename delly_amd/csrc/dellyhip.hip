@@ -7,8 +7,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
-#include <ctime>
-#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -100,9 +98,10 @@ struct dellyhip_batch {
   uint64_t msa_ws_stride = 0;
   int msa_nmax = 2;
   // timing
-  std::vector<hipEvent_t> ev;        // 3 events per launch since the last kernel_ms()
+  std::vector<hipEvent_t> ev;        // 4 events per launch since the last kernel_ms()
   hipEvent_t last = nullptr;
-  double ms_split = 0, ms_msa = 0;
+  hipEvent_t mid = nullptr;          // recorded between the DP kernels and the post kernel
+  double ms_split = 0, ms_msa = 0, ms_dp = 0, ms_dp_last = 0;
   int launches = 0;
   bool pending = false;
 };
@@ -135,7 +134,7 @@ int ensure_scratch(dellyhip_ctx* c) {
 // three launches per K bin: packed DP over pairs, 32-bit kernel for deferred junctions,
 // post-processing (tracebacks, split detection) one junction per wavefront
 template <int K>
-void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters, hipStream_t s) {
+void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters, hipStream_t s, hipEvent_t mid) {
   // equal number of work items per block (static striding): a grid of `max_blocks` with a
   // remainder would leave most of the chip idle during the last partial round
   auto balanced = [&](int items) {
@@ -147,6 +146,7 @@ void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters,
   hipLaunchKernelGGL(dh::split_pair_kernel<K>, dim3(balanced(pairs)), dim3(dh::WAVE), 0, s, a);
   a.n_work = 2 * pairs;  // same counter: number of deferred pairs (0 -> the kernel returns at once)
   hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(std::min(2 * pairs, 1024)), dim3(dh::WAVE), 0, s, a);
+  if (mid) (void)hipEventRecord(mid, s);  // (with several K bins: the last bin's DP end)
   hipLaunchKernelGGL(dh::split_post_kernel<K>, dim3(balanced(2 * pairs)), dim3(dh::WAVE), 0, s, a);
 }
 
@@ -182,11 +182,11 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     if (cnt == 0) continue;
     a.work_list = b->work.p + 2 * b->bin_first[K];
     switch (K) {
-      case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
-      case 2: launch_split<2>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
-      case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
-      case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
-      default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s); break;
+      case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 2: launch_split<2>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
     }
     HIPCHK(hipGetLastError());
   }
@@ -399,9 +399,10 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   if (b->n == 0) return 0;
   int rc;
-  hipEvent_t e3[3];
-  for (int q = 0; q < 3; ++q) HIPCHK(hipEventCreate(&e3[q]));
-  for (int q = 0; q < 3; ++q) b->ev.push_back(e3[q]);
+  hipEvent_t e3[4];
+  for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreate(&e3[q]));
+  for (int q = 0; q < 4; ++q) b->ev.push_back(e3[q]);
+  b->mid = e3[3];
   HIPCHK(hipEventRecord(e3[0], s));
   if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
@@ -439,37 +440,15 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
 int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
   if (!b->pending) return 0;
-  if (getenv("DELLYHIP_DEBUG_POSTMORTEM")) {  // bring-up aid: inspect device state of a stuck launch
-    bool done = false;
-    for (int it = 0; it < 50 && !done; ++it) {
-      struct timespec ts = {0, 100000000};
-      nanosleep(&ts, nullptr);
-      done = hipEventQuery(b->last) == hipSuccess;
-    }
-    if (!done) {
-      hipStream_t s2;
-      (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-      int32_t cnt[32];
-      (void)hipMemcpyAsync(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost, s2);
-      std::vector<dellyhip_result> r(std::min(b->n, 16));
-      (void)hipMemcpyAsync(r.data(), b->res.p, r.size() * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s2);
-      (void)hipStreamSynchronize(s2);
-      fprintf(stderr, "[postmortem] counters:");
-      for (int q = 0; q < 24; ++q) fprintf(stderr, " %d", cnt[q]);
-      fprintf(stderr, "\n");
-      for (size_t q = 0; q < r.size(); ++q)
-        fprintf(stderr, "[postmortem] j%zu status=%d unsplit=%d best=%d cl=%d rl=%d rr=%d ok=%d clen=%d rlen=%d\n", q, r[q].status,
-                r[q].score_unsplit, r[q].score_best, r[q].cons_left, r[q].ref_left, r[q].ref_right, r[q].ok, r[q].cons_len, r[q].ref_len);
-      _exit(3);
-    }
-  }
   HIPCHK(hipEventSynchronize(b->last));
-  for (size_t q = 0; q + 2 < b->ev.size(); q += 3) {
-    float a = 0, d = 0;
+  for (size_t q = 0; q + 3 < b->ev.size(); q += 4) {
+    float a = 0, d = 0, e = 0;
     HIPCHK(hipEventElapsedTime(&a, b->ev[q], b->ev[q + 1]));
     HIPCHK(hipEventElapsedTime(&d, b->ev[q + 1], b->ev[q + 2]));
+    HIPCHK(hipEventElapsedTime(&e, b->ev[q + 1], b->ev[q + 3]));
     b->ms_msa += a;
     b->ms_split += d;
+    b->ms_dp += e;
   }
   for (auto e : b->ev) (void)hipEventDestroy(e);
   b->ev.clear();
@@ -486,6 +465,13 @@ int dellyhip_batch_device_results(dellyhip_ctx* c, dellyhip_batch* b, void** dpt
   return 0;
 }
 
+int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_dp) {
+  if (!b || !ms_dp) return fail(DELLYHIP_E_ARG, "null argument");
+  (void)c;
+  *ms_dp = b->ms_dp_last;
+  return 0;
+}
+
 int dellyhip_batch_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_split, double* ms_msa, int32_t* launches) {
   if (!b) return fail(DELLYHIP_E_ARG, "null argument");
   int rc = dellyhip_batch_sync(c, b);
@@ -494,7 +480,8 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_spli
   if (ms_split) *ms_split = b->ms_split / L;
   if (ms_msa) *ms_msa = b->ms_msa / L;
   if (launches) *launches = b->launches;
-  b->ms_split = b->ms_msa = 0;
+  b->ms_dp_last = b->ms_dp / L;
+  b->ms_split = b->ms_msa = b->ms_dp = 0;
   b->launches = 0;
   return 0;
 }

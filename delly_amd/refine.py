@@ -25,7 +25,7 @@ EXPORTS = [
     "dellyhip_create", "dellyhip_destroy", "dellyhip_last_error", "dellyhip_default_params_sr",
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
-    "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_long_needle",
+    "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
     "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info",
 ]
 
@@ -198,6 +198,12 @@ class ResidentBatch:
         a, b, l = C.c_double(0), C.c_double(0), C.c_int32(0)
         self.ctx._check(self.ctx.lib.dellyhip_batch_kernel_ms(self.ctx._ctx, self._b, C.byref(a), C.byref(b), C.byref(l)))
         return a.value, b.value, l.value
+
+    def dp_kernel_ms(self):
+        """Average ms of split_pair_kernel alone over the launches of the last kernel_ms() window."""
+        a = C.c_double(0)
+        self.ctx._check(self.ctx.lib.dellyhip_batch_dp_kernel_ms(self.ctx._ctx, self._b, C.byref(a)))
+        return a.value
 
     def device_results(self):
         """(device pointer, bytes) of the n result records in HBM."""

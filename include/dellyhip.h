@@ -177,6 +177,10 @@ int dellyhip_batch_device_results(dellyhip_ctx* ctx, dellyhip_batch* b, void** d
  * launch stream; also returns the launch count. */
 int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_split,
                              double* ms_msa, int32_t* launches);
+/* Average duration (ms) of the dominant kernel alone -- the packed DP kernel
+ * split_pair_kernel -- over the launches covered by the last
+ * dellyhip_batch_kernel_ms() call (HIP events on the launch stream). */
+int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
 /* ---- single-item wrappers (parity tests, assemble.h / asmode.h call sites) */
 
