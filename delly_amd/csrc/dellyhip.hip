@@ -14,6 +14,7 @@
 #include "msa_kernel.hpp"
 #include "split_main.hpp"
 #include "split_pk.hpp"
+#include "ins_kernel.hpp"
 
 namespace {
 
@@ -89,6 +90,7 @@ struct dellyhip_batch {
   uint64_t out_stride = 0;
   DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
+  int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
   // direct (single longNeedle) mode
   DevBuf<uint8_t> ref_blob;
   DevBuf<uint64_t> ref_off;
@@ -177,9 +179,11 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.ref_off = b->ref_off.p;
     a.ref_len = b->ref_len.p;
   }
+  bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
     int cnt = b->bin_count[K];
     if (cnt == 0) continue;
+    any_bin = true;
     a.work_list = b->work.p + 2 * b->bin_first[K];
     switch (K) {
       case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
@@ -188,6 +192,15 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
       case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
       default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
     }
+    HIPCHK(hipGetLastError());
+  }
+  if (!any_bin && b->mid) HIPCHK(hipEventRecord(b->mid, s));  // keeps the per-launch event quartet complete
+  if (b->ins_count > 0 && !direct) {
+    a.work_list = b->work.p + b->ins_first;
+    a.n_work = b->ins_count;
+    const int rounds = (b->ins_count + c->scratch_blocks - 1) / c->scratch_blocks;
+    const int grid = (b->ins_count + rounds - 1) / rounds;
+    hipLaunchKernelGGL(dh::ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -202,11 +215,17 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
   std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
+  std::vector<int32_t> ins;
+  const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
     int kk = (m + 1 + dh::WAVE - 1) / dh::WAVE;
     kk = std::max(1, std::min(kk, dh::KMAX));
     const dellyhip_junction& J = b->h_junc[i];
+    if (!direct && J.svt == 4) {  // splitAlign path: own kernel, one junction per wavefront
+      ins.push_back(i);
+      continue;
+    }
     long span = (long)J.sv_end - (long)J.sv_start;
     int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
     bins[kk].push_back(std::make_pair(approx, i));
@@ -223,6 +242,9 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     }
     b->bin_count[K] = (int)work.size() / 2 - b->bin_first[K];
   }
+  b->ins_first = (int)work.size();
+  b->ins_count = (int)ins.size();
+  work.insert(work.end(), ins.begin(), ins.end());
   int rc = b->work.alloc(std::max<size_t>(work.size(), 2));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));

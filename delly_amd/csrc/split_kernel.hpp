@@ -319,26 +319,46 @@ __device__ __forceinline__ void pass_dir(const uint8_t* rowstr, const uint8_t* c
   }
 }
 
-// Serial traceback over the stored direction codes (uniform across the wave).
+// Traceback over the stored direction codes (uniform across the wave).  A dependent
+// L2 round trip per step would dominate the post-processing stage, so the codes are read
+// in windows: lane l fetches the code word of cell (rr-l, cc-l) -- the diagonal through
+// the current cell -- and the walk continues out of registers (v_readlane) for as long as
+// the path stays inside the fetched words (16 columns per row), then refetches.
 // Pushes ops (0 's', 1 'v', 2 'h') until a border is reached; the remaining
 // straight run is returned as tailV / tailH.  Returns the number of pushed ops.
 template <int K>
 __device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, uint8_t* tr, int lane, int& tailV,
                                          int& tailH) {
   int tl = 0;
+  rr = rfl(rr);
+  cc = rfl(cc);
   while (rr > 0 && cc > 0) {
-    int l = rr / K, i = rr - l * K;
-    int t = cc + l - 1;
-    uint32_t w = ld_scratch(&dirs[((size_t)(t >> 4) * K + i) * WAVE + l]);
-    w = (uint32_t)rfl((int)w);
-    uint32_t code = (w >> (2 * (t & 15))) & 3u;
-    if (lane == 0) tr[tl] = (uint8_t)code;
-    ++tl;
-    if (code == 1) --rr;
-    else if (code == 2) --cc;
-    else {
-      --rr;
-      --cc;
+    const int r = rr - lane, c = cc - lane;
+    uint32_t w = 0;
+    int tw = -1;
+    if (r >= 1 && c >= 1) {
+      const int lo = r / K, i = r - lo * K;
+      tw = (c + lo - 1) >> 4;
+      w = ld_scratch(&dirs[((size_t)tw * K + i) * WAVE + lo]);
+    }
+    int l = 0;
+    bool inwin = true;
+    while (inwin) {
+      const int lo = rr / K;
+      const int t = cc + lo - 1;
+      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+      const int twl = __builtin_amdgcn_readlane(tw, l);
+      if ((t >> 4) != twl) {
+        inwin = false;  // path left the fetched word of this row
+      } else {
+        const uint32_t code = (wl >> (2 * (t & 15))) & 3u;
+        if (lane == 0) tr[tl] = (uint8_t)code;
+        ++tl;
+        if (code == 1) { --rr; ++l; }
+        else if (code == 2) --cc;
+        else { --rr; --cc; ++l; }
+        if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
+      }
     }
   }
   tailV = rr;  // column 0: only vertical moves remain

@@ -67,7 +67,9 @@ struct JCtx {
 };
 
 // ---- stage 1 ---------------------------------------------------------------------
-template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds>
+// INS: the caller is the insertion kernel (svt 4, splitAlign path); every other kernel flags
+// svt 4 junctions, which the host never routes to them, with DELLYHIP_E_LIMIT.
+template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds, bool INS = false>
 __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
@@ -108,7 +110,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
       if (WRITE_DEFAULTS && cons_g != X.ob) X.ob[i] = ch;
     }
   }
-  if (go && !X.direct && J.svt == 4) {  // splitAlign/edlib path: not in this kernel
+  if (go && !X.direct && (J.svt == 4) != INS) {  // splitAlign/edlib path <-> insertion kernel only
     status = DELLYHIP_E_LIMIT;
     go = false;
   }
@@ -131,7 +133,16 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     const uint8_t* c1 = A.chr_seq[J.chr];
     const uint8_t* c2 = A.chr_seq[J.chr2];
     int sBeg, sEnd, eBeg, eEnd;
-    if (is_tra(J.svt)) {
+    if (INS) {
+      // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
+      const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
+      sBeg = max(0, svS - bs);
+      sEnd = min(len1, svS + bs);
+      eBeg = max(0, svE - bs);
+      eEnd = min(len2, svE + bs);
+      seg[0] = Seg{c1, sBeg, max(0, eEnd - sBeg), 0};
+      nseg = 1;
+    } else if (is_tra(J.svt)) {
       sBeg = max(0, svS - boundary);
       sEnd = min(len1, svS + boundary);
       eBeg = max(0, svE - boundary);
@@ -181,7 +192,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     }
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     for (int q = 0; q < nseg; ++q) n += seg[q].len;
-    if (go && n > NMAX) {
+    if (go && (n > NMAX || (INS && n < 3))) {  // (splitAlign indexes distRev[n-2]: n < 3 is outside its domain)
       status = DELLYHIP_E_LIMIT;
       go = false;
     }
@@ -322,6 +333,234 @@ __device__ __forceinline__ int dir_and_trace(const uint8_t* rowstr, const uint8_
   return n;
 }
 
+// column masks -> cumulative counts, equality mask, optional alignment rows.  Columns
+// [0, posC) take their letters from S.cons / S.ref by running count, columns [posC, Ltot) from
+// the reverse-complemented strings through needle.h:209-217's output switch.
+template <typename STRS>
+__device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& S, PostLds& L, int Ltot, int posC,
+                                             int lane) {
+  const int m = X.m, n = X.n;
+  uint8_t* ob = X.ob;
+  __syncthreads();
+  if (lane == 0) {
+    int cv = 0, cr = 0;
+    int nw = (Ltot + 63) >> 6;
+    for (int w = 0; w < nw; ++w) {
+      L.cumV[w] = cv;
+      L.cumR[w] = cr;
+      cv += __popcll(L.mV[w]);
+      cr += __popcll(L.mR[w]);
+    }
+    L.cumV[nw] = cv;
+    L.cumR[nw] = cr;
+  }
+  __syncthreads();
+  // characters of every column -> equality mask (+ optional alignment output)
+  uint8_t* aln = ob + OUT_CONS_CAP + OUT_ALLELE_CAP;
+  for (int base = 0; base < Ltot; base += 64) {
+    int jcol = base + lane;
+    int w = base >> 6;
+    unsigned long long mv = L.mV[w], mr = L.mR[w];
+    unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int cv = L.cumV[w] + __popcll(mv & below);
+    int cr = L.cumR[w] + __popcll(mr & below);
+    bool v = (mv >> lane) & 1ull, r = (mr >> lane) & 1ull;
+    uint8_t c0 = '-', c1 = '-';
+    if (jcol < Ltot) {
+      if (jcol < posC) {
+        if (v) c0 = S.cons[cv];
+        if (r) c1 = S.ref[cr];
+      } else {
+        if (v) c0 = outmap(S.rcons[m - 1 - cv]);
+        if (r) c1 = outmap(S.rref[n - 1 - cr]);
+      }
+    }
+    unsigned long long e = __ballot(jcol < Ltot && v && r && c0 == c1);
+    if (lane == 0) L.mE[w] = e;
+    if (A.want_alignment && jcol < Ltot) {
+      aln[jcol] = c0;
+      aln[Ltot + jcol] = c1;
+    }
+  }
+  __syncthreads();
+  if (A.want_alignment && lane == 0) {
+    X.out->aln_off = X.ob_off + OUT_CONS_CAP + OUT_ALLELE_CAP;
+    X.out->aln_len = Ltot;
+  }
+}
+
+// _findSplit / _percentIdentity / _findHomology / _coordTransform / exact alleles on the column
+// masks (split.h:166-375, 596-637); writes the result record.
+template <typename STRS>
+__device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PostLds& L, bool go, int Ltot,
+                                             int posC, int lane) {
+  const dellyhip_params& P = A.p;
+  const int m = X.m, n = X.n;
+  uint8_t* ob = X.ob;
+  // _findSplit (split.h:319-375) on the masks (uniform code)
+  if (go) {
+    const int svt = X.svt;
+    int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
+    int J0 = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
+    int cStart = 0, cEnd = 0, rStart = 0, rEnd = 0;
+    int closedLen = 0, chosenLen = 0;
+    int pos = J0;
+    while (pos < Ltot) {
+      int a = pos;  // next gap column: NOT (v & r)
+      while (a < Ltot) {
+        int w = a >> 6, o = a & 63;
+        unsigned long long x = (~(L.mV[w] & L.mR[w])) >> o;
+        if (x) { a += __builtin_ctzll(x); break; }
+        a = (w + 1) << 6;
+      }
+      if (a >= Ltot) break;
+      int b1 = a;  // end of the run: next non-gap column
+      while (b1 < Ltot) {
+        int w = b1 >> 6, o = b1 & 63;
+        unsigned long long x = (L.mV[w] & L.mR[w]) >> o;
+        if (x) { b1 += __builtin_ctzll(x); break; }
+        b1 = (w + 1) << 6;
+      }
+      if (b1 >= Ltot) break;  // trailing run: never closed, never evaluated
+      int ra = cnt_before(L.mR, L.cumR, a), rb = cnt_before(L.mR, L.cumR, b1);
+      int va = cnt_before(L.mV, L.cumV, a), vb = cnt_before(L.mV, L.cumV, b1);
+      int refspan = rb - ra + 1, varspan = vb - va + 1;
+      closedLen += b1 - a;
+      bool better = (svt == 4) ? (varspan > (cEnd - cStart)) : (refspan > (rEnd - rStart));
+      if (better) {
+        rStart = ra; rEnd = ra + refspan; cStart = va; cEnd = va + varspan;
+        chosenLen = b1 - a;
+      }
+      pos = b1 + 1;
+    }
+    bool ok = rEnd > rStart;
+    if (ok) {
+      if (svt == 4) ok = ((rEnd - rStart) < 5) && ((cEnd - cStart) > 15);
+      else ok = ((cEnd - cStart) < 5) && ((rEnd - rStart) > 15);
+    }
+    int ma = 0, mm = 0;
+    float percId = 0.f;
+    if (ok) {
+      // _percentIdentity split.h:282-316
+      for (int w = 0; w < ((Ltot + 63) >> 6); ++w) {
+        unsigned long long both = L.mV[w] & L.mR[w];
+        ma += __popcll(both & L.mE[w]);
+        mm += __popcll(both & ~L.mE[w]);
+      }
+      mm += closedLen - chosenLen;
+      percId = (float)(uint32_t)ma / (float)(uint32_t)(ma + mm);
+      if (percId < P.flank_quality) ok = false;
+    }
+    int homLeft = 0, homRight = 0;
+    if (ok) {
+      // _findHomology split.h:262-280
+      if (svt == 4) {
+        homRight = longest_homology(S.cons, cStart, 1, m - cStart, S.ref, rEnd - 1, 1, n - (rEnd - 1));
+        homLeft = longest_homology(S.cons, cEnd - 2, -1, min(cEnd - 1, m), S.ref, rStart - 1, -1, min(rStart, n));
+      } else {
+        homRight = longest_homology(S.cons, cEnd - 1, 1, m - (cEnd - 1), S.ref, rStart, 1, n - rStart);
+        homLeft = longest_homology(S.cons, cStart - 1, -1, min(cStart, m), S.ref, rEnd - 2, -1, min(rEnd - 1, n));
+      }
+      const int varIndex = m, refIndex = n;
+      if ((homLeft + P.minimum_flank_size > cStart) || (varIndex < cEnd + homRight + P.minimum_flank_size)) ok = false;
+      if ((homLeft + P.minimum_flank_size > rStart) || (refIndex < rEnd + homRight + P.minimum_flank_size)) ok = false;
+    }
+    if (ok) {
+      // _coordTransform split.h:166-244
+      uint32_t gs = 0, ge = 0;
+      bool ct_ok = true;
+      const int svS = X.svS, svE = X.svE;
+      const int sBeg = X.sBeg, sEnd = X.sEnd, eBeg = X.eBeg, eEnd = X.eEnd;
+      if (is_tra(svt)) {
+        int ct = svt - 5;
+        int annealed = (ct == 3) ? (eEnd - eBeg) : (sEnd - sBeg);
+        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
+        else if (ct == 0) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)((uint64_t)(int64_t)eBeg + ((uint64_t)n - (uint64_t)(int64_t)rEnd) + 1); }
+        else if (ct == 1) { gs = (uint32_t)(sBeg + (annealed - rStart) + 1); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
+        else if (ct == 2) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
+        else { gs = (uint32_t)(sBeg + (rEnd - annealed)); ge = (uint32_t)(eBeg + rStart); }
+      } else if (svt == 2) {
+        if (svE - svS > P.indelsize) {
+          int annealed = sEnd - sBeg;
+          if (rStart >= annealed || rEnd < annealed) ct_ok = false;
+          else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
+        } else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(sBeg + rEnd); }
+      } else if (svt == 3) {
+        int annealed = eEnd - eBeg;
+        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
+        else { gs = (uint32_t)(sBeg + (rEnd - annealed)); ge = (uint32_t)(eBeg + rStart); }
+      } else if (svt == 0) {
+        int annealed = sEnd - sBeg;
+        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
+        else if (svE - svS > P.min_cons_window) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)((uint64_t)(int64_t)eBeg + ((uint64_t)n - (uint64_t)(int64_t)rEnd) + 1); }
+        else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eEnd - (rEnd - annealed)); }
+      } else if (svt == 1) {
+        int annealed = (svE - svS > P.min_cons_window) ? (sEnd - sBeg) : ((svS - sBeg) + (svE - sBeg));
+        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
+        else { gs = (uint32_t)(sBeg + (annealed - rStart) + 1); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
+      } else if (svt == 4) {
+        gs = (uint32_t)(sBeg + rStart);
+        ge = (uint32_t)(sBeg + rEnd);
+      }
+      int allele_len = 0, status = 0;
+      const bool final_ok = ct_ok && (is_tra(svt) || gs < ge);
+      if (final_ok) {
+        // exact alleles split.h:606-624
+        if ((svE - svS <= P.indelsize) && (svt == 2 || svt == 4)) {
+          int colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
+          int colB = select_bit(L.mV, L.cumV, cEnd, Ltot);
+          if (colA > colB) colA = colB;
+          int rA = cnt_before(L.mR, L.cumR, colA), rB = cnt_before(L.mR, L.cumR, colB);
+          int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
+          int nr = rB - rA, na = vB - vA;
+          uint8_t* al = ob + OUT_CONS_CAP;
+          if (nr + na + 1 <= OUT_ALLELE_CAP) {
+            for (int base = colA & ~63; base < colB; base += 64) {
+              int jcol = base + lane;
+              int w = base >> 6;
+              unsigned long long mv = L.mV[w], mr = L.mR[w];
+              unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+              int cv = L.cumV[w] + __popcll(mv & below);
+              int cr = L.cumR[w] + __popcll(mr & below);
+              bool v = (mv >> lane) & 1ull, r = (mr >> lane) & 1ull;
+              if (jcol >= colA && jcol < colB) {
+                if (v) al[nr + 1 + (cv - vA)] = (jcol < posC) ? S.cons[cv] : outmap(S.rcons[m - 1 - cv]);
+                if (r) al[cr - rA] = (jcol < posC) ? S.ref[cr] : outmap(S.rref[n - 1 - cr]);
+              }
+            }
+            if (lane == 0) al[nr] = ',';
+            allele_len = nr + na + 1;
+          } else {
+            status = DELLYHIP_E_LIMIT;
+          }
+        }
+      }
+      if (lane == 0) {
+        dellyhip_result* R = X.out;
+        R->c_start = cStart; R->c_end = cEnd; R->r_start = rStart; R->r_end = rEnd;
+        R->hom_left = homLeft; R->hom_right = homRight;
+        R->matches = ma; R->mismatches = mm;
+        if (final_ok) {
+          if (allele_len) {
+            R->allele_off = X.ob_off + OUT_CONS_CAP;
+            R->allele_len = allele_len;
+          }
+          if (status) R->status = status;
+          R->ok = 1;
+          R->sv_start = (int32_t)gs;
+          R->sv_end = (int32_t)ge;
+          R->sr_align_quality = percId;
+          R->ins_len = cEnd - cStart - 1;
+          R->cons_bp = cStart;
+          R->hom_len = max(0, homLeft + homRight - 2);
+          R->ci_wiggle = max(homLeft, homRight);
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- stage 4: tracebacks + split detection -> result ----------------------------------
 template <int K>
 __device__ __noinline__ void junction_post(const SplitArgs& A, JCtx& X, StrLds& S, PostLds& L, uint32_t* scratch, int lane) {
@@ -384,209 +623,10 @@ __device__ __noinline__ void junction_post(const SplitArgs& A, JCtx& X, StrLds& 
     for (int k = 0; k < tvR; k += 64) { mask_append(L, pos, min(64, tvR - k), ~0ull, 0ull, lane); pos += min(64, tvR - k); }
     for (int k = 0; k < thR; k += 64) { mask_append(L, pos, min(64, thR - k), 0ull, ~0ull, lane); pos += min(64, thR - k); }
     Ltot = pos;
-    __syncthreads();
-    if (lane == 0) {
-      int cv = 0, cr = 0;
-      int nw = (Ltot + 63) >> 6;
-      for (int w = 0; w < nw; ++w) {
-        L.cumV[w] = cv;
-        L.cumR[w] = cr;
-        cv += __popcll(L.mV[w]);
-        cr += __popcll(L.mR[w]);
-      }
-      L.cumV[nw] = cv;
-      L.cumR[nw] = cr;
-    }
-    __syncthreads();
-    // characters of every column -> equality mask (+ optional alignment output)
-    uint8_t* aln = ob + OUT_CONS_CAP + OUT_ALLELE_CAP;
-    for (int base = 0; base < Ltot; base += 64) {
-      int jcol = base + lane;
-      int w = base >> 6;
-      unsigned long long mv = L.mV[w], mr = L.mR[w];
-      unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      int cv = L.cumV[w] + __popcll(mv & below);
-      int cr = L.cumR[w] + __popcll(mr & below);
-      bool v = (mv >> lane) & 1ull, r = (mr >> lane) & 1ull;
-      uint8_t c0 = '-', c1 = '-';
-      if (jcol < Ltot) {
-        if (jcol < posC) {
-          if (v) c0 = S.cons[cv];
-          if (r) c1 = S.ref[cr];
-        } else {
-          if (v) c0 = outmap(S.rcons[m - 1 - cv]);
-          if (r) c1 = outmap(S.rref[n - 1 - cr]);
-        }
-      }
-      unsigned long long e = __ballot(jcol < Ltot && v && r && c0 == c1);
-      if (lane == 0) L.mE[w] = e;
-      if (A.want_alignment && jcol < Ltot) {
-        aln[jcol] = c0;
-        aln[Ltot + jcol] = c1;
-      }
-    }
-    __syncthreads();
-    if (A.want_alignment && lane == 0) {
-      X.out->aln_off = X.ob_off + OUT_CONS_CAP + OUT_ALLELE_CAP;
-      X.out->aln_len = Ltot;
-    }
+    masks_finish(A, X, S, L, Ltot, posC, lane);
   }
   if (go && X.direct && lane == 0) X.out->ok = 1;  // longNeedle() returned true
-
-  // _findSplit (split.h:319-375) on the masks (uniform code)
-  if (go && !X.direct) {
-    const int svt = X.svt;
-    int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
-    int J0 = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
-    int cStart = 0, cEnd = 0, rStart = 0, rEnd = 0;
-    int closedLen = 0, chosenLen = 0;
-    int pos = J0;
-    while (pos < Ltot) {
-      int a = pos;  // next gap column: NOT (v & r)
-      while (a < Ltot) {
-        int w = a >> 6, o = a & 63;
-        unsigned long long x = (~(L.mV[w] & L.mR[w])) >> o;
-        if (x) { a += __builtin_ctzll(x); break; }
-        a = (w + 1) << 6;
-      }
-      if (a >= Ltot) break;
-      int b1 = a;  // end of the run: next non-gap column
-      while (b1 < Ltot) {
-        int w = b1 >> 6, o = b1 & 63;
-        unsigned long long x = (L.mV[w] & L.mR[w]) >> o;
-        if (x) { b1 += __builtin_ctzll(x); break; }
-        b1 = (w + 1) << 6;
-      }
-      if (b1 >= Ltot) break;  // trailing run: never closed, never evaluated
-      int ra = cnt_before(L.mR, L.cumR, a), rb = cnt_before(L.mR, L.cumR, b1);
-      int va = cnt_before(L.mV, L.cumV, a), vb = cnt_before(L.mV, L.cumV, b1);
-      int refspan = rb - ra + 1, varspan = vb - va + 1;
-      closedLen += b1 - a;
-      bool better = (svt == 4) ? (varspan > (cEnd - cStart)) : (refspan > (rEnd - rStart));
-      if (better) {
-        rStart = ra; rEnd = ra + refspan; cStart = va; cEnd = va + varspan;
-        chosenLen = b1 - a;
-      }
-      pos = b1 + 1;
-    }
-    bool ok = rEnd > rStart;
-    if (ok) {
-      if (svt == 4) ok = ((rEnd - rStart) < 5) && ((cEnd - cStart) > 15);
-      else ok = ((cEnd - cStart) < 5) && ((rEnd - rStart) > 15);
-    }
-    int ma = 0, mm = 0;
-    float percId = 0.f;
-    if (ok) {
-      // _percentIdentity split.h:282-316
-      for (int w = 0; w < ((Ltot + 63) >> 6); ++w) {
-        unsigned long long both = L.mV[w] & L.mR[w];
-        ma += __popcll(both & L.mE[w]);
-        mm += __popcll(both & ~L.mE[w]);
-      }
-      mm += closedLen - chosenLen;
-      percId = (float)(uint32_t)ma / (float)(uint32_t)(ma + mm);
-      if (percId < P.flank_quality) ok = false;
-    }
-    int homLeft = 0, homRight = 0;
-    if (ok) {
-      // _findHomology split.h:262-280 (svt != 4 in this kernel)
-      homRight = longest_homology(S.cons, cEnd - 1, 1, m - (cEnd - 1), S.ref, rStart, 1, n - rStart);
-      homLeft = longest_homology(S.cons, cStart - 1, -1, min(cStart, m), S.ref, rEnd - 2, -1, min(rEnd - 1, n));
-      const int varIndex = m, refIndex = n;
-      if ((homLeft + P.minimum_flank_size > cStart) || (varIndex < cEnd + homRight + P.minimum_flank_size)) ok = false;
-      if ((homLeft + P.minimum_flank_size > rStart) || (refIndex < rEnd + homRight + P.minimum_flank_size)) ok = false;
-    }
-    if (ok) {
-      // _coordTransform split.h:166-244
-      uint32_t gs = 0, ge = 0;
-      bool ct_ok = true;
-      const int svS = X.svS, svE = X.svE;
-      const int sBeg = X.sBeg, sEnd = X.sEnd, eBeg = X.eBeg, eEnd = X.eEnd;
-      if (is_tra(svt)) {
-        int ct = svt - 5;
-        int annealed = (ct == 3) ? (eEnd - eBeg) : (sEnd - sBeg);
-        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
-        else if (ct == 0) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)((uint64_t)(int64_t)eBeg + ((uint64_t)n - (uint64_t)(int64_t)rEnd) + 1); }
-        else if (ct == 1) { gs = (uint32_t)(sBeg + (annealed - rStart) + 1); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
-        else if (ct == 2) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
-        else { gs = (uint32_t)(sBeg + (rEnd - annealed)); ge = (uint32_t)(eBeg + rStart); }
-      } else if (svt == 2) {
-        if (svE - svS > P.indelsize) {
-          int annealed = sEnd - sBeg;
-          if (rStart >= annealed || rEnd < annealed) ct_ok = false;
-          else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
-        } else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(sBeg + rEnd); }
-      } else if (svt == 3) {
-        int annealed = eEnd - eBeg;
-        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
-        else { gs = (uint32_t)(sBeg + (rEnd - annealed)); ge = (uint32_t)(eBeg + rStart); }
-      } else if (svt == 0) {
-        int annealed = sEnd - sBeg;
-        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
-        else if (svE - svS > P.min_cons_window) { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)((uint64_t)(int64_t)eBeg + ((uint64_t)n - (uint64_t)(int64_t)rEnd) + 1); }
-        else { gs = (uint32_t)(sBeg + rStart); ge = (uint32_t)(eEnd - (rEnd - annealed)); }
-      } else if (svt == 1) {
-        int annealed = (svE - svS > P.min_cons_window) ? (sEnd - sBeg) : ((svS - sBeg) + (svE - sBeg));
-        if (rStart >= annealed || rEnd < annealed) ct_ok = false;
-        else { gs = (uint32_t)(sBeg + (annealed - rStart) + 1); ge = (uint32_t)(eBeg + (rEnd - annealed)); }
-      }
-      int allele_len = 0, status = 0;
-      const bool final_ok = ct_ok && (is_tra(svt) || gs < ge);
-      if (final_ok) {
-        // exact alleles split.h:606-624
-        if ((svE - svS <= P.indelsize) && (svt == 2 || svt == 4)) {
-          int colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
-          int colB = select_bit(L.mV, L.cumV, cEnd, Ltot);
-          if (colA > colB) colA = colB;
-          int rA = cnt_before(L.mR, L.cumR, colA), rB = cnt_before(L.mR, L.cumR, colB);
-          int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
-          int nr = rB - rA, na = vB - vA;
-          uint8_t* al = ob + OUT_CONS_CAP;
-          if (nr + na + 1 <= OUT_ALLELE_CAP) {
-            for (int base = colA & ~63; base < colB; base += 64) {
-              int jcol = base + lane;
-              int w = base >> 6;
-              unsigned long long mv = L.mV[w], mr = L.mR[w];
-              unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-              int cv = L.cumV[w] + __popcll(mv & below);
-              int cr = L.cumR[w] + __popcll(mr & below);
-              bool v = (mv >> lane) & 1ull, r = (mr >> lane) & 1ull;
-              if (jcol >= colA && jcol < colB) {
-                if (v) al[nr + 1 + (cv - vA)] = (jcol < posC) ? S.cons[cv] : outmap(S.rcons[m - 1 - cv]);
-                if (r) al[cr - rA] = (jcol < posC) ? S.ref[cr] : outmap(S.rref[n - 1 - cr]);
-              }
-            }
-            if (lane == 0) al[nr] = ',';
-            allele_len = nr + na + 1;
-          } else {
-            status = DELLYHIP_E_LIMIT;
-          }
-        }
-      }
-      if (lane == 0) {
-        dellyhip_result* R = X.out;
-        R->c_start = cStart; R->c_end = cEnd; R->r_start = rStart; R->r_end = rEnd;
-        R->hom_left = homLeft; R->hom_right = homRight;
-        R->matches = ma; R->mismatches = mm;
-        if (final_ok) {
-          if (allele_len) {
-            R->allele_off = X.ob_off + OUT_CONS_CAP;
-            R->allele_len = allele_len;
-          }
-          if (status) R->status = status;
-          R->ok = 1;
-          R->sv_start = (int32_t)gs;
-          R->sv_end = (int32_t)ge;
-          R->sr_align_quality = percId;
-          R->ins_len = cEnd - cStart - 1;
-          R->cons_bp = cStart;
-          R->hom_len = max(0, homLeft + homRight - 2);
-          R->ci_wiggle = max(homLeft, homRight);
-        }
-      }
-    }
-  }
-  __syncthreads();
+  split_detect(A, X, S, L, go && !X.direct, Ltot, posC, lane);
 }
 
 // ---- one junction per wavefront -----------------------------------------------------

@@ -78,6 +78,9 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   (two-window branch src/split.h:117), DUP, INV 3to3/5to5 and
                   the four BND orientations across two chromosomes, varying
                   flank lengths.
+    mode "ins"  : svt 4 insertions (splitAlign path, src/split.h:480-538): 16..120 bp
+                  novel or tandem-duplicated sequence, soft-masked / N-containing
+                  reference stretches, pure-reference negatives.
     n_reads 0   : unit U (one consensus per junction); >0: unit U_full (that
                   many distinct split reads per junction, host order = as generated).
     """
@@ -115,6 +118,21 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                 kind, svt, ell = "inv1", 1, int(rng.integers(400, 1500))
             else:
                 kind, svt = "bnd%d" % (sel - 8), 5 + (sel - 8)
+        elif mode == "ins":
+            svt = 4
+            sel = j % 10
+            flankL = int(rng.integers(55, 98))    # consensus <= 97 + 120 + 97 = 314 (kernel limit 319)
+            flankR = int(rng.integers(55, 98))
+            ell = int(rng.integers(20, 121))      # inserted length
+            kind = "ins"
+            if sel == 6:
+                kind = "insdup"                    # tandem duplication of the left flank -> homology
+            elif sel == 7:
+                kind = "insnone"                   # pure reference: splitAlign finds no gap
+            elif sel == 8:
+                kind = "insmask"                   # soft-masked reference + an N
+            elif sel == 9:
+                ell = int(rng.integers(14, 19))    # around the > 15 threshold of _validSRAlignment
         else:
             v = j % 100
             if v == 1:
@@ -124,6 +142,18 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             elif v == 3:
                 kind = "hom"
         e = s + ell
+        ins_seq = None
+        if svt == 4:
+            e = s + int(rng.integers(0, 3))
+            if kind == "insdup":
+                ins_seq = G[s - ell:s].copy()
+            elif kind == "insnone":
+                ins_seq = G[0:0]
+            else:
+                ins_seq = ACGT[rng.integers(0, 4, ell)]
+            if kind == "insmask":
+                G[s - 40:s + 40] = G[s - 40:s + 40] + 32   # lower case
+                G[s + 50] = ord("N")
         if kind == "nrun":
             G[s - 60:s - 50] = ord("N")
         if kind == "hom":
@@ -135,6 +165,10 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             left, right = G[s - L:s], G[e:e + L]
         elif kind == "noref":
             left, right = G[s - L:s], G[s:s + L]
+        elif svt == 4:
+            up = np.where((G >= 97) & (G <= 122), G - 32, G).astype(np.uint8)
+            left, right = np.concatenate([up[s - L:s], ins_seq]), up[s:s + L]
+            L = left.size
         elif kind == "dup":
             left, right = G[e - L:e], G[s:s + L]
         elif kind == "inv0":
@@ -164,6 +198,10 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         rec["sv_start"] = base + s + jit_s
         rec["sv_end"] = base + e + jit_e
         rec["ins_len"] = 0
+        if svt == 4:
+            rec["sv_end"] = max(int(rec["sv_start"]), base + e + jit_e)
+            rec["ins_len"] = max(0, ins_seq.size + int(rng.integers(-2, 3)))
+            flankL += ins_seq.size
         rec["seq_first"] = len(seqs)
         if n_reads <= 0:
             cons = _mutate(rng, alt[L - flankL:L + flankR], sub_rate)
@@ -171,7 +209,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             rec["n_seq"] = 1
         else:
             seen = set()
-            lo, hi = 25, 2 * L - read_len - 25
+            lo, hi = 25, alt.size - read_len - 25
             tries = 0
             while len(seen) < n_reads and tries < 50 * n_reads:
                 tries += 1

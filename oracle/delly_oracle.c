@@ -935,6 +935,279 @@ static int coord_transform(const dellyhip_params* c, uint64_t refsize, const bpo
 }
 
 /* ------------------------------------------------------------------------ */
+/* edlib (vendored third-party code of the reference: src/edlib.cpp, edlib    */
+/* v1.2.x) restated as a plain unit-cost DP.  edlibAlign() runs Myers'        */
+/* bit-vector algorithm inside an Ukkonen band with a doubling k; every       */
+/* observable output (editDistance, endLocations[0], startLocations[0], the   */
+/* op string of obtainAlignmentTraceback) is a function of the exact DP       */
+/* matrix, which is what is computed here:                                    */
+/*   - D[i][j], i over the query, j over the target; D[i][0] = i;             */
+/*     D[0][j] = 0 (HW) or j (SHW, NW)                      edlib.cpp:573-575 */
+/*   - HW/SHW end locations: columns of the last query row that attain the    */
+/*     minimum, in increasing order; the column "before the target"           */
+/*     (position -1) takes part only when the query length is not a multiple  */
+/*     of 64, because it is observed through the W padding rows of the last   */
+/*     block (c - W >= -1 needs W >= 1)                     edlib.cpp:653-691 */
+/*   - HW start: SHW of the reversed query on the reversed target prefix,     */
+/*     LAST optimal end                                     edlib.cpp:236-249 */
+/*   - path: NW traceback on target[start..end], preferring "up" (INSERT,     */
+/*     consumes a query letter), then "left" (DELETE), then the diagonal      */
+/*                                                          edlib.cpp:1018-1125 */
+/* Hirschberg mode (alignment data >= 1 MiB, edlib.cpp:1188-1191) breaks ties */
+/* differently and is NOT restated: such calls return DOR_ED_LIMIT.           */
+
+#define DOR_ED_LIMIT (-4)
+enum { ED_NW = 0, ED_SHW = 1, ED_HW = 2 };
+enum { OP_MATCH = 0, OP_INSERT = 1, OP_DELETE = 2, OP_MISMATCH = 3 };
+
+typedef struct {
+  int ed, num_loc, end_loc, start_loc; /* loc = -2: not set */
+  unsigned char* aln;
+  int aln_len;
+} ed_res;
+
+static int32_t* ed_fill(const char* q, int qn, const char* t, int tn, int hw) {
+  size_t W = (size_t)tn + 1;
+  int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qn + 1) * W);
+  for (int j = 0; j <= tn; ++j) D[j] = hw ? 0 : j;
+  for (int i = 1; i <= qn; ++i) {
+    int32_t* r = D + (size_t)i * W;
+    const int32_t* u = r - W;
+    r[0] = i;
+    for (int j = 1; j <= tn; ++j) {
+      int v = u[j - 1] + (q[i - 1] != t[j - 1]);
+      if (u[j] + 1 < v) v = u[j] + 1;
+      if (r[j - 1] + 1 < v) v = r[j - 1] + 1;
+      r[j] = v;
+    }
+  }
+  return D;
+}
+
+/* obtainAlignmentTraceback on an exact NW matrix, forward op order */
+static void ed_trace(const char* q, int qn, const char* t, int tn, ed_res* r) {
+  (void)q; (void)t;
+  int32_t* D = ed_fill(q, qn, t, tn, 0);
+  size_t W = (size_t)tn + 1;
+  unsigned char* ops = (unsigned char*)malloc((size_t)qn + (size_t)tn + 1);
+  int L = 0, i = qn, j = tn;
+  while (i > 0 && j > 0) {
+    int cur = D[(size_t)i * W + j];
+    if (D[(size_t)(i - 1) * W + j] + 1 == cur) { ops[L++] = OP_INSERT; --i; }
+    else if (D[(size_t)i * W + j - 1] + 1 == cur) { ops[L++] = OP_DELETE; --j; }
+    else { ops[L++] = (D[(size_t)(i - 1) * W + j - 1] == cur) ? OP_MATCH : OP_MISMATCH; --i; --j; }
+  }
+  while (j > 0) { ops[L++] = OP_DELETE; --j; }  /* query exhausted: edlib.cpp:1027-1031,1087-1091 */
+  while (i > 0) { ops[L++] = OP_INSERT; --i; }  /* target exhausted: edlib.cpp:1057-1062,1079-1084 */
+  for (int a = 0, b = L - 1; a < b; ++a, --b) { unsigned char x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
+  free(D);
+  r->aln = ops;
+  r->aln_len = L;
+}
+
+/* edlibAlign(query, target, edlibNewAlignConfig(-1, mode, task, NULL, 0)); task 0 DISTANCE, 1 LOC, 2 PATH */
+static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int task, ed_res* r) {
+  r->ed = -1; r->num_loc = 0; r->end_loc = r->start_loc = -2; r->aln = NULL; r->aln_len = 0;
+  if (qn == 0 || tn == 0) { /* edlib.cpp:160-178 */
+    if (mode == ED_NW) { r->ed = imax(qn, tn); r->end_loc = tn - 1; }
+    else { r->ed = qn; r->end_loc = -1; }
+    r->num_loc = 1;
+    return 0;
+  }
+  const int pad = ((qn + 63) / 64) * 64 - qn; /* W */
+  const int j0 = pad >= 1 ? 0 : 1;
+  int32_t* D = ed_fill(q, qn, t, tn, mode == ED_HW);
+  const int32_t* last = D + (size_t)qn * ((size_t)tn + 1);
+  if (mode == ED_NW) {
+    r->ed = last[tn];
+    r->end_loc = tn - 1;
+    r->num_loc = 1;
+  } else {
+    int best = last[j0];
+    for (int j = j0; j <= tn; ++j) if (last[j] < best) best = last[j];
+    r->ed = best;
+    for (int j = tn; j >= j0; --j) if (last[j] == best) { r->end_loc = j - 1; r->num_loc++; }
+  }
+  free(D);
+  if (task == 0) return 0;
+  if (mode == ED_HW) {
+    if (r->end_loc == -1) r->start_loc = 0; /* edlib.cpp:222-235 */
+    else {
+      int tl = r->end_loc + 1;
+      char* rq = (char*)malloc((size_t)qn + 1);
+      char* rt = (char*)malloc((size_t)tl + 1);
+      for (int i = 0; i < qn; ++i) rq[i] = q[qn - 1 - i];
+      for (int j = 0; j < tl; ++j) rt[j] = t[r->end_loc - j];
+      int32_t* R = ed_fill(rq, qn, rt, tl, 0);
+      const int32_t* rl = R + (size_t)qn * ((size_t)tl + 1);
+      int best = rl[j0], lastj = j0;
+      for (int j = j0; j <= tl; ++j) {
+        if (rl[j] < best) best = rl[j];
+      }
+      for (int j = j0; j <= tl; ++j) if (rl[j] == best) lastj = j;
+      r->start_loc = r->end_loc - (lastj - 1);
+      free(R); free(rq); free(rt);
+    }
+  } else r->start_loc = 0;
+  if (task == 1) return 0;
+  {
+    const int s0 = r->start_loc, tl = r->end_loc - s0 + 1;
+    if (tl == 0) { /* obtainAlignment edlib.cpp:1169-1176 */
+      r->aln_len = qn;
+      r->aln = (unsigned char*)malloc((size_t)qn + 1);
+      memset(r->aln, OP_INSERT, (size_t)qn);
+      return 0;
+    }
+    long long blocks = (qn + 63) / 64;
+    long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
+    if (!(sz < 1024 * 1024)) return DOR_ED_LIMIT;
+    ed_trace(q, qn, t + s0, tl, r);
+  }
+  return 0;
+}
+
+int dor_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int task, int* out,
+                    unsigned char* aln, int cap) {
+  ed_res r;
+  int rc = ed_align(q, qn, t, tn, mode, task, &r);
+  if (rc) return rc;
+  out[0] = r.ed; out[1] = r.num_loc; out[2] = r.end_loc; out[3] = r.start_loc;
+  int L = r.aln_len;
+  if (r.aln && L <= cap) memcpy(aln, r.aln, (size_t)L);
+  free(r.aln);
+  return L;
+}
+
+/* infixStart / infixEnd  src/util.h:86-99 */
+static uint32_t infix_start(const ed_res* c) {
+  int32_t tIdx = c->end_loc;
+  for (int i = 0; i < c->aln_len; ++i) if (c->aln[i] != OP_INSERT) --tIdx;
+  return tIdx >= 0 ? (uint32_t)(tIdx + 1) : 0u;
+}
+
+/* editDistanceVec  src/split.h:377-405 */
+static void edit_distance_vec(const char* sI, int nI, const char* sJ, const ed_res* c, uint32_t* dist) {
+  for (int i = 0; i < nI; ++i) dist[i] = 0;
+  int32_t tIdx = -1, qIdx = -1;
+  uint32_t ed = 0;
+  for (int j = 0; j < c->aln_len; ++j) {
+    if (c->aln[j] == OP_DELETE) { ++tIdx; ++ed; }
+    else if (c->aln[j] == OP_INSERT) { ++qIdx; ++ed; dist[qIdx] = ed; }
+    else { ++tIdx; ++qIdx; if (sI[qIdx] != sJ[tIdx]) ++ed; dist[qIdx] = ed; }
+  }
+}
+
+/* splitAlign  src/split.h:480-538 + the row swap of _consRefAlignment :546-552.
+ * Returns 1 ok, 0 false, <0 error; *out rows: [0] consensus, [1] reference.
+ * internals[5] = {csStart, csEnd, bestJoin, leftEnd, rightStart} (-1 when not reached). */
+static int split_align(const char* cons, int m, const char* ref, int n, amat* out, int* internals) {
+  for (int i = 0; i < 5; ++i) internals[i] = -1;
+  out->d = NULL; out->rows = 2; out->cols = 0;
+  if (n < 3) return DOR_ED_LIMIT; /* the reference indexes distRev[n-2] and loops to size()-1 */
+  ed_res c;
+  int rc;
+  if ((rc = ed_align(ref, n / 3, cons, m, ED_HW, 2, &c))) return rc;
+  uint32_t csStart = infix_start(&c);
+  free(c.aln);
+  int so = (int)(2 * (size_t)n / 3);
+  if ((rc = ed_align(ref + so, n - so, cons, m, ED_HW, 2, &c))) return rc;
+  uint32_t csEnd = (uint32_t)c.end_loc;
+  free(c.aln);
+  internals[0] = (int)csStart;
+  internals[1] = (int)csEnd;
+  if (csStart >= csEnd) return 0;
+  /* std::string::substr(pos, len): len clamped to size - pos */
+  uint32_t csl = csEnd - csStart;
+  if (csl > (uint32_t)m - csStart) csl = (uint32_t)m - csStart;
+  const char* cs = cons + csStart;
+  uint32_t* distFwd = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+  uint32_t* distRev = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+  if ((rc = ed_align(ref, n, cs, (int)csl, ED_SHW, 2, &c))) { free(distFwd); free(distRev); return rc; }
+  edit_distance_vec(ref, n, cs, &c, distFwd);
+  free(c.aln);
+  char* refRev = (char*)malloc((size_t)n + 1);
+  char* csRev = (char*)malloc((size_t)csl + 1);
+  memcpy(refRev, ref, (size_t)n);
+  memcpy(csRev, cs, (size_t)csl);
+  dor_reverse_complement(refRev, n);
+  dor_reverse_complement(csRev, (int)csl);
+  if ((rc = ed_align(refRev, n, csRev, (int)csl, ED_SHW, 2, &c))) { free(distFwd); free(distRev); free(refRev); free(csRev); return rc; }
+  edit_distance_vec(refRev, n, csRev, &c, distRev);
+  free(c.aln);
+  free(refRev);
+  free(csRev);
+  uint32_t bestJoin = 0;
+  for (uint32_t i = 1; i < (uint32_t)n - 1; ++i)
+    if (distFwd[i] + distRev[n - i - 2] < distFwd[bestJoin] + distRev[n - bestJoin - 2]) bestJoin = i;
+  free(distFwd);
+  free(distRev);
+  internals[2] = (int)bestJoin;
+  ed_res cl, cr;
+  if ((rc = ed_align(ref, (int)bestJoin + 1, cons, m, ED_HW, 2, &cl))) return rc;
+  uint32_t leftEnd = (uint32_t)cl.end_loc;
+  if ((rc = ed_align(ref + bestJoin + 1, n - (int)bestJoin - 1, cons, m, ED_HW, 2, &cr))) { free(cl.aln); return rc; }
+  uint32_t rightStart = infix_start(&cr);
+  internals[3] = (int)leftEnd;
+  internals[4] = (int)rightStart;
+  if (leftEnd + 15u >= rightStart) { free(cl.aln); free(cr.aln); return 0; }
+  /* glueAlignment(svRefStr, cons, gaplen, HW, ...)  split.h:407-477: row 0 query (ref), row 1 target (cons) */
+  uint32_t gaplen = rightStart - leftEnd - 1u;
+  int32_t tIdx = cl.end_loc, qIdx = -1;
+  uint32_t missingStart = 0;
+  for (int i = 0; i < cl.aln_len; ++i) if (cl.aln[i] != OP_INSERT) --tIdx;
+  if (tIdx >= 0) missingStart = (uint32_t)tIdx + 1u;
+  uint32_t missingEnd = (uint32_t)cr.end_loc;
+  if (missingEnd < (uint32_t)m) missingEnd = (uint32_t)m - missingEnd - 1u;
+  uint64_t total = (uint64_t)missingStart + (uint64_t)cl.aln_len + gaplen + (uint64_t)cr.aln_len + missingEnd;
+  if (total > (uint64_t)m + (uint64_t)n + 8) { free(cl.aln); free(cr.aln); return DOR_ED_LIMIT; }
+  amat g = amat_new(2, (int)total);
+  uint32_t o = 0;
+  for (uint32_t j = 0; j < missingStart; ++j) { AT(g, 1, j) = cons[j]; AT(g, 0, j) = '-'; }
+  o = missingStart;
+  for (int j = 0; j < cl.aln_len; ++j) {
+    if (cl.aln[j] == OP_INSERT) AT(g, 1, o + j) = '-';
+    else AT(g, 1, o + j) = cons[++tIdx];
+  }
+  for (int j = 0; j < cl.aln_len; ++j) {
+    if (cl.aln[j] == OP_DELETE) AT(g, 0, o + j) = '-';
+    else AT(g, 0, o + j) = ref[++qIdx];
+  }
+  o += (uint32_t)cl.aln_len;
+  for (uint32_t j = 0; j < gaplen; ++j) { AT(g, 0, o + j) = '-'; AT(g, 1, o + j) = cons[++tIdx]; }
+  o += gaplen;
+  for (int j = 0; j < cr.aln_len; ++j) {
+    if (cr.aln[j] == OP_INSERT) AT(g, 1, o + j) = '-';
+    else AT(g, 1, o + j) = cons[++tIdx];
+  }
+  for (int j = 0; j < cr.aln_len; ++j) {
+    if (cr.aln[j] == OP_DELETE) AT(g, 0, o + j) = '-';
+    else AT(g, 0, o + j) = ref[++qIdx];
+  }
+  o += (uint32_t)cr.aln_len;
+  for (uint32_t j = 0; j < missingEnd; ++j) { AT(g, 1, o + j) = cons[++tIdx]; AT(g, 0, o + j) = '-'; }
+  free(cl.aln);
+  free(cr.aln);
+  /* swap rows: split.h:548-552 */
+  for (int j = 0; j < g.cols; ++j) { char x = AT(g, 0, j); AT(g, 0, j) = AT(g, 1, j); AT(g, 1, j) = x; }
+  *out = g;
+  return 1;
+}
+
+int dor_split_align(const char* cons, int m, const char* ref, int n, char* rows, int cap, int* len, int* internals) {
+  amat g;
+  int in5[5];
+  int rc = split_align(cons, m, ref, n, &g, in5);
+  if (internals) memcpy(internals, in5, sizeof(in5));
+  *len = (rc == 1) ? g.cols : 0;
+  if (rc != 1) return rc;
+  if (g.cols > cap) { amat_free(&g); return -1; }
+  memcpy(rows, g.d, (size_t)g.cols);
+  memcpy(rows + cap, g.d + g.cols, (size_t)g.cols);
+  amat_free(&g);
+  return 1;
+}
+
+/* ------------------------------------------------------------------------ */
 /* batch driver: loop body of src/shortpe.h:183-197 (msa + alignConsensus)    */
 
 typedef struct {
@@ -985,11 +1258,6 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   R->cons_len = m;
   R->cons_off = blob_put(b, cons, (uint64_t)m);
 
-  if (J->svt == 4) { /* splitAlign/edlib not restated */
-    R->status = DELLYHIP_E_LIMIT;
-    free(cons);
-    return;
-  }
   /* alignConsensus  split.h:644-666 */
   if (m < (2 * c->minimum_flank_size + J->ins_len)) {
     free(cons);
@@ -1001,7 +1269,10 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   bp.svt = J->svt;
   bp.chr = J->chr;
   bp.chr2 = J->chr2;
-  init_breakpoint(b->chr_len, &bp, m, J->svt);
+  if (J->svt == 4) { /* split.h:650-652: size_t arithmetic, then (int32_t) */
+    int32_t bufferSpace = imax((int32_t)(((size_t)m - (size_t)J->ins_len) / 3), c->minimum_flank_size);
+    init_breakpoint(b->chr_len, &bp, bufferSpace, J->svt);
+  } else init_breakpoint(b->chr_len, &bp, m, J->svt);
   sbuf part1, ref;
   sb_init(&part1);
   sb_init(&ref);
@@ -1014,7 +1285,14 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   /* _alignConsensus split.h:560-642 (realign=false) */
   amat al;
   int diag[5];
-  int found = long_needle_core(cons, m, ref.d, n, &al, diag);
+  int found;
+  if (J->svt == 4) { /* _consRefAlignment split.h:546-552; diag = {csStart, csEnd, bestJoin, leftEnd, rightStart} */
+    found = split_align(cons, m, ref.d, n, &al, diag);
+    if (found < 0) {
+      R->status = DELLYHIP_E_LIMIT;
+      found = 0;
+    }
+  } else found = long_needle_core(cons, m, ref.d, n, &al, diag);
   R->score_unsplit = diag[0];
   R->score_best = diag[1];
   R->cons_left = diag[2];

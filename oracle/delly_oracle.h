@@ -10,9 +10,10 @@
  * bit-identical outputs on seeded inputs (the reference ships no tests or
  * golden vectors of its own -- SURVEY.md F8).
  *
- * NOT restated (yet): svt==4 insertions (splitAlign -> edlib) and the
- * long-read MSA (msaEdlib/msaWfa); dor_refine_batch reports
- * DELLYHIP_E_LIMIT in result.status for those.
+ * edlib (vendored by the reference, src/edlib.cpp) is restated as a plain
+ * unit-cost DP for the traceback regime (alignment data < 1 MiB); Hirschberg
+ * mode and the long-read MSA (msaEdlib/msaWfa) are NOT restated:
+ * dor_refine_batch reports DELLYHIP_E_LIMIT in result.status for those.
  */
 #ifndef DELLY_ORACLE_H
 #define DELLY_ORACLE_H
@@ -31,6 +32,14 @@ int dor_longest_homology(const char* a, int la, const char* b, int lb, int thr);
  * {mat[m][n], bestScore, consLeft, refLeft, refRight} */
 int dor_long_needle(const char* s1, int m, const char* s2, int n, char* rows, int cap, int* len,
                     int* diag);
+/* edlibAlign(q, t, {-1, mode, task}); mode 0 NW/1 SHW/2 HW, task 0 DISTANCE/1 LOC/2 PATH;
+ * out[4] = {editDistance, numLocations, endLocations[0], startLocations[0]}; returns alignmentLength or <0 */
+int dor_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int task, int* out,
+                    unsigned char* aln, int cap);
+/* splitAlign + row swap (split.h:480-552); rows[0..len) consensus row, rows[cap..) reference row;
+ * internals[5] = {csStart, csEnd, bestJoin, leftEnd, rightStart} */
+int dor_split_align(const char* cons, int m, const char* ref, int n, char* rows, int cap, int* len,
+                    int* internals);
 int dor_gotoh(const dellyhip_params* p, const char* a1, int r1, int m, const char* a2, int r2, int n,
               char* out, int cap, int* len);
 int dor_consensus(const dellyhip_params* p, const char* a, int r, int m, char* cs, int cap);

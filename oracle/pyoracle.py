@@ -94,6 +94,37 @@ class Oracle:
         L = ln.value
         return bool(rc), rows[:L].tobytes(), rows[cap:cap + L].tobytes(), d
 
+    def edlib_align(self, q, t, mode, task=2):
+        """edlibAlign(q, t, {k=-1, mode, task}); mode 0 NW / 1 SHW / 2 HW; task 0 DISTANCE / 1 LOC / 2 PATH
+        -> (editDistance, numLocations, endLocations[0], startLocations[0], ops bytes) or None (port: Hirschberg regime)"""
+        q, t = _u8(q), _u8(t)
+        cap = q.size + t.size + 8
+        aln = np.zeros(cap, dtype=np.uint8)
+        out = (C.c_int * 4)()
+        L = self._f("edlib_align")(_p(q), q.size, _p(t), t.size, mode, task, out, _p(aln, C.POINTER(C.c_ubyte)), cap)
+        if L < 0:
+            return None
+        o = list(out)
+        if self.kind == "port":  # the port reports numLocations only for the modes that enumerate them
+            pass
+        return o[0], o[1], o[2], o[3], aln[:L].tobytes()
+
+    def split_align(self, cons, ref):
+        """splitAlign + row swap -> (rc, cons_row, ref_row, internals or None)"""
+        cons, ref = _u8(cons), _u8(ref)
+        cap = cons.size + ref.size + 16
+        rows = np.zeros(2 * cap, dtype=np.uint8)
+        ln = C.c_int(0)
+        if self.kind == "port":
+            internals = (C.c_int * 5)()
+            rc = self._f("split_align")(_p(cons), cons.size, _p(ref), ref.size, _p(rows), cap, C.byref(ln), internals)
+            d = list(internals)
+        else:
+            rc = self._f("split_align")(_p(cons), cons.size, _p(ref), ref.size, _p(rows), cap, C.byref(ln))
+            d = None
+        L = ln.value
+        return rc, rows[:L].tobytes(), rows[cap:cap + L].tobytes(), d
+
     def gotoh(self, a1, a2):
         """a1, a2: lists of equal-length byte strings (alignment rows) -> (score, rows)"""
         r1, m = len(a1), len(a1[0])

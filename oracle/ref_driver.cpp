@@ -236,6 +236,40 @@ int dref_long_needle(const char* s1, int m, const char* s2, int n, char* rows, i
   return 1;
 }
 
+// edlibAlign(query, target, {k=-1, mode, task, no extra equalities})  src/edlib.cpp:139-300,
+// as called by splitAlign (src/split.h:485-527) and _alignConsensus (:568-569).
+// mode: 0 NW, 1 SHW, 2 HW (EdlibAlignMode); task: 0 DISTANCE, 1 LOC, 2 PATH.
+// out[4] = {editDistance, numLocations, endLocations[0], startLocations[0]} (locations -2 when absent).
+// Returns alignmentLength (ops copied to aln when it fits cap).
+int dref_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int task, int* out,
+                     unsigned char* aln, int cap) {
+  EdlibAlignResult r = edlibAlign(q, qn, t, tn, edlibNewAlignConfig(-1, (EdlibAlignMode)mode, (EdlibAlignTask)task, NULL, 0));
+  out[0] = r.editDistance;
+  out[1] = r.numLocations;
+  out[2] = r.endLocations ? r.endLocations[0] : -2;
+  out[3] = r.startLocations ? r.startLocations[0] : -2;
+  int L = r.alignmentLength;
+  if (r.alignment && L <= cap) std::memcpy(aln, r.alignment, (size_t)L);
+  edlibFreeAlignResult(r);
+  return L;
+}
+
+// splitAlign(cons, svRefStr, align)  src/split.h:480-538 followed by the row swap of
+// _consRefAlignment (:546-552).  Returns 1/0, rows[0..len) = consensus row, rows[cap..cap+len) = ref row.
+int dref_split_align(const char* cons, int m, const char* ref, int n, char* rows, int cap, int* len) {
+  using namespace torali;
+  TAlign aln;
+  bool ok = _consRefAlignment(std::string(cons, cons + m), std::string(ref, ref + n), aln, 4);
+  int L = (int)aln.shape()[1];
+  *len = L;
+  if (L > cap) return -1;
+  for (int j = 0; j < L; ++j) {
+    rows[j] = aln[0][j];
+    rows[(size_t)cap + j] = aln[1][j];
+  }
+  return ok ? 1 : 0;
+}
+
 // gotoh(a1, a2, align, AlignConfig<true,true>, c.aliscore)  src/gotoh.h:71-174
 // as called by palign, src/msa.h:106-107.
 int dref_gotoh(const dellyhip_params* p, const char* a1, int r1, int m, const char* a2, int r2,

@@ -27,6 +27,8 @@ BATCHES = {
     "full_c2_n8": (24, dict(mode="c2", seed=43, first=0, n_reads=8)),
     "full_mixed_n5": (36, dict(mode="mixed", seed=44, first=0, n_reads=5)),
     "full_c2_n20": (6, dict(mode="c2", seed=45, first=0, n_reads=20)),
+    "u_ins": (160, dict(mode="ins", seed=46, first=0)),
+    "full_ins_n6": (30, dict(mode="ins", seed=47, first=0, n_reads=6)),
 }
 
 
@@ -34,15 +36,84 @@ def random_seq(rng, n, alphabet=b"ACGT"):
     return bytes(rng.choice(list(alphabet), n).astype(np.uint8))
 
 
+def edlib_vectors(ref):
+    """edlibAlign (NW/SHW/HW, PATH) and splitAlign on seeded strings -> edlib.npz"""
+    rng = np.random.default_rng(20260926)
+
+    def mutate(s, rate):
+        out = bytearray()
+        for ch in s:
+            u = rng.random()
+            if u < rate / 3:
+                continue
+            if u < 2 * rate / 3:
+                out.append(rng.choice(list(b"ACGT")))
+                out.append(ch)
+                continue
+            if u < rate:
+                out.append(rng.choice(list(b"ACGT")))
+                continue
+            out.append(ch)
+        return bytes(out)
+
+    q_l, t_l, mode_l, out_l, ops_l = [], [], [], [], []
+    for it in range(240):
+        kind = it % 6
+        qn = int(rng.integers(1, 200))
+        if it % 7 == 0:
+            qn = 64 * int(rng.integers(1, 4))
+        if kind < 2:
+            t = random_seq(rng, int(rng.integers(1, 320)))
+            a = int(rng.integers(0, len(t)))
+            q = mutate(t[a:a + qn], float(rng.choice([0.0, 0.02, 0.1, 0.3]))) or b"A"
+        elif kind == 2:
+            q, t = random_seq(rng, qn), random_seq(rng, int(rng.integers(1, 320)))
+        elif kind == 3:
+            q, t = random_seq(rng, qn, b"AC"), random_seq(rng, int(rng.integers(1, 100)), b"GT")
+        elif kind == 4:
+            q, t = random_seq(rng, qn, b"A"), random_seq(rng, int(rng.integers(1, 100)), b"AC")
+        else:
+            t = random_seq(rng, int(rng.integers(1, 320)))
+            q = mutate(t, 0.05) or b"C"
+        for mode in (0, 1, 2):
+            ed, nl, el, sl, ops = ref.edlib_align(q, t, mode, 2)
+            q_l.append(q); t_l.append(t); mode_l.append(mode); out_l.append((ed, nl, el, sl)); ops_l.append(ops)
+    d = dict(q=np.array(q_l, dtype=object), t=np.array(t_l, dtype=object), mode=np.array(mode_l, dtype=np.int32),
+             out=np.array(out_l, dtype=np.int32), ops=np.array(ops_l, dtype=object))
+    # splitAlign: reference window vs consensus with a planted insertion
+    c_l, r_l, rc_l, r0_l, r1_l = [], [], [], [], []
+    for it in range(60):
+        n = int(rng.integers(60, 260))
+        refw = random_seq(rng, n, b"ACGT" if it % 5 else b"ACGTN")
+        cut = int(rng.integers(n // 3, 2 * n // 3))
+        ins = random_seq(rng, int(rng.integers(0, 120))) if it % 6 else refw[max(0, cut - 40):cut]
+        a = int(rng.integers(0, n // 4))
+        b = int(rng.integers(3 * n // 4, n))
+        cons = mutate(refw[a:cut] + ins + refw[cut:b], 0.01) or b"A"
+        rc, r0, r1, _ = ref.split_align(cons, refw)
+        c_l.append(cons); r_l.append(refw); rc_l.append(rc); r0_l.append(r0); r1_l.append(r1)
+    d.update(sa_cons=np.array(c_l, dtype=object), sa_ref=np.array(r_l, dtype=object), sa_rc=np.array(rc_l, dtype=np.int32),
+             sa_row0=np.array(r0_l, dtype=object), sa_row1=np.array(r1_l, dtype=object))
+    np.savez_compressed(os.path.join(HERE, "edlib.npz"), **d)
+    print("edlib ok: %d alignments, %d splitAlign (%d true)" % (len(q_l), len(c_l), int(np.sum(np.array(rc_l) == 1))))
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Oracle("reference")
+    only = sys.argv[1:]  # e.g. "u_ins edlib": regenerate just these (zip timestamps churn otherwise)
+    if not only or "edlib" in only:
+        edlib_vectors(ref)
     # --- batches ---------------------------------------------------------------
     for name, (n, kw) in BATCHES.items():
+        if only and name not in only:
+            continue
         b = synth.make_batch(n, **kw)
         res, blob = ref.refine_batch(b, want_alignment=True)
         np.savez_compressed(os.path.join(HERE, "batch_%s.npz" % name), n=n, kwargs=repr(kw), results=res, blob=blob)
         print(name, "ok=%d/%d" % (int(res["ok"].sum()), n))
+    if only and "primitives" not in only:
+        return
     # --- primitives ------------------------------------------------------------
     rng = np.random.default_rng(20260925)
     prim = {}

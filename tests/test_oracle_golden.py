@@ -52,7 +52,37 @@ def test_port_reproduces_golden_primitives(port):
         assert port.consensus(list(rows)) == cons
 
 
-@pytest.mark.parametrize("mode,n_reads,n", [("c2", 0, 150), ("mixed", 0, 180), ("mixed", 7, 36), ("c2", 12, 12)])
+def test_port_reproduces_golden_edlib(port):
+    """the plain-DP restatement of edlib against vectors produced by the reference's vendored edlib"""
+    g = np.load(os.path.join(GOLD, "edlib.npz"), allow_pickle=True)
+    for q, t, mode, out, ops in zip(g["q"], g["t"], g["mode"], g["out"], g["ops"]):
+        r = port.edlib_align(q, t, int(mode), 2)
+        assert r is not None
+        assert tuple(r[:4]) == tuple(int(x) for x in out) and r[4] == ops, (len(q), len(t), int(mode))
+    for cons, ref, rc, r0, r1 in zip(g["sa_cons"], g["sa_ref"], g["sa_rc"], g["sa_row0"], g["sa_row1"]):
+        prc, p0, p1, _ = port.split_align(cons, ref)
+        assert (prc, p0, p1) == (int(rc), r0, r1)
+
+
+def test_port_edlib_vs_reference_fresh(port, reference):
+    rng = np.random.default_rng(99)
+    for it in range(300):
+        t = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 330))).astype(np.uint8))
+        if it % 3 == 0:
+            q = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 260))).astype(np.uint8))
+        else:
+            a = int(rng.integers(0, len(t)))
+            q = bytearray(t[a:a + int(rng.integers(1, 200))])
+            for k in range(len(q)):
+                if rng.random() < 0.05:
+                    q[k] = rng.choice(list(b"ACGT"))
+            q = bytes(q)
+        for mode in (0, 1, 2):
+            assert port.edlib_align(q, t, mode) == reference.edlib_align(q, t, mode), (it, mode)
+
+
+@pytest.mark.parametrize("mode,n_reads,n", [("c2", 0, 150), ("mixed", 0, 180), ("mixed", 7, 36), ("c2", 12, 12),
+                                            ("ins", 0, 150), ("ins", 6, 24)])
 def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
     b = synth.make_batch(n, mode=mode, n_reads=n_reads, seed=777, first=5000)
     rr, rb = reference.refine_batch(b)
