@@ -620,6 +620,43 @@ int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char*
   return rc;
 }
 
+int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const char* target, int32_t tn, int32_t mode,
+                         int32_t task, int32_t out[4], unsigned char* ops, int32_t ops_cap, int32_t* ops_len) {
+  if (!c || !out || !ops_len || qn < 0 || tn < 0 || (qn && !query) || (tn && !target) || mode < 0 || mode > 2 ||
+      task < 0 || task > 2)
+    return fail(DELLYHIP_E_ARG, "bad argument");
+  *ops_len = 0;
+  if (qn == 0 || tn == 0) {  // edlib.cpp:160-178: no locations beyond the end, no alignment
+    out[0] = (mode == 0) ? std::max(qn, tn) : qn;
+    out[1] = 1;
+    out[2] = (mode == 0) ? tn - 1 : -1;
+    out[3] = -2;
+    return 0;
+  }
+  if (tn > dh::MMAX || qn > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "edlibAlign operand exceeds the insertion-kernel limits");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_scratch(c))) return rc;
+  DevBuf<uint8_t> dq, dt, dops;
+  DevBuf<int32_t> dout;
+  if ((rc = dq.alloc(qn)) || (rc = dt.alloc(tn)) || (rc = dops.alloc(qn + tn + 8)) || (rc = dout.alloc(8))) return rc;
+  HIPCHK(hipMemcpy(dq.p, query, qn, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dt.p, target, tn, hipMemcpyHostToDevice));
+  dh::EdArgs a{dq.p, dt.p, qn, tn, mode, task, dout.p, dops.p, c->scratch.p};
+  hipLaunchKernelGGL(dh::edlib_single_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int32_t h[5];
+  HIPCHK(hipMemcpy(h, dout.p, sizeof h, hipMemcpyDeviceToHost));
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+  *ops_len = h[4];
+  if (h[4] > 0) {
+    if (!ops || h[4] > ops_cap) return fail(DELLYHIP_E_ARG, "ops buffer too small");
+    HIPCHK(hipMemcpy(ops, dops.p, h[4], hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 int dellyhip_lcs(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, int32_t* out) {
   if (!c || !out) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));

@@ -34,6 +34,7 @@ struct __attribute__((aligned(16))) InsLds {
 struct EdKeys {
   unsigned kf;  // min over rows of (E[r][qlen] << 12) | r          -> first optimal end
   unsigned kl;  // min over rows of (E[r][qlen] << 12) | (4095 - r) -> last optimal end
+  int cnt;      // number of rows attaining the minimum (edlib's numLocations)
 };
 
 // One DP pass.  Row r (slot r = lane*K + i, 0..tlen) is target prefix length r, column c is
@@ -120,6 +121,13 @@ __device__ __forceinline__ EdKeys pass_ed(const uint8_t* tp, int tstep, int tlen
   EdKeys k;
   k.kf = (unsigned)rfl((int)kf);
   k.kl = (unsigned)rfl((int)kl);
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int r = lane * K + i;
+    cnt += __popcll(__ballot(r >= r0 && r <= tlen && (unsigned)colq[i] == (k.kf >> 12)));
+  }
+  k.cnt = cnt;
   return k;
 }
 
@@ -132,6 +140,7 @@ __device__ __noinline__ EdKeys ed_pass(const uint8_t* tp, int tstep, int tlen, c
   const int kd = ed_rows_per_lane(tlen);
   EdKeys k;
   k.kf = k.kl = 0xffffffffu;
+  k.cnt = 0;
   if (kd <= 1) k = pass_ed<1, DIRS>(tp, tstep, tlen, qp, qstep, qlen, hw, r0, dirs, lane);
   else if (kd == 2) k = pass_ed<2, DIRS>(tp, tstep, tlen, qp, qstep, qlen, hw, r0, dirs, lane);
   else if (kd == 3) k = pass_ed<3, DIRS>(tp, tstep, tlen, qp, qstep, qlen, hw, r0, dirs, lane);
@@ -203,6 +212,7 @@ struct EdRes {
   int endLoc;    // endLocations[0]
   int startLoc;  // startLocations[0]
   int nops;      // alignmentLength (ops in tr[], reverse order)
+  int nloc;      // numLocations
 };
 
 // number of the first admissible row of the last column: "position -1" (no target letter
@@ -229,6 +239,7 @@ __device__ __forceinline__ EdRes ed_hw(const uint8_t* T, int tn, const uint8_t* 
   o.endLoc = (int)(k.kf & 4095u) - 1;
   o.startLoc = 0;
   o.nops = 0;
+  o.nloc = k.cnt;
   if (!loc) return o;
   if (o.endLoc == -1) {  // edlib.cpp:222-235
     if (path) o.nops = fill_inserts(tr, qn, lane);
@@ -259,6 +270,7 @@ __device__ __forceinline__ EdRes ed_shw(const uint8_t* T, int tn, const uint8_t*
   o.ed = (int)(k.kf >> 12);
   o.endLoc = (int)(k.kf & 4095u) - 1;
   o.startLoc = 0;
+  o.nloc = k.cnt;
   if (o.endLoc == -1) o.nops = fill_inserts(tr, qn, lane);
   else o.nops = traceback_ed(dirs, ed_rows_per_lane(tn), o.endLoc + 1, qn, tr, lane);
   return o;
@@ -407,6 +419,62 @@ __device__ void process_ins(const SplitArgs& A, int j, InsLds& L, uint32_t* scra
   }
   X.go = go;
   split_detect(A, X, L.s, L.p, go, Ltot, Ltot, lane);
+}
+
+// ---- single edlibAlign call (parity tests; edlib.h:242-246) ----------------------------
+struct EdArgs {
+  const uint8_t* q;   // query, qn <= NMAX
+  const uint8_t* t;   // target, tn <= MMAX
+  int32_t qn, tn;
+  int32_t mode;       // EdlibAlignMode: 0 NW, 1 SHW, 2 HW
+  int32_t task;       // EdlibAlignTask: 0 DISTANCE, 1 LOC, 2 PATH
+  int32_t* out;       // {editDistance, numLocations, endLocations[0], startLocations[0] (-2: not computed), alignmentLength}
+  uint8_t* ops;       // alignment (EDLIB_EDOP_*), forward order
+  uint32_t* scratch;
+};
+
+__global__ __launch_bounds__(WAVE) void edlib_single_kernel(EdArgs a) {
+  __shared__ uint8_t q[NMAX];
+  __shared__ uint8_t t[MMAX + 1];
+  __shared__ uint8_t tr[TRACE_CAP];
+  const int lane = threadIdx.x;
+  const int qn = a.qn, tn = a.tn;
+  for (int i = lane; i < qn; i += WAVE) q[i] = a.q[i];
+  for (int i = lane; i < tn; i += WAVE) t[i] = a.t[i];
+  __syncthreads();
+  EdRes o;
+  const bool loc = a.task >= 1, path = a.task >= 2;
+  if (a.mode == 2) {
+    o = ed_hw(t, tn, q, qn, loc, path, a.scratch, tr, lane);
+  } else if (a.mode == 1) {
+    if (path) o = ed_shw(t, tn, q, qn, a.scratch, tr, lane);
+    else {
+      const EdKeys k = ed_pass<false>(t, 1, tn, q, 1, qn, 0, ed_first_row(qn), a.scratch, lane);
+      o.ed = (int)(k.kf >> 12);
+      o.endLoc = (int)(k.kf & 4095u) - 1;
+      o.startLoc = 0;
+      o.nops = 0;
+      o.nloc = k.cnt;
+    }
+  } else {  // NW: the single admissible end is the last row
+    EdKeys k;
+    if (path) k = ed_pass<true>(t, 1, tn, q, 1, qn, 0, tn, a.scratch, lane);
+    else k = ed_pass<false>(t, 1, tn, q, 1, qn, 0, tn, a.scratch, lane);
+    o.ed = (int)(k.kf >> 12);
+    o.endLoc = tn - 1;
+    o.startLoc = 0;
+    o.nloc = 1;
+    o.nops = path ? traceback_ed(a.scratch, ed_rows_per_lane(tn), tn, qn, tr, lane) : 0;
+  }
+  __syncthreads();
+  for (int i = lane; i < o.nops; i += WAVE) a.ops[i] = tr[o.nops - 1 - i];
+  if (lane == 0) {
+    a.out[0] = o.ed;
+    a.out[1] = o.nloc;
+    a.out[2] = o.endLoc;
+    a.out[3] = loc ? o.startLoc : -2;
+    a.out[4] = o.nops;
+  }
 }
 
 __global__ __launch_bounds__(WAVE) void ins_kernel(SplitArgs A) {

@@ -26,7 +26,7 @@ EXPORTS = [
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
     "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
-    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info",
+    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align",
 ]
 
 
@@ -141,6 +141,17 @@ class Context:
                                                   C.byref(ln), C.byref(found)))
         L = ln.value if found.value else 0
         return bool(found.value), rows[:L].tobytes(), rows[cap:cap + L].tobytes()
+
+    def edlib_align(self, q, t, mode, task=2):
+        """edlibAlign(q, t, {k=-1, mode, task}) -> (editDistance, numLocations, endLoc, startLoc, ops)"""
+        q, t = _u8(q), _u8(t)
+        cap = q.size + t.size + 8
+        ops = np.zeros(cap, dtype=np.uint8)
+        out = (C.c_int32 * 4)()
+        ln = C.c_int32(0)
+        self._check(self.lib.dellyhip_edlib_align(self._ctx, _p(q), q.size, _p(t), t.size, mode, task, out,
+                                                  ops.ctypes.data_as(C.POINTER(C.c_ubyte)), cap, C.byref(ln)))
+        return out[0], out[1], out[2], out[3], ops[:ln.value].tobytes()
 
     def lcs(self, a, b):
         a, b = _u8(a), _u8(b)

@@ -190,6 +190,20 @@ int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms
 int dellyhip_long_needle(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
                          char* align_rows, int32_t aln_cap, int32_t* aln_len, int32_t* found);
 
+/* EdlibAlignResult edlibAlign(query, queryLength, target, targetLength,
+ *                             edlibNewAlignConfig(-1, mode, task, NULL, 0))
+ * src/edlib.h:242-246, src/edlib.cpp:139-300 -- the calls made by splitAlign
+ * (src/split.h:485-527, HW/SHW + PATH) and _alignConsensus (src/split.h:568-569,
+ * NW + DISTANCE).  mode = EdlibAlignMode (0 NW, 1 SHW, 2 HW), task =
+ * EdlibAlignTask (0 DISTANCE, 1 LOC, 2 PATH).  out[4] = {editDistance,
+ * numLocations, endLocations[0], startLocations[0]} (start = -2 for DISTANCE);
+ * ops receives the EDLIB_EDOP_* alignment of the first location (PATH).
+ * Limits of this wrapper: targetLength <= 319, queryLength <= 2048 (the shapes
+ * of the short-read insertion path; edlib's Hirschberg regime is not reached). */
+int dellyhip_edlib_align(dellyhip_ctx* ctx, const char* query, int32_t query_len, const char* target,
+                         int32_t target_len, int32_t mode, int32_t task, int32_t out[4],
+                         unsigned char* ops, int32_t ops_cap, int32_t* ops_len);
+
 /* int lcs(s1, s2)  src/msa.h:10-30 */
 int dellyhip_lcs(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
                  int32_t* out);
