@@ -87,7 +87,9 @@ typedef struct dellyhip_result {
   int32_t mismatches;
   int32_t c_start, c_end, r_start, r_end; /* AlignDescriptor (src/split.h:15)   */
   int32_t hom_left, hom_right;
-  /* longNeedle internals (parity diagnostics; src/needle.h:104-123) */
+  /* longNeedle internals (parity diagnostics; src/needle.h:104-123).  For svt 4
+   * (splitAlign, src/split.h:480-538) the five slots carry csStart, csEnd,
+   * bestJoin, leftEnd, rightStart instead; -1 = not reached. */
   int32_t score_unsplit;  /* mat[m][n]            */
   int32_t score_best;     /* bestScore            */
   int32_t cons_left, ref_left, ref_right;

@@ -6,7 +6,8 @@ from delly_amd import refine, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-b = synth.make_batch(n, mode="c2", n_reads=nreads)
+mode = sys.argv[4] if len(sys.argv) > 4 else "c2"
+b = synth.make_batch(n, mode=mode, n_reads=nreads)
 ctx = refine.Context()
 ctx.set_chromosomes(b.chroms)
 rb = ctx.upload(b)
@@ -18,5 +19,19 @@ rb.sync()
 dt = (time.perf_counter() - t) / steps
 ms_split, ms_msa, _ = rb.kernel_ms()
 res, _ = rb.fetch()
-print("U_full n=%d reads=%d: %.2f ms/step -> %.0f junctions/s | msa kernel %.2f ms, split %.2f ms | ok %d mean cons %.0f" % (
+print(mode + " n=%d reads=%d: %.2f ms/step -> %.0f junctions/s | msa kernel %.2f ms, split %.2f ms | ok %d mean cons %.0f" % (
     n, nreads, dt * 1e3, n / dt, ms_msa, ms_split, int(res["ok"].sum()), res["cons_len"].mean()), flush=True)
+
+if len(sys.argv) > 5:  # CPU reference beside it (oracle/_ref, all host threads) -- test infrastructure, not the product
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyoracle
+    kind = "reference" if pyoracle.have_reference() else "port"
+    O = pyoracle.Oracle(kind)
+    sub = synth.make_batch(min(n, 2048), mode=mode, n_reads=nreads)
+    for th in (1, os.cpu_count()):
+        k = sub.n if th > 1 else min(sub.n, 128)
+        s1 = synth.make_batch(k, mode=mode, n_reads=nreads)
+        t = time.perf_counter()
+        O.refine_batch(s1, want_alignment=False, n_threads=th)
+        dt = time.perf_counter() - t
+        print("cpu %s threads=%d: %d junctions in %.2f s -> %.0f junctions/s" % (kind, th, k, dt, k / dt), flush=True)
