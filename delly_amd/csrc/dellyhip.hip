@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,6 +47,8 @@ struct DevBuf {
     if (e != hipSuccess) { p = nullptr; n = 0; return fail(DELLYHIP_E_NOMEM, "hipMalloc", e); }
     return 0;
   }
+  // keeps the allocation when it is already large enough (hipMalloc/hipFree synchronise the device)
+  int reserve(size_t count) { return (p && n >= count) ? 0 : alloc(count); }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -71,6 +74,7 @@ struct dellyhip_ctx {
   uint64_t scratch_words = 0;
   int scratch_blocks = 0;
   DevBuf<int32_t> counters;  // work counters (one per K bin + MSA)
+  int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
 };
 
 struct dellyhip_batch {
@@ -245,7 +249,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->ins_first = (int)work.size();
   b->ins_count = (int)ins.size();
   work.insert(work.end(), ins.begin(), ins.end());
-  int rc = b->work.alloc(std::max<size_t>(work.size(), 2));
+  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 2));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
@@ -286,6 +290,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   c->device = device;
   c->params = *params;
   c->n_cu = prop.multiProcessorCount;
+  if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -442,6 +447,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.ws_stride = b->msa_ws_stride;
     ma.n_work = b->n;
     ma.work_counter = c->counters.p;
+    ma.defer_counter = c->counters.p + 8;
+    ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
     int grid = std::min(b->n, c->n_cu * 8);
     if ((rc = dh::msa_launch(ma, grid, b->msa_nmax, s))) return fail(rc, "msa_launch");
     HIPCHK(hipGetLastError());
@@ -667,7 +674,7 @@ int dellyhip_gotoh(dellyhip_ctx* c, const char* a1, int32_t r1, int32_t m, const
                    char* align_out, int32_t cap, int32_t* len, int32_t* score) {
   if (!c || !len || !score) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  int rc = dh::msa_single_gotoh(c->stream, c->params, a1, r1, m, a2, r2, n, align_out, cap, len, score);
+  int rc = dh::msa_single_gotoh(c->stream, c->params, c->msa_tmax, a1, r1, m, a2, r2, n, align_out, cap, len, score);
   return rc ? fail(rc, "gotoh") : 0;
 }
 
@@ -675,7 +682,7 @@ int dellyhip_msa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, const u
                  int32_t cs_cap, int32_t* cs_len, int32_t* rows) {
   if (!c || !cs_len || !rows || n_reads < 0) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  int rc = dh::msa_single(c->stream, c->params, n_reads, seq_blob, seq_off, cs, cs_cap, cs_len, rows);
+  int rc = dh::msa_single(c->stream, c->params, c->msa_tmax, n_reads, seq_blob, seq_off, cs, cs_cap, cs_len, rows);
   return rc ? fail(rc, "msa") : 0;
 }
 

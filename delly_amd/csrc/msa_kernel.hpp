@@ -35,6 +35,10 @@ constexpr int GKMAX = 8;     // Gotoh rows per lane: 64*8 >= LCAP
 constexpr int NODES = 2 * NRMAX + 1;
 constexpr int GINF = 1000000;  // DnaScore::inf, src/align.h:21
 constexpr int PROFW = 8;     // dwords per profile column: meta + 5 values (+2 pad)
+constexpr int TMAXC = 96;    // profile column types per alignment node the score table is built for
+constexpr int HSLOTS = 256;  // open-addressing table of column-type keys
+constexpr int FASTK = 5;      // rows per lane served by the score-table kernel (node length <= 319)
+constexpr int MSA_DEFER = 1; // merge_nodes: more column types than the table holds -> direct-float kernel
 
 struct MsaArgs {
   const dellyhip_junction* junc;
@@ -49,6 +53,8 @@ struct MsaArgs {
   uint64_t ws_stride;
   int32_t n_work;
   int32_t* work_counter;
+  int32_t tmax;           // column types per node handled by the score table (<= TMAXC)
+  int32_t* defer_counter; // junctions handed to the direct-float kernel
   // single-item gotoh mode (dellyhip_gotoh): two given alignments
   const uint8_t* g_a1;
   const uint8_t* g_a2;
@@ -68,9 +74,23 @@ struct MsaWs {
   }
 };
 
-struct __attribute__((aligned(16))) MsaLds {
+// guide-tree phase (distanceMatrix + upgma) and alignment phase never overlap
+struct MsaLdsTree {
   unsigned long long lcsmask[NRMAX][5][LCSW];
   int8_t d[NODES * NODES];
+};
+struct MsaLdsLut {
+  unsigned long long hkey[HSLOTS];          // open-addressing set of column-type keys
+  unsigned long long tkey[2][TMAXC];        // key of each dense type id, per profile
+  uint8_t slot_id[HSLOTS];
+  uint8_t type[2][LCAP];                    // column -> type id
+  int8_t tab[TMAXC * TMAXC];                // (int) score of (type1, type2)
+};
+struct __attribute__((aligned(16))) MsaLds {
+  union {
+    MsaLdsTree t;
+    MsaLdsLut g;
+  } u;
   int16_t par[NODES], lch[NODES], rch[NODES];
   int32_t node_rows[NODES], node_len[NODES], node_base[NODES];
   uint32_t roff[NRMAX];   // read offsets relative to the junction's first read
@@ -137,8 +157,8 @@ struct Node {
 // ---- profile: src/align.h:131-171, compressed to the non-zero entries ---------
 // column record (PROFW dwords): [0] = cnt | k0<<4 | k1<<8 | k2<<12 | k3<<16 | k4<<20, [1..5] = float values
 // single-sequence mode: [0] = the raw byte.
-__device__ __forceinline__ void build_profile(const Node& a, uint32_t* prof, MsaLds& L, int lane) {
-  // first / last aligned nucleotide per row (align.h:139-151)
+// first / last aligned nucleotide per row (align.h:139-151) -> L.first / L.last
+__device__ __forceinline__ void row_spans(const Node& a, MsaLds& L, int lane) {
   for (int i = 0; i < a.rows; ++i) {
     int first = -1, last = a.len;
     for (int base = 0; base < a.len; base += WAVE) {
@@ -156,25 +176,40 @@ __device__ __forceinline__ void build_profile(const Node& a, uint32_t* prof, Msa
     }
   }
   __syncthreads();
-  for (int j = lane; j < a.len; j += WAVE) {
-    float cnt[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int sum = 0;
-    for (int i = 0; i < a.rows; ++i) {
-      int f = L.first[i], l = L.last[i];
-      // first == -1 (all-gap row): the reference's test (firstAlignedNuc <= j) is true and
-      // lastAlignedNuc stays a.shape()[1], so the row counts everywhere
-      if (f <= j && j <= l) {
-        ++sum;
-        uint8_t ch = a.p[(size_t)i * a.stride + j];
-        if (ch == 'A' || ch == 'a') cnt[0] += 1.f;
-        else if (ch == 'C' || ch == 'c') cnt[1] += 1.f;
-        else if (ch == 'G' || ch == 'g') cnt[2] += 1.f;
-        else if (ch == 'T' || ch == 't') cnt[3] += 1.f;
-        else if (ch == 'N' || ch == 'n') cnt[4] += 1.f;
-        else if (ch == '-') cnt[5] += 1.f;
-        else --sum;
-      }
+}
+
+// letter counts of column j over the rows that cover it (align.h:153-166); cnt[5] = '-'
+__device__ __forceinline__ int column_counts(const Node& a, const MsaLds& L, int j, int (&cnt)[6]) {
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cnt[k] = 0;
+  for (int i = 0; i < a.rows; ++i) {
+    int f = L.first[i], l = L.last[i];
+    // first == -1 (all-gap row): the reference's test (firstAlignedNuc <= j) is true and
+    // lastAlignedNuc stays a.shape()[1], so the row counts everywhere
+    if (f <= j && j <= l) {
+      ++sum;
+      uint8_t ch = a.p[(size_t)i * a.stride + j];
+      if (ch == 'A' || ch == 'a') ++cnt[0];
+      else if (ch == 'C' || ch == 'c') ++cnt[1];
+      else if (ch == 'G' || ch == 'g') ++cnt[2];
+      else if (ch == 'T' || ch == 't') ++cnt[3];
+      else if (ch == 'N' || ch == 'n') ++cnt[4];
+      else if (ch == '-') ++cnt[5];
+      else --sum;
     }
+  }
+  return sum;
+}
+
+__device__ __forceinline__ void build_profile(const Node& a, uint32_t* prof, MsaLds& L, int lane) {
+  row_spans(a, L, lane);
+  for (int j = lane; j < a.len; j += WAVE) {
+    int ic[6];
+    const int sum = column_counts(a, L, j, ic);
+    float cnt[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cnt[k] = (float)ic[k];
     float fs = (float)sum;
     uint32_t meta = 0;
     int n = 0;
@@ -196,10 +231,97 @@ __device__ __forceinline__ void build_single(const Node& a, uint32_t* prof, int 
   for (int j = lane; j < a.len; j += WAVE) prof[(size_t)j * PROFW] = a.p[j];
 }
 
+// ---- profile column TYPES and their score table --------------------------------------
+// A profile column is the float vector count[k]/sum (k = A,C,G,T,N); _score (align.h:104-110)
+// of two columns depends only on the two (count[0..4], sum) tuples.  A node of r <= 32 rows has
+// few distinct tuples (coverage level x letter, plus the odd mismatch column), so the (int)
+// score of every type pair is evaluated once per merge -- with the reference's float
+// expression and evaluation order -- into an int8 table in LDS and the DP cell reads one byte.
+// key = count[0..4] (6 bits each) | sum << 30
+__device__ __forceinline__ unsigned long long column_key(const int (&cnt)[6], int sum) {
+  return (unsigned long long)cnt[0] | ((unsigned long long)cnt[1] << 6) | ((unsigned long long)cnt[2] << 12) |
+         ((unsigned long long)cnt[3] << 18) | ((unsigned long long)cnt[4] << 24) | ((unsigned long long)sum << 30);
+}
+
+// types of node `a` into L.u.g.type[which] / tkey[which]; returns the number of types or -1
+// when there are more than tmax
+__device__ __forceinline__ int build_types(const Node& a, int which, MsaLds& L, int lane, int tmax) {
+  MsaLdsLut& G = L.u.g;
+  row_spans(a, L, lane);
+  for (int q = lane; q < HSLOTS; q += WAVE) G.hkey[q] = ~0ull;
+  __syncthreads();
+  int fail = 0;
+  for (int j = lane; j < a.len; j += WAVE) {
+    int ic[6];
+    const int sum = column_counts(a, L, j, ic);
+    const unsigned long long key = column_key(ic, sum);
+    int slot = (int)((key * 0x9E3779B97F4A7C15ull) >> 56);
+    int probes = 0;
+    for (; probes < HSLOTS; ++probes) {
+      const unsigned long long old = atomicCAS(&G.hkey[slot], ~0ull, key);
+      if (old == ~0ull || old == key) break;
+      slot = (slot + 1) & (HSLOTS - 1);
+    }
+    if (probes >= HSLOTS) fail = 1;
+    G.type[which][j] = (uint8_t)slot;
+  }
+  __syncthreads();
+  int T = 0;
+#pragma unroll
+  for (int q = 0; q < HSLOTS / WAVE; ++q) {
+    const int sl = q * WAVE + lane;
+    const unsigned long long k = G.hkey[sl];
+    const bool occ = k != ~0ull;
+    const unsigned long long b = __ballot(occ);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int id = T + __popcll(b & below);
+    if (occ) {
+      G.slot_id[sl] = (uint8_t)min(id, 255);
+      if (id < TMAXC) G.tkey[which][id] = k;
+    }
+    T += __popcll(b);
+  }
+  if (__ballot(fail) != 0ull) T = HSLOTS + 1;
+  __syncthreads();
+  if (T > tmax || T > TMAXC) return -1;
+  for (int j = lane; j < a.len; j += WAVE) G.type[which][j] = G.slot_id[G.type[which][j]];
+  __syncthreads();
+  return T;
+}
+
 // (int) score as x86-64 cvttss2si does it: NaN / out of range -> 0x80000000
 __device__ __forceinline__ int cvt_x86(float f) {
   if (!(f == f) || f >= 2147483648.0f || f < -2147483648.0f) return (int)0x80000000;
   return (int)f;
+}
+
+// tab[t1*T2 + t2] = (int) _score(column of type t1, column of type t2)   align.h:104-110
+// Returns false when a score is 0x80000000 (NaN profile entry: a column covered by foreign letters
+// only) -- not representable in the int8 table, the junction goes to the direct-float kernel.
+__device__ __forceinline__ bool fill_table(int T1, int T2, const dellyhip_params& P, MsaLds& L, int lane) {
+  MsaLdsLut& G = L.u.g;
+  const float fm = (float)P.match, fmm = (float)P.mismatch;
+  int nan = 0;
+  for (int e = lane; e < T1 * T2; e += WAVE) {
+    const int t1 = e / T2, t2 = e - t1 * T2;
+    const unsigned long long k1 = G.tkey[0][t1], k2 = G.tkey[1][t2];
+    const float s1 = (float)(int)(k1 >> 30), s2 = (float)(int)(k2 >> 30);
+    float sc = 0.f;
+    for (int a = 0; a < 5; ++a) {
+      const float p1 = (float)(int)((k1 >> (6 * a)) & 63ull) / s1;   // align.h:169 (0/0 = NaN)
+      if (p1 == 0.0f) continue;                                      // exact: x + (+-0) == x
+      for (int b = 0; b < 5; ++b) {
+        const float p2 = (float)(int)((k2 >> (6 * b)) & 63ull) / s2;
+        if (p2 == 0.0f) continue;
+        sc = sc + (p1 * p2) * ((a == b) ? fm : fmm);                 // align.h:108
+      }
+    }
+    const int v = cvt_x86(sc);
+    if (v == (int)0x80000000) nan = 1;
+    G.tab[e] = (int8_t)v;
+  }
+  __syncthreads();
+  return __ballot(nan) == 0ull;
 }
 
 // ---- K2: Gotoh DP (gotoh.h:103-141) ------------------------------------------------
@@ -207,40 +329,51 @@ __device__ __forceinline__ int cvt_x86(float f) {
 // AlignConfig<true,true> (src/msa.h:106): end gaps free on both sequences.
 // Trace nibble per cell: bit0 = bit1, bit1 = bit2, bit2 = bit3, bit3 = bit4 of gotoh.h:88-91.
 // Returns S[m][n] (the alignment score) in every lane.
-template <int K, bool SINGLE>
-__device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* prof2, int m, int n,
-                                       const dellyhip_params& P, uint32_t* bits, int lane) {
-  int S[K], H[K], hgo[K], hge[K];
+// MODE 0: both nodes are single sequences (byte compare, align.h:100-102)
+// MODE 1: profile x profile through the type-pair score table in LDS (L.u.g)
+// MODE 2: profile x profile, float expression evaluated per cell (any number of column types)
+template <int K, int MODE>
+__device__ __forceinline__ int gotoh_pass_impl(const uint32_t* prof1, const uint32_t* prof2, int m, int n,
+                                               const dellyhip_params& P, uint32_t* bits, const MsaLds& L, int T2,
+                                               int lane) {
+  constexpr bool SINGLE = (MODE == 0);
+  constexpr bool FLT = (MODE == 2);
+  int S[K], H[K];
   uint32_t rmeta[K];
-  float rp[K][5];
+  float rp[FLT ? K : 1][5];
   uint32_t accA[K], accB[K];
-  int mx1[K];
+  int mx1[FLT ? K : 1];
   const int go = P.gap_open, ge = P.gap_extend;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     int s = lane * K + i;
     S[i] = 0;        // S[r][0] = _verticalGap(ac, 0, n, ...) = 0
     H[i] = -GINF;    // newhoz at column 0
-    hgo[i] = (s == m) ? 0 : go + ge;   // _horizontalGap(ac, row, m, .): free in the last row
-    hge[i] = (s == m) ? 0 : ge;
     rmeta[i] = SINGLE ? (uint32_t)NOMATCH : 0u;
+    if (FLT) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) rp[i][q] = 0.f;
+      for (int q = 0; q < 5; ++q) rp[i][q] = 0.f;
+    }
     if (s >= 1 && s <= m) {
-      const uint32_t* rec = prof1 + (size_t)(s - 1) * PROFW;
-      rmeta[i] = rec[0];
-      if (!SINGLE) {
+      if (MODE == 1) rmeta[i] = (uint32_t)L.u.g.type[0][s - 1] * (uint32_t)T2;
+      else {
+        const uint32_t* rec = prof1 + (size_t)(s - 1) * PROFW;
+        rmeta[i] = rec[0];
+        if (FLT) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) rp[i][q] = __uint_as_float(rec[1 + q]);
+          for (int q = 0; q < 5; ++q) rp[i][q] = __uint_as_float(rec[1 + q]);
+        }
       }
     }
     accA[i] = accB[i] = 0;
-    int n1 = SINGLE ? 0 : (int)(rmeta[i] & 15u);
-    int mx = 0;
+    if (FLT) {
+      int n1 = (int)(rmeta[i] & 15u);
+      int mx = 0;
 #pragma unroll
-    for (int q = 1; q <= 5; ++q)
-      if (__ballot(n1 >= q)) mx = q;
-    mx1[i] = mx;
+      for (int q = 1; q <= 5; ++q)
+        if (__ballot(n1 >= q)) mx = q;
+      mx1[i] = mx;
+    }
   }
   const float fm = (float)P.match, fmm = (float)P.mismatch;
   const int T = n + 63;
@@ -255,16 +388,20 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
     uint32_t chm = SINGLE ? (uint32_t)NOMATCH : 0u;
     float chp[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (ci < n) {
-      const uint32_t* rec = prof2 + (size_t)ci * PROFW;
-      chm = rec[0];
-      if (!SINGLE) {
+      if (MODE == 1) chm = (uint32_t)L.u.g.type[1][ci];
+      else {
+        const uint32_t* rec = prof2 + (size_t)ci * PROFW;
+        chm = rec[0];
+        if (FLT) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q) chp[q] = __uint_as_float(rec[1 + q]);
+          for (int q = 0; q < 5; ++q) chp[q] = __uint_as_float(rec[1 + q]);
+        }
       }
     }
+#pragma unroll
     for (int f = 0; f < 16; ++f) {
       cmeta = (uint32_t)dpp_from_prev((int)cmeta, __builtin_amdgcn_readlane((int)chm, f));
-      if (!SINGLE) {
+      if (FLT) {
 #pragma unroll
         for (int q = 0; q < 5; ++q)
           cp[q] = __int_as_float(
@@ -275,7 +412,7 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
       c += 1;
       const bool active = (unsigned)(c - 1) < (unsigned)n;
       int mx2 = 0;
-      if (!SINGLE) {
+      if (FLT) {
         int n2a = active ? (int)(cmeta & 15u) : 0;
 #pragma unroll
         for (int q = 1; q <= 5; ++q)
@@ -291,18 +428,20 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
           int sco;
           if (SINGLE) {
             sco = (rmeta[i] == cmeta) ? P.match : P.mismatch;   // align.h:100-102
+          } else if (MODE == 1) {
+            sco = (int)L.u.g.tab[rmeta[i] + cmeta];   // (NaN scores never reach this kernel: fill_table)
           } else {
             float sc = 0.f;
             const int n1 = (int)(rmeta[i] & 15u);
 #pragma unroll
             for (int i1 = 0; i1 < 5; ++i1) {
-              if (i1 < mx1[i]) {
+              if (i1 < mx1[FLT ? i : 0]) {
 #pragma unroll
                 for (int i2 = 0; i2 < 5; ++i2) {
                   if (i2 < mx2) {
                     const bool on = (i1 < n1) && (i2 < n2);
                     const uint32_t k1 = (rmeta[i] >> (4 + 4 * i1)) & 7u, k2 = (cmeta >> (4 + 4 * i2)) & 7u;
-                    const float t = (rp[i][i1] * cp[i2]) * ((k1 == k2) ? fm : fmm);   // align.h:108
+                    const float t = (rp[FLT ? i : 0][i1] * cp[i2]) * ((k1 == k2) ? fm : fmm);   // align.h:108
                     sc = on ? (sc + t) : sc;
                   }
                 }
@@ -310,9 +449,11 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
             }
             sco = cvt_x86(sc);
           }
-          const int hext = H[i] + hge[i];
+          const bool lastrow = (lane * K + i == m);   // _horizontalGap(ac, row, m, .): free in the last row
+          const int hgo = lastrow ? 0 : go + ge, hge = lastrow ? 0 : ge;
+          const int hext = H[i] + hge;
           const int vext = uV + vge;
-          const int newhoz = max(S[i] + hgo[i], hext);
+          const int newhoz = max(S[i] + hgo, hext);
           int v = max(uS + vgo, vext);
           int s = max(max((int)((uint32_t)dS + (uint32_t)sco), newhoz), v);
           uint32_t nib = (newhoz != hext ? 1u : 0u) | (v != vext ? 2u : 0u);
@@ -348,39 +489,73 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
   return __shfl(fin, m / K);
 }
 
-// traceback state machine of gotoh.h:143-167 over the stored nibbles (uniform, serial)
+// out-of-line instance (direct-float kernel, single-item wrapper); the score-table kernel
+// inlines the pass so that its __launch_bounds__ register budget covers it
+template <int K, int MODE>
+__device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* prof2, int m, int n,
+                                       const dellyhip_params& P, uint32_t* bits, const MsaLds& L, int T2, int lane) {
+  return gotoh_pass_impl<K, MODE>(prof1, prof2, m, n, P, bits, L, T2, lane);
+}
+
+// traceback state machine of gotoh.h:143-167 over the stored nibbles (uniform).  Nibble
+// words are fetched in windows -- lane l loads the word of cell (row-l, col-l) -- and the walk
+// runs out of registers while the path stays inside the fetched words (8 columns per row).
 template <int K>
 __device__ __noinline__ int gotoh_traceback(const uint32_t* bits, int row, int col, uint8_t* tr, int lane, int& tailV,
                                             int& tailH) {
   int tl = 0;
   int state = 0;  // 0 's', 1 'h', 2 'v'
+  row = rfl(row);
+  col = rfl(col);
   while (row > 0 && col > 0) {
-    int l = row / K, i = row - l * K;
-    int t0 = col + l - 1;
-    uint32_t w = ld_scratch(&bits[((size_t)(t0 >> 3) * K + i) * WAVE + l]);
-    w = (uint32_t)rfl((int)w);
-    uint32_t nib = (w >> (4 * (t0 & 7))) & 15u;
-    if (state == 0) {
-      if (nib & 4u) state = 1;
-      else if (nib & 8u) state = 2;
-      else {
-        --row;
-        --col;
-        if (lane == 0) tr[tl] = 0;
-        ++tl;
-        continue;
-      }
+    const int r = row - lane, c = col - lane;
+    uint32_t w = 0;
+    int tw = -1;
+    if (r >= 1 && c >= 1) {
+      const int lo = r / K, i = r - lo * K;
+      tw = (c + lo - 1) >> 3;
+      w = ld_scratch(&bits[((size_t)tw * K + i) * WAVE + lo]);
     }
-    if (state == 1) {
-      if (nib & 1u) state = 0;
-      --col;
-      if (lane == 0) tr[tl] = 2;
-      ++tl;
-    } else {
-      if (nib & 2u) state = 0;
-      --row;
-      if (lane == 0) tr[tl] = 1;
-      ++tl;
+    int l = 0;
+    bool inwin = true;
+    while (inwin) {
+      const int lo = row / K;
+      const int t0 = col + lo - 1;
+      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
+      const int twl = __builtin_amdgcn_readlane(tw, l);
+      if ((t0 >> 3) != twl) {
+        inwin = false;
+      } else {
+        const uint32_t nib = (wl >> (4 * (t0 & 7))) & 15u;
+        bool moved_diag = false;
+        if (state == 0) {
+          if (nib & 4u) state = 1;
+          else if (nib & 8u) state = 2;
+          else {
+            --row;
+            --col;
+            ++l;
+            if (lane == 0) tr[tl] = 0;
+            ++tl;
+            moved_diag = true;
+          }
+        }
+        if (!moved_diag) {
+          if (state == 1) {
+            if (nib & 1u) state = 0;
+            --col;
+            if (lane == 0) tr[tl] = 2;
+            ++tl;
+          } else {
+            if (nib & 2u) state = 0;
+            --row;
+            ++l;
+            if (lane == 0) tr[tl] = 1;
+            ++tl;
+          }
+        }
+        if (row <= 0 || col <= 0 || l >= WAVE) inwin = false;
+      }
     }
   }
   tailV = (col == 0) ? row : 0;
@@ -388,47 +563,72 @@ __device__ __noinline__ int gotoh_traceback(const uint32_t* bits, int row, int c
   return tl;
 }
 
-template <int K>
-__device__ __forceinline__ int gotoh_dispatch_k(bool single, const uint32_t* p1, const uint32_t* p2, int m, int n,
-                                                const dellyhip_params& P, uint32_t* bits, uint8_t* tr, int lane,
+// mode: 0 single x single, 1 score table, 2 direct float
+template <int K, bool SLOW>
+__device__ __forceinline__ int gotoh_dispatch_k(int mode, const uint32_t* p1, const uint32_t* p2, int m, int n,
+                                                const dellyhip_params& P, uint32_t* bits, MsaLds& L, int T2, int lane,
                                                 int& tl, int& tailV, int& tailH) {
-  int score = single ? gotoh_pass<K, true>(p1, p2, m, n, P, bits, lane) : gotoh_pass<K, false>(p1, p2, m, n, P, bits, lane);
+  int score;
+  if constexpr (SLOW) {
+    if (mode == 0) score = gotoh_pass<K, 0>(p1, p2, m, n, P, bits, L, T2, lane);
+    else score = gotoh_pass<K, 2>(p1, p2, m, n, P, bits, L, T2, lane);
+  } else {
+    if (mode == 0) score = gotoh_pass_impl<K, 0>(p1, p2, m, n, P, bits, L, T2, lane);
+    else score = gotoh_pass_impl<K, 1>(p1, p2, m, n, P, bits, L, T2, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  tl = gotoh_traceback<K>(bits, m, n, tr, lane, tailV, tailH);
+  tl = gotoh_traceback<K>(bits, m, n, L.trace, lane, tailV, tailH);
   return score;
 }
 
 // gotoh(a1, a2, align, AlignConfig<true,true>, sc): merges two nodes into `out`
-// (rows a1 then rows a2, row stride LCAP).  Returns 0 or DELLYHIP_E_LIMIT.
+// (rows a1 then rows a2, row stride LCAP).  Returns 0, DELLYHIP_E_LIMIT, or (SLOW == false only)
+// MSA_DEFER when a node has more column types than the score table holds.
+template <bool SLOW>
 __device__ __forceinline__ int merge_nodes(const Node& a1, const Node& a2, uint8_t* out, int& out_len, int& score,
                                            const dellyhip_params& P, uint32_t* prof, uint32_t* bits, MsaLds& L,
-                                           int lane) {
+                                           int lane, int tmax) {
   const int m = a1.len, n = a2.len;
   if (m > LCAP - 1 || n > LCAP || m + 1 > WAVE * GKMAX) return DELLYHIP_E_LIMIT;
   uint32_t* p1 = prof;
   uint32_t* p2 = prof + (size_t)LCAP * PROFW;
   const bool single = (a1.rows == 1 && a2.rows == 1);
+  int T2 = 0;
+  if (!SLOW && m + 1 > WAVE * FASTK) return MSA_DEFER;
   if (single) {
     build_single(a1, p1, lane);
     build_single(a2, p2, lane);
-  } else {
+  } else if (SLOW) {
     build_profile(a1, p1, L, lane);
     __syncthreads();
     build_profile(a2, p2, L, lane);
+  } else {
+    const int T1 = build_types(a1, 0, L, lane, tmax);
+    if (T1 < 0) return MSA_DEFER;
+    T2 = build_types(a2, 1, L, lane, tmax);
+    if (T2 < 0) return MSA_DEFER;
+    if (!fill_table(T1, T2, P, L, lane)) return MSA_DEFER;
   }
   __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int tl = 0, tailV = 0, tailH = 0;
+  const int mode = single ? 0 : (SLOW ? 2 : 1);
   const int K = (m + 1 + WAVE - 1) / WAVE;
   switch (K) {
-    case 1: score = gotoh_dispatch_k<1>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 2: score = gotoh_dispatch_k<2>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 3: score = gotoh_dispatch_k<3>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 4: score = gotoh_dispatch_k<4>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 5: score = gotoh_dispatch_k<5>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 6: score = gotoh_dispatch_k<6>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    case 7: score = gotoh_dispatch_k<7>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
-    default: score = gotoh_dispatch_k<8>(single, p1, p2, m, n, P, bits, L.trace, lane, tl, tailV, tailH); break;
+    case 1: score = gotoh_dispatch_k<1, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH); break;
+    case 2: score = gotoh_dispatch_k<2, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH); break;
+    case 3: score = gotoh_dispatch_k<3, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH); break;
+    case 4: score = gotoh_dispatch_k<4, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH); break;
+    case 5: score = gotoh_dispatch_k<5, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH); break;
+    default:
+      // K = 6..8 (node longer than 319 columns) only in the direct-float kernel: their register
+      // footprint would otherwise set the occupancy of the score-table kernel
+      if constexpr (SLOW) {
+        if (K == 6) score = gotoh_dispatch_k<6, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH);
+        else if (K == 7) score = gotoh_dispatch_k<7, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH);
+        else score = gotoh_dispatch_k<8, SLOW>(mode, p1, p2, m, n, P, bits, L, T2, lane, tl, tailV, tailH);
+      }
+      break;
   }
   __syncthreads();
   const int tail = tailV + tailH;
@@ -521,6 +721,7 @@ __device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_para
 }
 
 // ---- msa() for one junction ----------------------------------------------------
+template <bool SLOW>
 __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, int nmax, int lane) {
   const dellyhip_junction J = A.junc[j];
   dellyhip_result* out = &A.res[j];
@@ -546,7 +747,7 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
     if (!status) {
       const uint8_t* blob = A.seq_blob + o0;
       // --- distanceMatrix (msa.h:32-44): match masks, then one pair per lane
-      for (int q = lane; q < N * 5 * LCSW; q += WAVE) (&L.lcsmask[0][0][0])[q] = 0ull;
+      for (int q = lane; q < N * 5 * LCSW; q += WAVE) (&L.u.t.lcsmask[0][0][0])[q] = 0ull;
       __syncthreads();
       for (int r = 0; r < N; ++r) {
         const uint8_t* s = blob + L.roff[r];
@@ -556,14 +757,14 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
 #pragma unroll
           for (int k = 0; k < 5; ++k) {
             unsigned long long bm = __ballot(code == k);
-            if (lane == 0) L.lcsmask[r][k][base >> 6] = bm;
+            if (lane == 0) L.u.t.lcsmask[r][k][base >> 6] = bm;
           }
         }
       }
       const int D = NODES;
       for (int q = lane; q < D * D; q += WAVE) {
         int i = q / D, jj = q - i * D;
-        L.d[q] = (jj > i) ? (int8_t)-1 : (int8_t)0;
+        L.u.t.d[q] = (jj > i) ? (int8_t)-1 : (int8_t)0;
       }
       for (int q = lane; q < D; q += WAVE) {
         L.par[q] = -1;
@@ -582,9 +783,9 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
             ++i;
           }
           int jj = i + 1 + rem;
-          int l = lcs_bitparallel(L.lcsmask[i], blob + L.roff[i], L.rlen[i], blob + L.roff[jj], L.rlen[jj]);
+          int l = lcs_bitparallel(L.u.t.lcsmask[i], blob + L.roff[i], L.rlen[i], blob + L.roff[jj], L.rlen[jj]);
           int mn = min(L.rlen[i], L.rlen[jj]);
-          L.d[i * D + jj] = (int8_t)((l * 100) / mn);   // msa.h:41
+          L.u.t.d[i * D + jj] = (int8_t)((l * 100) / mn);   // msa.h:41
         }
       }
       __syncthreads();
@@ -595,7 +796,7 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
         for (int q = lane; q < nn * D; q += WAVE) {   // rows 0..nn-1
           int i = q / D, jj = q - i * D;
           if (jj > i && jj < nn) {
-            int dv = L.d[q];
+            int dv = L.u.t.d[q];
             if (dv > -1) {
               int k2 = ((dv + 1) << 13) | (8191 - q);   // max d, then first in row-major order
               key = max(key, k2);
@@ -617,17 +818,17 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
         __syncthreads();
         for (int i = lane; i < nn; i += WAVE) {
           if (L.par[i] == -1) {
-            int a = (dI < i) ? L.d[dI * D + i] : L.d[i * D + dI];
-            int b = (dJ < i) ? L.d[dJ * D + i] : L.d[i * D + dJ];
-            L.d[i * D + nn] = (int8_t)((a + b) / 2);
+            int a = (dI < i) ? L.u.t.d[dI * D + i] : L.u.t.d[i * D + dI];
+            int b = (dJ < i) ? L.u.t.d[dJ * D + i] : L.u.t.d[i * D + dJ];
+            L.u.t.d[i * D + nn] = (int8_t)((a + b) / 2);
           }
         }
         __syncthreads();
         for (int i = lane; i < nn + 1; i += WAVE) {
-          if (i < dI) L.d[i * D + dI] = -1;
-          if (i > dI) L.d[dI * D + i] = -1;
-          if (i < dJ) L.d[i * D + dJ] = -1;
-          if (i > dJ) L.d[dJ * D + i] = -1;
+          if (i < dI) L.u.t.d[i * D + dI] = -1;
+          if (i > dI) L.u.t.d[dI * D + i] = -1;
+          if (i < dJ) L.u.t.d[i * D + dJ] = -1;
+          if (i > dJ) L.u.t.d[dJ * D + i] = -1;
         }
         __syncthreads();
       }
@@ -660,8 +861,9 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
         if (rc < N) { a2.p = blob + L.roff[rc]; a2.stride = 0; }
         else { a2.p = alnbuf + (size_t)L.node_base[rc] * LCAP; a2.stride = LCAP; }
         int olen = 0, score = 0;
-        int rcode = merge_nodes(a1, a2, alnbuf + (size_t)L.node_base[x] * LCAP, olen, score, A.p, prof, bits, L, lane);
-        if (rcode) status = rcode;
+        int rcode = merge_nodes<SLOW>(a1, a2, alnbuf + (size_t)L.node_base[x] * LCAP, olen, score, A.p, prof, bits, L, lane,
+                                      A.tmax);
+        if (rcode) status = (rcode == MSA_DEFER) ? DH_DEFERRED : rcode;
         if (lane == 0) L.node_len[x] = olen;
         __syncthreads();
       }
@@ -680,11 +882,17 @@ __device__ void msa_junction(const MsaArgs& A, int j, MsaLds& L, uint8_t* ws, in
     out->sr_support = rows;
     out->status = status;
     A.cons_len[j] = status ? 0 : cons_len;
+    if (!SLOW && status == DH_DEFERRED) atomicAdd(A.defer_counter, 1);
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(WAVE) void msa_kernel(MsaArgs A, int nmax) {
+#ifndef DH_MSA_WAVES
+#define DH_MSA_WAVES 3
+#endif
+// score-table kernel: every junction; junctions with too many column types are flagged
+// DH_DEFERRED for msa_slow_kernel
+__global__ __launch_bounds__(WAVE, DH_MSA_WAVES) void msa_kernel(MsaArgs A, int nmax) {
   __shared__ MsaLds L;
   const int lane = threadIdx.x;
   uint8_t* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
@@ -693,20 +901,49 @@ __global__ __launch_bounds__(WAVE) void msa_kernel(MsaArgs A, int nmax) {
     if (lane == 0) w = atomicAdd(A.work_counter, 1);
     w = rfl(w);
     if (w >= A.n_work) break;
-    msa_junction(A, w, L, ws, nmax, lane);
+    msa_junction<false>(A, w, L, ws, nmax, lane);
   }
 }
 
-// single gotoh(a1, a2) on caller-supplied alignments (dellyhip_gotoh)
+// direct-float kernel (per-cell profile dot product, ~250 VGPRs): only deferred junctions
+__global__ __launch_bounds__(WAVE) void msa_slow_kernel(MsaArgs A, int nmax) {
+  __shared__ MsaLds L;
+  const int lane = threadIdx.x;
+  uint8_t* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  if (*A.defer_counter == 0) return;
+  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
+    if (A.res[w].status != DH_DEFERRED) continue;
+    __syncthreads();
+    msa_junction<true>(A, w, L, ws, nmax, lane);
+  }
+}
+
+// single gotoh(a1, a2) on caller-supplied alignments (dellyhip_gotoh).  Runs the score-table
+// path and the direct-float path and reports DELLYHIP_E_RUNTIME if they disagree (the table is
+// an optimisation of the float expression, never an approximation of it).
 __global__ __launch_bounds__(WAVE) void gotoh_single_kernel(MsaArgs A) {
   __shared__ MsaLds L;
   const int lane = threadIdx.x;
   Node a1{A.g_a1, A.g_r1, A.g_m, A.g_m}, a2{A.g_a2, A.g_r2, A.g_n, A.g_n};
   uint32_t* prof = reinterpret_cast<uint32_t*>(A.ws);
   uint32_t* bits = prof + 2 * (size_t)LCAP * PROFW;
-  int olen = 0, score = 0;
-  int rc = (A.g_r1 + A.g_r2 > 2 * NRMAX || A.g_r1 > NRMAX || A.g_r2 > NRMAX) ? DELLYHIP_E_LIMIT
-                                                                               : merge_nodes(a1, a2, A.g_out, olen, score, A.p, prof, bits, L, lane);
+  int olen = 0, score = 0, olen2 = 0, score2 = 0;
+  int rc = DELLYHIP_E_LIMIT;
+  if (!(A.g_r1 + A.g_r2 > 2 * NRMAX || A.g_r1 > NRMAX || A.g_r2 > NRMAX)) {
+    uint8_t* out2 = A.g_out + (size_t)(A.g_r1 + A.g_r2) * LCAP;
+    rc = merge_nodes<true>(a1, a2, A.g_out, olen, score, A.p, prof, bits, L, lane, A.tmax);
+    const int rc2 = merge_nodes<false>(a1, a2, out2, olen2, score2, A.p, prof, bits, L, lane, A.tmax);
+    if (!rc && rc2 != MSA_DEFER) {
+      int bad = (rc2 != 0) || (olen2 != olen) || (score2 != score);
+      if (!bad)
+        for (int q = lane; q < (A.g_r1 + A.g_r2) * LCAP; q += WAVE) {
+          const int col = q % LCAP;
+          if (col < olen && A.g_out[q] != out2[q]) bad = 1;
+        }
+      if (__ballot(bad) != 0ull) rc = DELLYHIP_E_RUNTIME;
+    }
+    if (lane == 0) A.g_info[3] = (rc2 == MSA_DEFER) ? 0 : 1;   // 1: the table path ran
+  }
   if (lane == 0) {
     A.g_info[0] = olen;
     A.g_info[1] = score;
@@ -740,8 +977,17 @@ inline int msa_prepare(const std::vector<dellyhip_junction>& junc, const uint64_
   return 0;
 }
 
+// score-table types need |match|, |mismatch| <= 127 (int8 table); otherwise every profile merge
+// goes to the direct-float kernel
+inline int msa_tmax(const dellyhip_params& P, int wanted) {
+  if (P.match > 127 || P.match < -127 || P.mismatch > 127 || P.mismatch < -127) return 0;
+  return std::max(0, std::min(wanted, TMAXC));
+}
+
+// a.work_counter and a.defer_counter must be zeroed on the stream before the call
 inline int msa_launch(const MsaArgs& a, int grid, int nmax, hipStream_t s) {
   hipLaunchKernelGGL(msa_kernel, dim3(grid), dim3(WAVE), 0, s, a, nmax);
+  hipLaunchKernelGGL(msa_slow_kernel, dim3(grid), dim3(WAVE), 0, s, a, nmax);
   return 0;
 }
 
@@ -763,15 +1009,15 @@ inline int msa_single_lcs(hipStream_t s, const char* s1, int m, const char* s2, 
   return e == hipSuccess ? 0 : DELLYHIP_E_RUNTIME;
 }
 
-inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, const char* a1, int r1, int m, const char* a2,
-                            int r2, int n, char* out, int cap, int32_t* len, int32_t* score) {
+inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, int tmax, const char* a1, int r1, int m,
+                            const char* a2, int r2, int n, char* out, int cap, int32_t* len, int32_t* score) {
   if (r1 < 1 || r2 < 1 || r1 > NRMAX || r2 > NRMAX || m < 0 || n < 0 || m > LCAP - 1 || n > LCAP) return DELLYHIP_E_LIMIT;
   uint8_t *d1 = nullptr, *d2 = nullptr, *dout = nullptr, *ws = nullptr;
   int* dinfo = nullptr;
   size_t wsb = MsaWs::bytes(2);
   if (hipMalloc((void**)&d1, std::max(r1 * m, 1)) != hipSuccess || hipMalloc((void**)&d2, std::max(r2 * n, 1)) != hipSuccess ||
-      hipMalloc((void**)&dout, (size_t)(r1 + r2) * LCAP) != hipSuccess || hipMalloc((void**)&ws, wsb) != hipSuccess ||
-      hipMalloc((void**)&dinfo, 16) != hipSuccess)
+      hipMalloc((void**)&dout, (size_t)2 * (r1 + r2) * LCAP) != hipSuccess || hipMalloc((void**)&ws, wsb) != hipSuccess ||
+      hipMalloc((void**)&dinfo, 32) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(d1, a1, (size_t)r1 * m, hipMemcpyHostToDevice);
   (void)hipMemcpy(d2, a2, (size_t)r2 * n, hipMemcpyHostToDevice);
@@ -781,6 +1027,7 @@ inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, const char*
   A.g_a1 = d1; A.g_a2 = d2; A.g_r1 = r1; A.g_m = m; A.g_r2 = r2; A.g_n = n;
   A.g_out = dout;
   A.g_info = dinfo;
+  A.tmax = msa_tmax(P, tmax);
   hipLaunchKernelGGL(gotoh_single_kernel, dim3(1), dim3(WAVE), 0, s, A);
   hipError_t e = hipStreamSynchronize(s);
   int info[3] = {0, 0, DELLYHIP_E_RUNTIME};
@@ -801,7 +1048,7 @@ inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, const char*
 }
 
 // msa(c, sps, cs) for one read set (dellyhip_msa)
-inline int msa_single(hipStream_t s, const dellyhip_params& P, int n_reads, const char* seq_blob,
+inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_reads, const char* seq_blob,
                       const uint64_t* seq_off, char* cs, int cs_cap, int32_t* cs_len, int32_t* rows) {
   if (n_reads > NRMAX) return DELLYHIP_E_LIMIT;
   dellyhip_junction J{};
@@ -818,18 +1065,20 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int n_reads, cons
   if (hipMalloc((void**)&dj, sizeof J) != hipSuccess || hipMalloc((void**)&dblob, std::max<uint64_t>(blob_bytes, 1)) != hipSuccess ||
       hipMalloc((void**)&doff, (n_reads + 1) * 8) != hipSuccess || hipMalloc((void**)&dres, sizeof(dellyhip_result)) != hipSuccess ||
       hipMalloc((void**)&dout, LCAP) != hipSuccess || hipMalloc((void**)&ws, wsb) != hipSuccess ||
-      hipMalloc((void**)&dlen, 4) != hipSuccess || hipMalloc((void**)&dcnt, 4) != hipSuccess)
+      hipMalloc((void**)&dlen, 4) != hipSuccess || hipMalloc((void**)&dcnt, 8) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(dj, &J, sizeof J, hipMemcpyHostToDevice);
   (void)hipMemcpy(dblob, seq_blob, blob_bytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(doff, seq_off, (n_reads + 1) * 8, hipMemcpyHostToDevice);
   (void)hipMemset(dres, 0, sizeof(dellyhip_result));
-  (void)hipMemset(dcnt, 0, 4);
+  (void)hipMemset(dcnt, 0, 8);
   (void)hipMemset(dlen, 0, 4);
   MsaArgs A{};
   A.junc = dj; A.seq_blob = dblob; A.seq_off = doff; A.p = P; A.res = dres; A.out_blob = dout; A.out_stride = LCAP;
   A.cons_len = dlen; A.ws = ws; A.ws_stride = wsb; A.n_work = 1; A.work_counter = dcnt;
-  hipLaunchKernelGGL(msa_kernel, dim3(1), dim3(WAVE), 0, s, A, nmax);
+  A.defer_counter = dcnt + 1;
+  A.tmax = msa_tmax(P, tmax);
+  msa_launch(A, 1, nmax, s);
   hipError_t e = hipStreamSynchronize(s);
   int rc = (e == hipSuccess) ? 0 : DELLYHIP_E_RUNTIME;
   dellyhip_result R{};

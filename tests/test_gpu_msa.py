@@ -90,3 +90,48 @@ def test_refine_batch_vs_port(gpu_ctx, port, mode, n_reads, n):
     gr, gb = gpu_ctx.refine(b, want_alignment=True)
     pr, pb = port.refine_batch(b)
     compare(gr, gb, pr, pb, fields=CORE + INTERNAL, label="hip-vs-port")
+
+
+def test_score_table_and_direct_float_paths_agree(port):
+    """msa() uses an int8 table of (type1, type2) profile scores; junctions whose nodes have
+    more column types than the table holds (DELLYHIP_MSA_TMAX) or more than 319 columns go to
+    the direct-float kernel.  Both routes must give the reference's bytes."""
+    from delly_amd import refine
+    b = synth.make_batch(48, mode="mixed", n_reads=9, seed=21)
+    pr, pb = port.refine_batch(b, want_alignment=False)
+    old = os.environ.get("DELLYHIP_MSA_TMAX")
+    try:
+        for tmax in ("96", "6", "0"):
+            os.environ["DELLYHIP_MSA_TMAX"] = tmax
+            ctx = refine.Context()
+            ctx.set_chromosomes(b.chroms)
+            gr, gb = ctx.refine(b, want_alignment=False)
+            ctx.close()
+            compare(gr, gb, pr, pb, fields=CORE + INTERNAL, blobs=("cons", "allele"), label="tmax=" + tmax)
+    finally:
+        if old is None:
+            os.environ.pop("DELLYHIP_MSA_TMAX", None)
+        else:
+            os.environ["DELLYHIP_MSA_TMAX"] = old
+
+
+def test_msa_long_nodes_take_the_direct_kernel(gpu_ctx, port):
+    # reads 250 bp spread over 430 bp: alignment nodes exceed 319 columns (K = 6..7)
+    rng = np.random.default_rng(17)
+    for it in range(6):
+        base = bytes(rng.choice(list(b"ACGT"), 460).astype(np.uint8))
+        reads = []
+        while len(reads) < 7:
+            o = int(rng.integers(0, 200))
+            x = bytearray(base[o:o + 250])
+            for k in range(len(x)):
+                if rng.random() < 0.01:
+                    x[k] = rng.choice(list(b"ACGT"))
+            if bytes(x) not in reads:
+                reads.append(bytes(x))
+        try:
+            got = gpu_ctx.msa(reads)
+        except Exception as e:  # consensus longer than the 319-byte output cap is a documented limit
+            assert "-4" in str(e)
+            continue
+        assert got == port.msa(reads), it
