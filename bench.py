@@ -89,6 +89,30 @@ def _subbatch(batch, n):
                        batch.with_msa, batch.truth[:n])
 
 
+def side_measurements(ctx, synth, steps=3):
+    """Not the headline: what `delly sr` pays per junction (U_full = msa of N reads +
+    alignConsensus) and the insertion path (splitAlign/edlib), each over a
+    resident batch, whole-step wall clock."""
+    out = {}
+    for name, n, kw in (("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
+                        ("ins_svt4", 5000, dict(mode="ins"))):
+        b = synth.make_batch(n, **kw)
+        ctx.set_chromosomes(b.chroms)
+        rb = ctx.upload(b)
+        rb.run(); rb.sync(); rb.kernel_ms()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rb.run()
+        rb.sync()
+        dt = (time.perf_counter() - t0) / steps
+        ms_split, ms_msa, _ = rb.kernel_ms()
+        res, _ = rb.fetch()
+        out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
+                     "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
+        rb.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--junctions", type=int, default=10000, help="junctions per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
     args = ap.parse_args()
 
     import torch
@@ -197,8 +222,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras:
+            rb.free()
+            rb = None
+            out["extras"] = side_measurements(ctx, synth)
         print(json.dumps(out), flush=True)
-    rb.free()
+    if rb is not None:
+        rb.free()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
