@@ -37,9 +37,11 @@ def params_sr():
     return Params(5, -4, -10, -1, 2, 13, 1000, 100, 0.95, 0)
 
 
-def params_lr():
-    """`delly lr` defaults: src/tegua.h:230-241 (aliscore unused on that path)."""
-    return Params(5, -4, -10, -1, 3, 100, 10000, 1000, 0.9, 0)
+def params_lr(realign=False):
+    """`delly lr` defaults: src/tegua.h:230-241 (aliscore unused on that path).
+    realign: the `realign` argument of alignConsensus (src/split.h:644-646, true on the
+    long-read call sites src/assemble.h:849,916) travels as bit 0 of `reserved`."""
+    return Params(5, -4, -10, -1, 3, 100, 10000, 1000, 0.9, 1 if realign else 0)
 
 
 class Junction(C.Structure):

@@ -16,6 +16,7 @@
 #include "split_main.hpp"
 #include "split_pk.hpp"
 #include "ins_kernel.hpp"
+#include "lr_kernel.hpp"
 
 namespace {
 
@@ -92,9 +93,15 @@ struct dellyhip_batch {
   DevBuf<dellyhip_result> res;
   DevBuf<uint8_t> out_blob;
   uint64_t out_stride = 0;
+  int32_t out_cons_cap = dh::OUT_CONS_CAP, out_allele_cap = dh::OUT_ALLELE_CAP, out_aln_cap = dh::OUT_ALN_CAP;
   DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
+  // long-read shapes (|consensus| > 319 or |svRefStr| > 2048): strip kernel, per-block workspace
+  std::vector<int32_t> h_win_len;    // |svRefStr| per junction, computed on the host (U path)
+  int lr_first = 0, lr_count = 0, lr_blocks = 0;
+  dh::LrArgs lr{};
+  DevBuf<uint8_t> lr_ws;
   // direct (single longNeedle) mode
   DevBuf<uint8_t> ref_blob;
   DevBuf<uint64_t> ref_off;
@@ -177,6 +184,8 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   a.scratch = c->scratch.p;
   a.scratch_words = c->scratch_words;
   a.want_alignment = b->want_alignment;
+  a.out_cons_cap = b->out_cons_cap;
+  a.out_allele_cap = b->out_allele_cap;
   a.pair_mode = 1;
   if (direct) {
     a.ref_base = b->ref_blob.p;
@@ -207,8 +216,51 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     hipLaunchKernelGGL(dh::ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
   }
+  if (b->lr_count > 0 && !direct) {
+    a.work_list = b->work.p + b->lr_first;
+    a.n_work = b->lr_count;
+    const int rounds = (b->lr_count + b->lr_blocks - 1) / b->lr_blocks;
+    const int grid = (b->lr_count + rounds - 1) / rounds;
+    dh::LrArgs lr = b->lr;
+    lr.realign = (c->params.reserved & 1) ? 1 : 0;
+    hipLaunchKernelGGL(dh::lr_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, lr);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
+
+// |svRefStr| of a junction: the integer arithmetic of _initBreakpoint (src/tags.h:151-172) and of
+// the concatenations in _getSVRef (src/split.h:70-163), mirrored from window_segments() so that
+// the host can route a junction to the short-read or the long-read kernel and size workspaces
+int host_window_len(const dellyhip_params& P, const dellyhip_junction& J, int m, const std::vector<int64_t>& chr_len) {
+  auto clampz = [](long v) { return (int)std::max<long>(0, v); };
+  const int svS = J.sv_start, svE = J.sv_end;
+  const int len1 = (int)(uint32_t)chr_len[J.chr], len2 = (int)(uint32_t)chr_len[J.chr2];
+  if (J.svt == 4) {
+    const int bs = std::max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
+    return clampz((long)std::min(len2, svE + bs) - std::max(0, svS - bs));
+  }
+  const int boundary = m;
+  if (J.svt >= 5 && J.svt < 9) {
+    int n = clampz((long)std::min(len1, svS + boundary) - std::max(0, svS - boundary));
+    if (J.chr != J.chr2) n += clampz((long)std::min(len2, svE + boundary) - std::max(0, svE - boundary));
+    return n;
+  }
+  const int mid = (svS + svE) / 2;
+  const int sBeg = std::max(0, svS - boundary), sEnd = std::min(svS + boundary, mid);
+  const int eBeg = std::max(mid + 1, svE - boundary), eEnd = std::min(len2, svE + boundary);
+  switch (J.svt) {
+    case 2: return (svE - svS <= P.indelsize) ? clampz((long)eEnd - sBeg) : clampz((long)sEnd - sBeg) + clampz((long)eEnd - eBeg);
+    case 3: return clampz((long)eEnd - eBeg) + clampz((long)sEnd - sBeg);
+    case 0: return (svE - svS > P.min_cons_window) ? clampz((long)sEnd - sBeg) + clampz((long)eEnd - eBeg)
+                                                    : clampz((long)sEnd - sBeg) + clampz((long)eEnd - svS) + clampz((long)eEnd - svE);
+    case 1: return (svE - svS > P.min_cons_window) ? clampz((long)sEnd - sBeg) + clampz((long)eEnd - eBeg)
+                                                    : clampz((long)svS - sBeg) + clampz((long)svE - sBeg) + clampz((long)eEnd - eBeg);
+    default: return 0;
+  }
+}
+
+bool is_lr_shape(const dellyhip_junction& J, int m, int n) { return J.svt != 4 && (m > dh::MMAX || n > dh::NMAX); }
 
 // K-bins junctions by consensus length and pairs them (two junctions per wavefront, packed
 // 16-bit DP).  Within a bin junctions are sorted by their approximate reference-window length
@@ -219,7 +271,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
   std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
-  std::vector<int32_t> ins;
+  std::vector<int32_t> ins, lrv;
   const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
@@ -228,6 +280,11 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     const dellyhip_junction& J = b->h_junc[i];
     if (!direct && J.svt == 4) {  // splitAlign path: own kernel, one junction per wavefront
       ins.push_back(i);
+      continue;
+    }
+    if (!direct && !b->h_win_len.empty() && is_lr_shape(J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
+        b->h_win_len[i] <= dh::LR_NMAX && b->lr_blocks > 0) {  // strip kernel (else: E_LIMIT in the short-read kernels)
+      lrv.push_back(i);
       continue;
     }
     long span = (long)J.sv_end - (long)J.sv_start;
@@ -249,6 +306,9 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->ins_first = (int)work.size();
   b->ins_count = (int)ins.size();
   work.insert(work.end(), ins.begin(), ins.end());
+  b->lr_first = (int)work.size();
+  b->lr_count = (int)lrv.size();
+  work.insert(work.end(), lrv.begin(), lrv.end());
   int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 2));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -337,7 +397,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -361,7 +421,26 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->with_msa = with_msa;
   b->want_alignment = want_alignment;
   b->h_junc.assign(junc, junc + n);
-  b->out_stride = dh::OUT_CONS_CAP + dh::OUT_ALLELE_CAP + (want_alignment ? dh::OUT_ALN_CAP : 0);
+  int lr_m = 0, lr_n = 0, lr_cnt = 0;
+  if (!with_msa) {  // |svRefStr| per junction; long-read shapes get larger output slots and a workspace
+    b->h_win_len.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const int m = (int)(seq_off[junc[i].seq_first + 1] - seq_off[junc[i].seq_first]);
+      const int w = host_window_len(c->params, junc[i], m, c->chr_len);
+      b->h_win_len[i] = w;
+      if (is_lr_shape(junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
+        lr_m = std::max(lr_m, m);
+        lr_n = std::max(lr_n, w);
+        ++lr_cnt;
+      }
+    }
+  }
+  if (lr_cnt) {
+    b->out_cons_cap = std::max<int>(dh::OUT_CONS_CAP, (lr_m + 16) & ~15);
+    b->out_allele_cap = std::max<int>(dh::OUT_ALLELE_CAP, (lr_m + lr_n + 8 + 15) & ~15);
+    b->out_aln_cap = std::max<int>(dh::OUT_ALN_CAP, 2 * ((lr_m + lr_n + 8 + 15) & ~15));
+  }
+  b->out_stride = (uint64_t)b->out_cons_cap + b->out_allele_cap + (want_alignment ? b->out_aln_cap : 0);
   b->out_stride = (b->out_stride + 15) & ~15ull;
   uint64_t blob_bytes = n_seq ? seq_off[n_seq] : 0;
   int rc = 0;
@@ -398,6 +477,29 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
       e = hipMemcpy(b->cons_len.p, b->h_cons_len.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
+    }
+    if (lr_cnt) {
+      dh::LrArgs& R = b->lr;
+      R.mcap = (lr_m + 64) & ~63;
+      R.ncap = (lr_n + 64) & ~63;
+      const int Q = (lr_m + 1 + dh::LRS - 1) / dh::LRS;
+      R.strip_words = dh::lr_strip_words(R.ncap);
+      uint64_t o = 0;
+      auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+      take(R.mcap);                               // cons at 0
+      R.off_rcons = take(R.mcap);
+      R.off_ref = take(R.ncap);
+      R.off_rref = take(R.ncap);
+      R.off_bnd0 = take(((uint64_t)R.ncap + 128) * 4);
+      R.off_bnd1 = take(((uint64_t)R.ncap + 128) * 4);
+      R.off_br = take((uint64_t)dh::LR_QMAX * dh::LRS * 4);
+      R.off_trF = take((uint64_t)R.mcap + R.ncap + 64);
+      R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
+      R.off_stack = take((uint64_t)Q * R.strip_words * 4);
+      R.ws_stride = o;
+      b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * 4));
+      if ((rc = b->lr_ws.alloc((size_t)R.ws_stride * b->lr_blocks))) return bail(rc);
+      R.ws = b->lr_ws.p;
     }
     if ((rc = build_bins(b, c->params))) return bail(rc);
   } else {

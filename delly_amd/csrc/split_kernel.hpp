@@ -65,6 +65,7 @@ struct SplitArgs {
   int32_t n_work;
   int32_t* work_counter;        // zeroed before launch (the atomic of shortpe.h:181)
   int32_t want_alignment;
+  int32_t out_cons_cap, out_allele_cap;  // layout of a junction's out_blob slot: [cons][allele][aln rows]
   int32_t pair_mode;            // 1: split_align_kernel runs behind the packed kernel (deferred junctions only)
 };
 
@@ -369,7 +370,8 @@ __device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, u
 // ---- column-mask stream -----------------------------------------------------
 
 // appends `cnt` (<=64) bits of (v, r) at bit position pos of the LDS masks
-__device__ __forceinline__ void mask_append(PostLds& L, int pos, int cnt, unsigned long long v, unsigned long long r,
+template <typename PL>
+__device__ __forceinline__ void mask_append(PL& L, int pos, int cnt, unsigned long long v, unsigned long long r,
                                             int lane) {
   if (cnt <= 0) return;
   unsigned long long keep = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);

@@ -66,6 +66,79 @@ struct JCtx {
   }
 };
 
+// _initBreakpoint (tags.h:151-172) + the pieces _getSVRef (split.h:70-163) concatenates.
+// Returns false for an unknown svt (_getSVRef returns "").
+template <bool INS>
+__device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyhip_junction& J, int m, Seg (&seg)[3],
+                                                int& nseg, int& sBeg, int& sEnd, int& eBeg, int& eEnd) {
+  const dellyhip_params& P = A.p;
+  bool go = true;
+  nseg = 0;
+  const int boundary = m;
+  const int svS = J.sv_start, svE = J.sv_end;
+  const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
+  const uint8_t* c1 = A.chr_seq[J.chr];
+  const uint8_t* c2 = A.chr_seq[J.chr2];
+  if (INS) {
+    // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
+    const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
+    sBeg = max(0, svS - bs);
+    sEnd = min(len1, svS + bs);
+    eBeg = max(0, svE - bs);
+    eEnd = min(len2, svE + bs);
+    seg[0] = Seg{c1, sBeg, max(0, eEnd - sBeg), 0};
+    nseg = 1;
+  } else if (is_tra(J.svt)) {
+    sBeg = max(0, svS - boundary);
+    sEnd = min(len1, svS + boundary);
+    eBeg = max(0, svE - boundary);
+    eEnd = min(len2, svE + boundary);
+    int ct = J.svt - 5;
+    Seg mainS{c1, sBeg, max(0, sEnd - sBeg), ct == 1};
+    if (J.chr != J.chr2) {
+      Seg part1{c2, eBeg, max(0, eEnd - eBeg), ct == 0};
+      if (ct == 3) { seg[0] = part1; seg[1] = mainS; }
+      else { seg[0] = mainS; seg[1] = part1; }
+      nseg = 2;
+    } else {
+      seg[0] = mainS;
+      nseg = 1;
+    }
+  } else {
+    int mid = (svS + svE) / 2;
+    sBeg = max(0, svS - boundary);
+    sEnd = min(svS + boundary, mid);
+    eBeg = max(mid + 1, svE - boundary);
+    eEnd = min(len2, svE + boundary);
+    if (J.svt == 2) {
+      if (svE - svS <= P.indelsize) { seg[0] = Seg{c1, sBeg, max(0, eEnd - sBeg), 0}; nseg = 1; }
+      else { seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0}; seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0}; nseg = 2; }
+    } else if (J.svt == 3) {
+      seg[0] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
+      seg[1] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0};
+      nseg = 2;
+    } else if (J.svt == 0) {
+      seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0};
+      if (svE - svS > P.min_cons_window) { seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 1}; nseg = 2; }
+      else { seg[1] = Seg{c1, svS, max(0, eEnd - svS), 1}; seg[2] = Seg{c1, svE, max(0, eEnd - svE), 0}; nseg = 3; }
+    } else if (J.svt == 1) {
+      if (svE - svS > P.min_cons_window) {
+        seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 1};
+        seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
+        nseg = 2;
+      } else {
+        seg[0] = Seg{c1, sBeg, max(0, svS - sBeg), 0};
+        seg[1] = Seg{c1, sBeg, max(0, svE - sBeg), 1};
+        seg[2] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
+        nseg = 3;
+      }
+    } else {
+      go = false;  // unknown svt: _getSVRef returns ""
+    }
+  }
+  return go;
+}
+
 // ---- stage 1 ---------------------------------------------------------------------
 // INS: the caller is the insertion kernel (svt 4, splitAlign path); every other kernel flags
 // svt 4 junctions, which the host never routes to them, with DELLYHIP_E_LIMIT.
@@ -127,69 +200,8 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
       for (int i = lane; i < n; i += WAVE) S.ref[i] = rg[i];
     }
   } else if (go) {
-    const int boundary = m;
-    const int svS = J.sv_start, svE = J.sv_end;
-    const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
-    const uint8_t* c1 = A.chr_seq[J.chr];
-    const uint8_t* c2 = A.chr_seq[J.chr2];
     int sBeg, sEnd, eBeg, eEnd;
-    if (INS) {
-      // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
-      const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
-      sBeg = max(0, svS - bs);
-      sEnd = min(len1, svS + bs);
-      eBeg = max(0, svE - bs);
-      eEnd = min(len2, svE + bs);
-      seg[0] = Seg{c1, sBeg, max(0, eEnd - sBeg), 0};
-      nseg = 1;
-    } else if (is_tra(J.svt)) {
-      sBeg = max(0, svS - boundary);
-      sEnd = min(len1, svS + boundary);
-      eBeg = max(0, svE - boundary);
-      eEnd = min(len2, svE + boundary);
-      int ct = J.svt - 5;
-      Seg mainS{c1, sBeg, max(0, sEnd - sBeg), ct == 1};
-      if (J.chr != J.chr2) {
-        Seg part1{c2, eBeg, max(0, eEnd - eBeg), ct == 0};
-        if (ct == 3) { seg[0] = part1; seg[1] = mainS; }
-        else { seg[0] = mainS; seg[1] = part1; }
-        nseg = 2;
-      } else {
-        seg[0] = mainS;
-        nseg = 1;
-      }
-    } else {
-      int mid = (svS + svE) / 2;
-      sBeg = max(0, svS - boundary);
-      sEnd = min(svS + boundary, mid);
-      eBeg = max(mid + 1, svE - boundary);
-      eEnd = min(len2, svE + boundary);
-      if (J.svt == 2) {
-        if (svE - svS <= P.indelsize) { seg[0] = Seg{c1, sBeg, max(0, eEnd - sBeg), 0}; nseg = 1; }
-        else { seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0}; seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0}; nseg = 2; }
-      } else if (J.svt == 3) {
-        seg[0] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
-        seg[1] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0};
-        nseg = 2;
-      } else if (J.svt == 0) {
-        seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 0};
-        if (svE - svS > P.min_cons_window) { seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 1}; nseg = 2; }
-        else { seg[1] = Seg{c1, svS, max(0, eEnd - svS), 1}; seg[2] = Seg{c1, svE, max(0, eEnd - svE), 0}; nseg = 3; }
-      } else if (J.svt == 1) {
-        if (svE - svS > P.min_cons_window) {
-          seg[0] = Seg{c1, sBeg, max(0, sEnd - sBeg), 1};
-          seg[1] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
-          nseg = 2;
-        } else {
-          seg[0] = Seg{c1, sBeg, max(0, svS - sBeg), 0};
-          seg[1] = Seg{c1, sBeg, max(0, svE - sBeg), 1};
-          seg[2] = Seg{c1, eBeg, max(0, eEnd - eBeg), 0};
-          nseg = 3;
-        }
-      } else {
-        go = false;  // unknown svt: _getSVRef returns ""
-      }
-    }
+    if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     for (int q = 0; q < nseg; ++q) n += seg[q].len;
     if (go && (n > NMAX || (INS && n < 3))) {  // (splitAlign indexes distRev[n-2]: n < 3 is outside its domain)
@@ -336,8 +348,8 @@ __device__ __forceinline__ int dir_and_trace(const uint8_t* rowstr, const uint8_
 // column masks -> cumulative counts, equality mask, optional alignment rows.  Columns
 // [0, posC) take their letters from S.cons / S.ref by running count, columns [posC, Ltot) from
 // the reverse-complemented strings through needle.h:209-217's output switch.
-template <typename STRS>
-__device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& S, PostLds& L, int Ltot, int posC,
+template <typename STRS, typename PL>
+__device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& S, PL& L, int Ltot, int posC,
                                              int lane) {
   const int m = X.m, n = X.n;
   uint8_t* ob = X.ob;
@@ -356,7 +368,7 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
   }
   __syncthreads();
   // characters of every column -> equality mask (+ optional alignment output)
-  uint8_t* aln = ob + OUT_CONS_CAP + OUT_ALLELE_CAP;
+  uint8_t* aln = ob + A.out_cons_cap + A.out_allele_cap;
   for (int base = 0; base < Ltot; base += 64) {
     int jcol = base + lane;
     int w = base >> 6;
@@ -384,15 +396,15 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
   }
   __syncthreads();
   if (A.want_alignment && lane == 0) {
-    X.out->aln_off = X.ob_off + OUT_CONS_CAP + OUT_ALLELE_CAP;
+    X.out->aln_off = X.ob_off + A.out_cons_cap + A.out_allele_cap;
     X.out->aln_len = Ltot;
   }
 }
 
 // _findSplit / _percentIdentity / _findHomology / _coordTransform / exact alleles on the column
 // masks (split.h:166-375, 596-637); writes the result record.
-template <typename STRS>
-__device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PostLds& L, bool go, int Ltot,
+template <typename STRS, typename PL>
+__device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PL& L, bool go, int Ltot,
                                              int posC, int lane) {
   const dellyhip_params& P = A.p;
   const int m = X.m, n = X.n;
@@ -513,8 +525,8 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           int rA = cnt_before(L.mR, L.cumR, colA), rB = cnt_before(L.mR, L.cumR, colB);
           int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
           int nr = rB - rA, na = vB - vA;
-          uint8_t* al = ob + OUT_CONS_CAP;
-          if (nr + na + 1 <= OUT_ALLELE_CAP) {
+          uint8_t* al = ob + A.out_cons_cap;
+          if (nr + na + 1 <= A.out_allele_cap) {
             for (int base = colA & ~63; base < colB; base += 64) {
               int jcol = base + lane;
               int w = base >> 6;
@@ -542,7 +554,7 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
         R->matches = ma; R->mismatches = mm;
         if (final_ok) {
           if (allele_len) {
-            R->allele_off = X.ob_off + OUT_CONS_CAP;
+            R->allele_off = X.ob_off + A.out_cons_cap;
             R->allele_len = allele_len;
           }
           if (status) R->status = status;
@@ -559,6 +571,45 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
     }
   }
   __syncthreads();
+}
+
+// longNeedle's glued alignment (needle.h:196-219) as column masks; column order:
+// [fwd tail][fwd ops reversed][ref gap][rev ops][rev tail].  trF / trR hold the traceback ops
+// in push order (0 's', 1 'v', 2 'h'); tv* / th* are the straight runs at the borders.
+// Returns the number of columns, posC = first column of the reverse part.
+template <typename PL>
+__device__ __forceinline__ int needle_masks(PL& L, const uint8_t* trF, int nF, int tvF, int thF, const uint8_t* trR,
+                                            int nR, int tvR, int thR, int gapref, int maskw, int lane, int& posC) {
+  for (int w = lane; w < maskw; w += WAVE) {
+    L.mV[w] = 0;
+    L.mR[w] = 0;
+    L.mE[w] = 0;
+  }
+  __syncthreads();
+  int pos = 0;
+  for (int k = 0; k < thF; k += 64) { mask_append(L, pos, min(64, thF - k), 0ull, ~0ull, lane); pos += min(64, thF - k); }
+  for (int k = 0; k < tvF; k += 64) { mask_append(L, pos, min(64, tvF - k), ~0ull, 0ull, lane); pos += min(64, tvF - k); }
+  for (int k = 0; k < nF; k += 64) {
+    int idx = k + lane;
+    int op = (idx < nF) ? (int)trF[nF - 1 - idx] : 0;
+    unsigned long long v = __ballot(idx < nF && op != 2);
+    unsigned long long r = __ballot(idx < nF && op != 1);
+    mask_append(L, pos, min(64, nF - k), v, r, lane);
+    pos += min(64, nF - k);
+  }
+  for (int k = 0; k < gapref; k += 64) { mask_append(L, pos, min(64, gapref - k), 0ull, ~0ull, lane); pos += min(64, gapref - k); }
+  posC = pos;
+  for (int k = 0; k < nR; k += 64) {
+    int idx = k + lane;
+    int op = (idx < nR) ? (int)trR[idx] : 0;
+    unsigned long long v = __ballot(idx < nR && op != 2);
+    unsigned long long r = __ballot(idx < nR && op != 1);
+    mask_append(L, pos, min(64, nR - k), v, r, lane);
+    pos += min(64, nR - k);
+  }
+  for (int k = 0; k < tvR; k += 64) { mask_append(L, pos, min(64, tvR - k), ~0ull, 0ull, lane); pos += min(64, tvR - k); }
+  for (int k = 0; k < thR; k += 64) { mask_append(L, pos, min(64, thR - k), 0ull, ~0ull, lane); pos += min(64, thR - k); }
+  return pos;
 }
 
 // ---- stage 4: tracebacks + split detection -> result ----------------------------------
@@ -588,41 +639,10 @@ __device__ __noinline__ void junction_post(const SplitArgs& A, JCtx& X, StrLds& 
   }
   __syncthreads();
 
-  // alignment as column masks; column order (needle.h:196-219):
-  // [fwd tail][fwd ops reversed][ref gap][rev ops][rev tail]
+  // alignment as column masks
   int Ltot = 0, posC = 0;
   if (go) {
-    for (int w = lane; w < MASKW; w += WAVE) {
-      L.mV[w] = 0;
-      L.mR[w] = 0;
-      L.mE[w] = 0;
-    }
-    __syncthreads();
-    int pos = 0;
-    for (int k = 0; k < thF; k += 64) { mask_append(L, pos, min(64, thF - k), 0ull, ~0ull, lane); pos += min(64, thF - k); }
-    for (int k = 0; k < tvF; k += 64) { mask_append(L, pos, min(64, tvF - k), ~0ull, 0ull, lane); pos += min(64, tvF - k); }
-    for (int k = 0; k < nF; k += 64) {
-      int idx = k + lane;
-      int op = (idx < nF) ? (int)L.trF[nF - 1 - idx] : 0;
-      unsigned long long v = __ballot(idx < nF && op != 2);
-      unsigned long long r = __ballot(idx < nF && op != 1);
-      mask_append(L, pos, min(64, nF - k), v, r, lane);
-      pos += min(64, nF - k);
-    }
-    int gapref = (n - refRight) - refLeft;
-    for (int k = 0; k < gapref; k += 64) { mask_append(L, pos, min(64, gapref - k), 0ull, ~0ull, lane); pos += min(64, gapref - k); }
-    posC = pos;
-    for (int k = 0; k < nR; k += 64) {
-      int idx = k + lane;
-      int op = (idx < nR) ? (int)L.trR[idx] : 0;
-      unsigned long long v = __ballot(idx < nR && op != 2);
-      unsigned long long r = __ballot(idx < nR && op != 1);
-      mask_append(L, pos, min(64, nR - k), v, r, lane);
-      pos += min(64, nR - k);
-    }
-    for (int k = 0; k < tvR; k += 64) { mask_append(L, pos, min(64, tvR - k), ~0ull, 0ull, lane); pos += min(64, tvR - k); }
-    for (int k = 0; k < thR; k += 64) { mask_append(L, pos, min(64, thR - k), 0ull, ~0ull, lane); pos += min(64, thR - k); }
-    Ltot = pos;
+    Ltot = needle_masks(L, L.trF, nF, tvF, thF, L.trR, nR, tvR, thR, (n - refRight) - refLeft, MASKW, lane, posC);
     masks_finish(A, X, S, L, Ltot, posC, lane);
   }
   if (go && X.direct && lane == 0) X.out->ok = 1;  // longNeedle() returned true

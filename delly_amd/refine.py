@@ -104,7 +104,8 @@ class Context:
         blob = _u8(seq_blob)
         off = np.ascontiguousarray(seq_off, dtype=np.uint64)
         res = np.zeros(n, dtype=abi.result_dtype())
-        cap = n * (6000 if want_alignment else 3100) + 64
+        # consensus + "REF,ALT" (+ two alignment rows): bounded by a few times the sequence bytes per junction
+        cap = n * (6000 if want_alignment else 3100) + int(blob.size) * (16 if want_alignment else 8) + 64
         out = np.zeros(cap, dtype=np.uint8)
         used = C.c_uint64(0)
         rc = fn(self._ctx, n, _p(junc, C.c_void_p), _p(blob), _p(off, C.POINTER(C.c_uint64)),
@@ -193,6 +194,7 @@ class ResidentBatch:
         self._b = C.c_void_p()
         junc = np.ascontiguousarray(batch.junctions)
         blob = _u8(batch.seq_blob)
+        self._blob_bytes = 0 if batch.with_msa else int(blob.size)
         off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
         rc = ctx.lib.dellyhip_batch_upload(ctx._ctx, self.n, _p(junc, C.c_void_p), _p(blob),
                                            _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1),
@@ -224,7 +226,7 @@ class ResidentBatch:
 
     def fetch(self):
         res = np.zeros(self.n, dtype=abi.result_dtype())
-        cap = self.n * 3100 + 64
+        cap = self.n * 3100 + 8 * self._blob_bytes + 64
         out = np.zeros(cap, dtype=np.uint8)
         used = C.c_uint64(0)
         self.ctx._check(self.ctx.lib.dellyhip_batch_fetch(self.ctx._ctx, self._b, _p(res, C.c_void_p), _p(out),

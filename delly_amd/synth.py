@@ -19,6 +19,7 @@ for a, b in zip(b"ACGTN", b"TGCAN"):
     _COMP[a] = b
 
 WINDOW = 4000  # bases of private genome per junction
+WINDOW_LR = 16000  # ... for mode "lr" (BASELINE config C4 shapes)
 
 
 def revcomp(a):
@@ -78,6 +79,11 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   (two-window branch src/split.h:117), DUP, INV 3to3/5to5 and
                   the four BND orientations across two chromosomes, varying
                   flank lengths.
+    mode "lr"   : long-read shapes (BASELINE config C4): ~2 kb consensus with 1 % substitutions
+                  and indels, DEL 3 kb (window ~7 kb, contiguous branch), short DEL, DEL beyond
+                  indelsize (two windows), INV, DUP; every third junction's consensus is given
+                  reverse-complemented (the orientation test of src/split.h:564-572 must flip it).
+                  Use with abi.params_lr(realign=True).
     mode "ins"  : svt 4 insertions (splitAlign path, src/split.h:480-538): 16..120 bp
                   novel or tandem-duplicated sequence, soft-masked / N-containing
                   reference stretches, pure-reference negatives.
@@ -85,6 +91,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   many distinct split reads per junction, host order = as generated).
     """
     two_chr = mode == "mixed"
+    WINDOW = WINDOW_LR if mode == "lr" else globals()["WINDOW"]
     chrA = np.empty(n * WINDOW, dtype=np.uint8)
     chrB = np.empty(n * WINDOW if two_chr else 0, dtype=np.uint8)
     junc = np.zeros(n, dtype=abi.junction_dtype())
@@ -118,6 +125,18 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                 kind, svt, ell = "inv1", 1, int(rng.integers(400, 1500))
             else:
                 kind, svt = "bnd%d" % (sel - 8), 5 + (sel - 8)
+        elif mode == "lr":
+            s = 6000
+            sel = j % 6
+            flankL = int(rng.integers(700, 1150))
+            flankR = int(rng.integers(700, 1150))
+            ell = 3000
+            if sel == 3:
+                ell = int(rng.integers(400, 1500))
+            elif sel == 4:
+                kind, svt, ell = "inv0", 0, 3500
+            elif sel == 5:
+                kind, svt, ell = "dup", 3, 3000
         elif mode == "ins":
             svt = 4
             sel = j % 10
@@ -160,7 +179,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             h = int(rng.integers(2, 11))
             G[e:e + h] = G[s:s + h]
         # ALT haplotype around the junction (left part ‖ right part), 150+150
-        L = 150
+        L = 1200 if mode == "lr" else 150
         if kind in ("del", "nrun", "hom"):
             left, right = G[s - L:s], G[e:e + L]
         elif kind == "noref":
@@ -205,6 +224,14 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         rec["seq_first"] = len(seqs)
         if n_reads <= 0:
             cons = _mutate(rng, alt[L - flankL:L + flankR], sub_rate)
+            if mode == "lr":
+                # sparse 1-base indels on top of the substitutions, then orientation
+                keep = rng.random(cons.size) >= 0.004
+                cons = cons[keep]
+                at = np.nonzero(rng.random(cons.size) < 0.004)[0]
+                cons = np.insert(cons, at, ACGT[rng.integers(0, 4, at.size)])
+                if j % 3 == 2:
+                    cons = revcomp(cons)
             seqs.append(cons)
             rec["n_seq"] = 1
         else:

@@ -1282,7 +1282,20 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   int n = (int)ref.n;
   R->ref_len = n;
 
-  /* _alignConsensus split.h:560-642 (realign=false) */
+  /* _alignConsensus split.h:560-642; realign (split.h:564-572) = bit 0 of params.reserved */
+  if (c->reserved & 1) {
+    char* revc = (char*)malloc((size_t)m + 1);
+    memcpy(revc, cons, (size_t)m);
+    dor_reverse_complement(revc, m);
+    ed_res f, r;
+    ed_align(ref.d, n, cons, m, ED_NW, 0, &f);
+    ed_align(ref.d, n, revc, m, ED_NW, 0, &r);
+    if (r.ed < f.ed) {
+      memcpy(cons, revc, (size_t)m);
+      if (b->out_blob && R->cons_off != UINT64_MAX) memcpy(b->out_blob + R->cons_off, cons, (size_t)m); /* sv.consensus = revc */
+    }
+    free(revc);
+  }
   amat al;
   int diag[5];
   int found;

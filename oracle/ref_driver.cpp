@@ -110,7 +110,7 @@ struct BlobWriter {
 
 void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr_seq,
                 const dellyhip_junction& J, const char* blob, const uint64_t* off,
-                dellyhip_result& R, BlobWriter& bw, int with_msa, int want_alignment) {
+                dellyhip_result& R, BlobWriter& bw, int with_msa, int want_alignment, bool realign) {
   using namespace torali;
   std::memset(&R, 0, sizeof(R));
   R.svid = J.svid;
@@ -156,8 +156,18 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
     if (bp.chr != bp.chr2) bp.part1 = _getSVRef(c, sndSeq, bp, bp.chr2, sv.svt);
     std::string svRefStr = _getSVRef(c, seq, bp, bp.chr, sv.svt);
     R.ref_len = (int32_t)svRefStr.size();
+    std::string consDiag = sv.consensus;
+    if (realign) {  // src/split.h:564-572, replayed for the diagnostics below
+      std::string revc = consDiag;
+      reverseComplement(revc);
+      EdlibAlignResult aF = edlibAlign(svRefStr.c_str(), svRefStr.size(), consDiag.c_str(), consDiag.size(), edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, NULL, 0));
+      EdlibAlignResult aR = edlibAlign(svRefStr.c_str(), svRefStr.size(), revc.c_str(), revc.size(), edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, NULL, 0));
+      if (aR.editDistance < aF.editDistance) consDiag = revc;
+      edlibFreeAlignResult(aF);
+      edlibFreeAlignResult(aR);
+    }
     TAlign align;
-    if (_consRefAlignment(sv.consensus, svRefStr, align, sv.svt)) {
+    if (_consRefAlignment(consDiag, svRefStr, align, sv.svt)) {
       if (want_alignment) {
         uint64_t len = align.shape()[1];
         std::string rows(2 * len, ' ');
@@ -169,7 +179,7 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
         R.aln_len = (int32_t)len;
       }
       AlignDescriptor ad;
-      if (_findSplit(c, sv.consensus, svRefStr, align, ad, sv.svt)) {
+      if (_findSplit(c, consDiag, svRefStr, align, ad, sv.svt)) {
         R.c_start = ad.cStart; R.c_end = ad.cEnd; R.r_start = ad.rStart; R.r_end = ad.rEnd;
         R.hom_left = ad.homLeft; R.hom_right = ad.homRight;
       }
@@ -177,7 +187,9 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
   }
 
   // The authoritative call: src/shortpe.h:186 / src/split.h:668-672
-  bool ok = alignConsensus(c, const_cast<bam_hdr_t*>(hdr), seq, sndSeq, sv);
+  bool ok = alignConsensus(c, const_cast<bam_hdr_t const*>(hdr), seq, sndSeq, sv, realign);
+  if (realign && sv.consensus != consIn && sv.consensus.size() == consIn.size() && R.cons_off != UINT64_MAX)
+    std::memcpy(bw.base + R.cons_off, sv.consensus.data(), sv.consensus.size());  // the orientation test replaced sv.consensus
   R.ok = ok ? 1 : 0;
   if (ok) {
     R.sv_start = sv.svStart;
@@ -360,7 +372,7 @@ int dref_refine_batch(const dellyhip_params* p, int n_chr, const char* const* ch
     for (;;) {
       uint32_t idx = next.fetch_add(1, std::memory_order_relaxed);
       if (idx >= (uint32_t)n_junc) break;
-      refine_one(c, &hdr, chr_seq, junc[idx], blob, off, results[idx], bw, with_msa, want_alignment);
+      refine_one(c, &hdr, chr_seq, junc[idx], blob, off, results[idx], bw, with_msa, want_alignment, (p->reserved & 1) != 0);
     }
   };
   if (n_threads <= 1) worker();
