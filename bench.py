@@ -89,14 +89,17 @@ def _subbatch(batch, n):
                        batch.with_msa, batch.truth[:n])
 
 
-def side_measurements(ctx, synth, steps=3):
+def side_measurements(ctx, synth, device=0, steps=3):
     """Not the headline: what `delly sr` pays per junction (U_full = msa of N reads +
     alignConsensus) and the insertion path (splitAlign/edlib), each over a
     resident batch, whole-step wall clock."""
     out = {}
+    from delly_amd import abi, refine
     for name, n, kw in (("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
-                        ("ins_svt4", 5000, dict(mode="ins"))):
+                        ("ins_svt4", 5000, dict(mode="ins")), ("lr_c4", 256, dict(mode="lr", sub_rate=0.01))):
         b = synth.make_batch(n, **kw)
+        if name == "lr_c4":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
+            ctx = refine.Context(params=abi.params_lr(realign=True), device=device)
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()
@@ -204,7 +207,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU, 150 bp consensus x 1 kb "
                                    "ref window, alignConsensus (longNeedle + split detection), bit-exact" % n,
@@ -225,7 +228,7 @@ def main():
         if world == 1 and not args.no_extras:
             rb.free()
             rb = None
-            out["extras"] = side_measurements(ctx, synth)
+            out["extras"] = side_measurements(ctx, synth, device=local)
         print(json.dumps(out), flush=True)
     if rb is not None:
         rb.free()

@@ -52,7 +52,8 @@ typedef struct dellyhip_params {
   int32_t indelsize;          /* c.indelsize       1000 sr / 10000 lr */
   int32_t min_cons_window;    /* c.minConsWindow    100 sr / 1000 lr */
   float flank_quality;        /* c.flankQuality    0.95 sr / 0.9 lr */
-  int32_t reserved;
+  int32_t reserved;          /* bit 0: the `realign` argument of alignConsensus (src/split.h:644-646,
+                              * orientation test :564-572; long-read call sites pass true) */
 } dellyhip_params;
 
 /* One SV candidate ("junction").  Mirrors the fields of

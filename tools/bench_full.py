@@ -7,8 +7,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 nreads = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 mode = sys.argv[4] if len(sys.argv) > 4 else "c2"
-b = synth.make_batch(n, mode=mode, n_reads=nreads)
-ctx = refine.Context()
+from delly_amd import abi
+kw = dict(sub_rate=0.01) if mode == "lr" else {}
+params = abi.params_lr(realign=True) if mode == "lr" else None
+b = synth.make_batch(n, mode=mode, n_reads=nreads, **kw)
+ctx = refine.Context(params=params)
 ctx.set_chromosomes(b.chroms)
 rb = ctx.upload(b)
 rb.run(); rb.sync(); rb.kernel_ms()
@@ -27,10 +30,11 @@ if len(sys.argv) > 5:  # CPU reference beside it (oracle/_ref, all host threads)
     import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
     O = pyoracle.Oracle(kind)
-    sub = synth.make_batch(min(n, 2048), mode=mode, n_reads=nreads)
+    if params is not None:
+        O.params = params
     for th in (1, os.cpu_count()):
-        k = sub.n if th > 1 else min(sub.n, 128)
-        s1 = synth.make_batch(k, mode=mode, n_reads=nreads)
+        k = min(n, 2048 if mode != "lr" else 256) if th > 1 else min(n, 128 if mode != "lr" else 4)
+        s1 = synth.make_batch(k, mode=mode, n_reads=nreads, **kw)
         t = time.perf_counter()
         O.refine_batch(s1, want_alignment=False, n_threads=th)
         dt = time.perf_counter() - t
