@@ -155,36 +155,8 @@ __device__ __noinline__ EdKeys ed_pass(const uint8_t* tp, int tstep, int tlen, c
 // (last op first), including the straight run at the border.  Returns the op count.
 template <int K>
 __device__ __forceinline__ int traceback_ed_k(const uint32_t* dirs, int rr, int cc, uint8_t* tr, int lane) {
-  int tl = 0;
-  while (rr > 0 && cc > 0) {
-    const int r = rr - lane, c = cc - lane;
-    uint32_t w = 0;
-    int tw = -1;
-    if (r >= 1 && c >= 1) {
-      const int lo = r / K, i = r - lo * K;
-      tw = (c + lo - 1) >> 4;
-      w = ld_scratch(&dirs[((size_t)tw * K + i) * WAVE + lo]);
-    }
-    int l = 0;
-    bool inwin = true;
-    while (inwin) {
-      const int lo = rr / K;
-      const int t = cc + lo - 1;
-      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-      const int twl = __builtin_amdgcn_readlane(tw, l);
-      if ((t >> 4) != twl) {
-        inwin = false;
-      } else {
-        const uint32_t code = (wl >> (2 * (t & 15))) & 3u;
-        if (lane == 0) tr[tl] = (uint8_t)code;
-        ++tl;
-        if (code == (uint32_t)ED_INSERT) --cc;
-        else if (code == (uint32_t)ED_DELETE) { --rr; ++l; }
-        else { --rr; --cc; ++l; }
-        if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
-      }
-    }
-  }
+  GeoK<K> G{dirs};
+  const int tl = traceback_runs<true>(G, rr, cc, tr, lane);
   // border runs: target exhausted -> INSERTs (edlib.cpp:1057-1062,1079-1084), query exhausted ->
   // DELETEs (:1027-1031,1087-1091)
   const int tail = (rr > 0) ? rr : cc;

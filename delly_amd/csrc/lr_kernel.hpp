@@ -384,44 +384,23 @@ __device__ __forceinline__ int lr_nw_distance(const uint8_t* target, int tn, con
   return rfl(d);
 }
 
-// windowed traceback over the per-strip direction codes; ops (0 's', 1 'v', 2 'h') to tr[] (global)
+// code-word geometry of the strip passes
+struct GeoLR {
+  const uint32_t* base;
+  uint64_t strip_words;
+  __device__ __forceinline__ void locate(int r, int c, size_t& wi, int& t) const {
+    const int qs = r / LRS, ls = r - qs * LRS;
+    const int lo = ls / LRK, i = ls - lo * LRK;
+    t = c + lo - 1;
+    wi = (size_t)qs * strip_words + ((size_t)(t >> 4) * LRK + i) * WAVE + lo;
+  }
+};
+
+// windowed run-length traceback over the per-strip direction codes; ops (0 's', 1 'v', 2 'h') to tr[] (global)
 __device__ __noinline__ int lr_traceback(const uint32_t* dirs, uint64_t strip_words, int rr, int cc, uint8_t* tr, int lane,
                                          int& tailV, int& tailH) {
-  constexpr int K = LRK;
-  int tl = 0;
-  rr = rfl(rr);
-  cc = rfl(cc);
-  while (rr > 0 && cc > 0) {
-    const int r = rr - lane, c = cc - lane;
-    uint32_t w = 0;
-    int tw = -1;
-    if (r >= 1 && c >= 1) {
-      const int qs = r / LRS, ls = r - qs * LRS;
-      const int lo = ls / K, i = ls - lo * K;
-      tw = (c + lo - 1) >> 4;
-      w = ld_scratch(&dirs[(size_t)qs * strip_words + ((size_t)tw * K + i) * WAVE + lo]);
-    }
-    int l = 0;
-    bool inwin = true;
-    while (inwin) {
-      const int ls = rr % LRS;
-      const int lo = ls / K;
-      const int t = cc + lo - 1;
-      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-      const int twl = __builtin_amdgcn_readlane(tw, l);
-      if ((t >> 4) != twl) {
-        inwin = false;
-      } else {
-        const uint32_t code = (wl >> (2 * (t & 15))) & 3u;
-        if (lane == 0) tr[tl] = (uint8_t)code;
-        ++tl;
-        if (code == 1) { --rr; ++l; }
-        else if (code == 2) --cc;
-        else { --rr; --cc; ++l; }
-        if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
-      }
-    }
-  }
+  GeoLR G{dirs, strip_words};
+  const int tl = traceback_runs<false>(G, rr, cc, tr, lane);
   tailV = rr;
   tailH = cc;
   return tl;

@@ -500,6 +500,8 @@ __device__ __noinline__ int gotoh_pass(const uint32_t* prof1, const uint32_t* pr
 // traceback state machine of gotoh.h:143-167 over the stored nibbles (uniform).  Nibble
 // words are fetched in windows -- lane l loads the word of cell (row-l, col-l) -- and the walk
 // runs out of registers while the path stays inside the fetched words (8 columns per row).
+// In state 's' a run of diagonal cells (neither bit3 nor bit4 set) is taken in one step: each
+// lane decodes the cell of its own row on the current diagonal, a ballot gives the run length.
 template <int K>
 __device__ __noinline__ int gotoh_traceback(const uint32_t* bits, int row, int col, uint8_t* tr, int lane, int& tailV,
                                             int& tailH) {
@@ -509,52 +511,54 @@ __device__ __noinline__ int gotoh_traceback(const uint32_t* bits, int row, int c
   col = rfl(col);
   while (row > 0 && col > 0) {
     const int r = row - lane, c = col - lane;
+    const int lo = (r >= 1) ? r / K : 0, ii = r - lo * K;
     uint32_t w = 0;
     int tw = -1;
     if (r >= 1 && c >= 1) {
-      const int lo = r / K, i = r - lo * K;
       tw = (c + lo - 1) >> 3;
-      w = ld_scratch(&bits[((size_t)tw * K + i) * WAVE + lo]);
+      w = ld_scratch(&bits[((size_t)tw * K + ii) * WAVE + lo]);
     }
     int l = 0;
     bool inwin = true;
     while (inwin) {
-      const int lo = row / K;
-      const int t0 = col + lo - 1;
-      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-      const int twl = __builtin_amdgcn_readlane(tw, l);
-      if ((t0 >> 3) != twl) {
+      const int d = lane - l;
+      const int cx = col - d;
+      const int tx = cx + lo - 1;
+      const bool valid = (d >= 0) && (r >= 1) && (cx >= 1) && ((tx >> 3) == tw);
+      const uint32_t nib = valid ? ((w >> (4 * (tx & 7))) & 15u) : 16u;
+      if (state == 0) {
+        const unsigned long long dm = __ballot(valid && (nib & 12u) == 0u) >> l;
+        const int L = (~dm == 0ull) ? WAVE : __builtin_ctzll(~dm);
+        if (L > 0) {
+          if (d >= 0 && d < L) tr[tl + d] = 0;
+          tl += L;
+          row -= L;
+          col -= L;
+          l += L;
+        }
+      }
+      if (row <= 0 || col <= 0 || l >= WAVE) {
         inwin = false;
       } else {
-        const uint32_t nib = (wl >> (4 * (t0 & 7))) & 15u;
-        bool moved_diag = false;
-        if (state == 0) {
-          if (nib & 4u) state = 1;
-          else if (nib & 8u) state = 2;
-          else {
-            --row;
-            --col;
-            ++l;
-            if (lane == 0) tr[tl] = 0;
-            ++tl;
-            moved_diag = true;
-          }
-        }
-        if (!moved_diag) {
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)nib, l);
+        if (nl == 16u) {
+          inwin = false;   // outside the fetched word of this row
+        } else {
+          if (state == 0) state = (nl & 4u) ? 1 : 2;   // (a diagonal cell cannot reach this point)
           if (state == 1) {
-            if (nib & 1u) state = 0;
+            if (nl & 1u) state = 0;
             --col;
             if (lane == 0) tr[tl] = 2;
             ++tl;
           } else {
-            if (nib & 2u) state = 0;
+            if (nl & 2u) state = 0;
             --row;
             ++l;
             if (lane == 0) tr[tl] = 1;
             ++tl;
           }
+          if (row <= 0 || col <= 0 || l >= WAVE) inwin = false;
         }
-        if (row <= 0 || col <= 0 || l >= WAVE) inwin = false;
       }
     }
   }

@@ -320,16 +320,22 @@ __device__ __forceinline__ void pass_dir(const uint8_t* rowstr, const uint8_t* c
   }
 }
 
-// Traceback over the stored direction codes (uniform across the wave).  A dependent
-// L2 round trip per step would dominate the post-processing stage, so the codes are read
-// in windows: lane l fetches the code word of cell (rr-l, cc-l) -- the diagonal through
-// the current cell -- and the walk continues out of registers (v_readlane) for as long as
-// the path stays inside the fetched words (16 columns per row), then refetches.
-// Pushes ops (0 's', 1 'v', 2 'h') until a border is reached; the remaining
-// straight run is returned as tailV / tailH.  Returns the number of pushed ops.
-template <int K>
-__device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, uint8_t* tr, int lane, int& tailV,
-                                         int& tailH) {
+// Traceback over stored 2-bit codes (uniform across the wave).  A dependent L2 round trip per
+// step would dominate the post-processing stage, so the codes are read in WINDOWS: lane l
+// fetches the code word of cell (rr-l, cc-l) -- the diagonal through the current cell -- and the
+// walk continues out of registers for as long as the path stays inside the fetched words (16
+// columns per row).  Inside a window, diagonal RUNS are taken in one step: every lane decodes
+// the cell of its own row on the current diagonal, a ballot gives the length of the run of
+// diagonal codes, the run's ops are stored lane-parallel.  Only gap ops advance one at a time.
+//
+// Geo::locate(r, c, word_index, t): code word of cell (r, c) and its step index t (field
+// t & 15 of word t >> 4).  ED = false: needle codes 0 diag 's', 1 vertical 'v' (row only),
+// 2 horizontal 'h'.  ED = true: EDLIB_EDOP codes 0 MATCH / 3 MISMATCH diagonal, 1 INSERT
+// (column only), 2 DELETE (row only).  Pushes the ops to tr[] until a border is reached and
+// returns their number; rr / cc are left at the border cell.
+template <bool ED, typename Geo>
+__device__ __forceinline__ int traceback_runs(const Geo& G, int& rr, int& cc, uint8_t* tr, int lane) {
+  constexpr uint32_t ROWCODE = ED ? 2u : 1u;
   int tl = 0;
   rr = rfl(rr);
   cc = rfl(cc);
@@ -338,30 +344,72 @@ __device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, u
     uint32_t w = 0;
     int tw = -1;
     if (r >= 1 && c >= 1) {
-      const int lo = r / K, i = r - lo * K;
-      tw = (c + lo - 1) >> 4;
-      w = ld_scratch(&dirs[((size_t)tw * K + i) * WAVE + lo]);
+      size_t wi;
+      int t;
+      G.locate(r, c, wi, t);
+      tw = t >> 4;
+      w = ld_scratch(G.base + wi);
     }
-    int l = 0;
+    int l = 0;   // rr == (rr at fetch time) - l: lane x holds the word of row rr - (x - l)
     bool inwin = true;
     while (inwin) {
-      const int lo = rr / K;
-      const int t = cc + lo - 1;
-      const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)w, l);
-      const int twl = __builtin_amdgcn_readlane(tw, l);
-      if ((t >> 4) != twl) {
-        inwin = false;  // path left the fetched word of this row
+      const int d = lane - l;
+      const int cx = cc - d;
+      bool valid = (d >= 0) && (r >= 1) && (cx >= 1);
+      int tx = 0;
+      if (valid) {
+        size_t wi;
+        G.locate(r, cx, wi, tx);
+        valid = ((tx >> 4) == tw);
+      }
+      const uint32_t code = valid ? ((w >> (2 * (tx & 15))) & 3u) : 4u;
+      const bool isd = ED ? (code == 0u || code == 3u) : (code == 0u);
+      const unsigned long long dm = __ballot(isd) >> l;
+      const int L = (~dm == 0ull) ? WAVE : __builtin_ctzll(~dm);
+      if (L > 0) {
+        if (d >= 0 && d < L) tr[tl + d] = (uint8_t)code;
+        tl += L;
+        rr -= L;
+        cc -= L;
+        l += L;
+      }
+      if (rr <= 0 || cc <= 0 || l >= WAVE) {
+        inwin = false;
       } else {
-        const uint32_t code = (wl >> (2 * (t & 15))) & 3u;
-        if (lane == 0) tr[tl] = (uint8_t)code;
-        ++tl;
-        if (code == 1) { --rr; ++l; }
-        else if (code == 2) --cc;
-        else { --rr; --cc; ++l; }
-        if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)code, l);
+        if (cl == 4u) {
+          inwin = false;   // the path left the fetched word of this row
+        } else {
+          if (lane == 0) tr[tl] = (uint8_t)cl;
+          ++tl;
+          if (cl == ROWCODE) { --rr; ++l; }
+          else --cc;
+          if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
+        }
       }
     }
   }
+  return tl;
+}
+
+// code-word geometry of pass_dir<K> / pass_ed<K, true>: word ((t >> 4)*K + i)*64 + lane(r), t = c + lane(r) - 1
+template <int K>
+struct GeoK {
+  const uint32_t* base;
+  __device__ __forceinline__ void locate(int r, int c, size_t& wi, int& t) const {
+    const int lo = r / K, i = r - lo * K;
+    t = c + lo - 1;
+    wi = ((size_t)(t >> 4) * K + i) * WAVE + lo;
+  }
+};
+
+// needle traceback (needle.h:154-192): ops 0 's', 1 'v', 2 'h'; the remaining straight run is
+// returned as tailV / tailH
+template <int K>
+__device__ __forceinline__ int traceback(const uint32_t* dirs, int rr, int cc, uint8_t* tr, int lane, int& tailV,
+                                         int& tailH) {
+  GeoK<K> G{dirs};
+  const int tl = traceback_runs<false>(G, rr, cc, tr, lane);
   tailV = rr;  // column 0: only vertical moves remain
   tailH = cc;  // row 0: only horizontal moves remain
   return tl;

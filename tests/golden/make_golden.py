@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 import pyoracle  # noqa: E402
-from delly_amd import synth  # noqa: E402
+from delly_amd import abi, synth  # noqa: E402
 
 BATCHES = {
     # name: (n, kwargs)
@@ -29,7 +29,10 @@ BATCHES = {
     "full_c2_n20": (6, dict(mode="c2", seed=45, first=0, n_reads=20)),
     "u_ins": (160, dict(mode="ins", seed=46, first=0)),
     "full_ins_n6": (30, dict(mode="ins", seed=47, first=0, n_reads=6)),
+    # long-read shapes (BASELINE config C4) with `delly lr` parameters and realign=true
+    "u_lr": (10, dict(mode="lr", seed=48, first=0, sub_rate=0.01)),
 }
+LR_BATCHES = {"u_lr"}
 
 
 def random_seq(rng, n, alphabet=b"ACGT"):
@@ -109,8 +112,10 @@ def main():
         if only and name not in only:
             continue
         b = synth.make_batch(n, **kw)
-        res, blob = ref.refine_batch(b, want_alignment=True)
-        np.savez_compressed(os.path.join(HERE, "batch_%s.npz" % name), n=n, kwargs=repr(kw), results=res, blob=blob)
+        lr = name in LR_BATCHES
+        res, blob = ref.refine_batch(b, want_alignment=True, params=abi.params_lr(realign=True) if lr else None)
+        np.savez_compressed(os.path.join(HERE, "batch_%s.npz" % name), n=n, kwargs=repr(kw), results=res, blob=blob,
+                            lr=int(lr))
         print(name, "ok=%d/%d" % (int(res["ok"].sum()), n))
     if only and "primitives" not in only:
         return

@@ -45,3 +45,13 @@ def test_lr_without_realign_and_mixed_with_short(port):
     pr, pb = port.refine_batch(a, params=abi.params_lr(realign=False), want_alignment=False)
     compare(gr, gb, pr, pb, fields=CORE + INTERNAL, blobs=("cons", "allele"), label="no-realign")
     ctx.close()
+
+
+def test_lr_reproduces_reference_golden_vectors(lr_ctx):
+    """HIP strip kernel vs the committed outputs of the reference itself (tests/golden/batch_u_lr.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_u_lr.npz"), allow_pickle=True)
+    b = synth.make_batch(int(g["n"]), **eval(str(g["kwargs"])))
+    lr_ctx.set_chromosomes(b.chroms)
+    gr, gb = lr_ctx.refine(b, want_alignment=True)
+    compare(gr, gb, g["results"], g["blob"], label="batch_u_lr.npz")

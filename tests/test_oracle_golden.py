@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import pyoracle
-from delly_amd import synth
+from delly_amd import abi, synth
 from util import CORE, compare
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -24,7 +24,8 @@ def test_port_reproduces_golden_batches(port, path):
     g = np.load(path, allow_pickle=True)
     kw = eval(str(g["kwargs"]))
     b = synth.make_batch(int(g["n"]), **kw)
-    res, blob = port.refine_batch(b, want_alignment=True)
+    lr = "lr" in g.files and int(g["lr"])
+    res, blob = port.refine_batch(b, want_alignment=True, params=abi.params_lr(realign=True) if lr else None)
     compare(res, blob, g["results"], g["blob"], label=os.path.basename(path))
 
 
