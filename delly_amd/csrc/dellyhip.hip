@@ -102,6 +102,9 @@ struct dellyhip_batch {
   int lr_first = 0, lr_count = 0, lr_blocks = 0;
   dh::LrArgs lr{};
   DevBuf<uint8_t> lr_ws;
+  // dellyhip_batch_fetch: device-side compaction
+  DevBuf<uint64_t> blob_off;
+  DevBuf<uint8_t> blob_compact;
   // direct (single longNeedle) mode
   DevBuf<uint8_t> ref_blob;
   DevBuf<uint64_t> ref_off;
@@ -317,6 +320,46 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
 
 }  // namespace
 
+// ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
+// off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
+__global__ void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
+  __shared__ uint64_t part[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(n, t * per), hi = min(n, lo + per);
+  uint64_t sum = 0;
+  for (int i = lo; i < hi; ++i)
+    sum += (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
+    uint64_t v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = part[t] - sum;
+  for (int i = lo; i < hi; ++i) {
+    off[i] = run;
+    run += (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
+  }
+  if (t == 1023) off[n] = part[1023];
+}
+// one wavefront per junction: its three pieces, back to back, at out + off[i]
+__global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n) {
+  const int lane = threadIdx.x;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const dellyhip_result R = res[i];
+    uint8_t* dst = out + off[i];
+    const uint64_t src[3] = {R.cons_off, R.allele_off, R.aln_off};
+    const int len[3] = {max(R.cons_len, 0), max(R.allele_len, 0), 2 * max(R.aln_len, 0)};
+    for (int k = 0; k < 3; ++k) {
+      for (int q = lane; q < len[k]; q += dh::WAVE) dst[q] = blob[src[k] + q];
+      dst += len[k];
+    }
+  }
+}
+
 extern "C" {
 
 const char* dellyhip_last_error(void) { return g_err.c_str(); }
@@ -397,7 +440,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -625,27 +668,38 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
   if (rc) return rc;
   uint64_t used = 0;
   if (b->n) {
-    HIPCHK(hipMemcpy(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> tmp((size_t)b->n * b->out_stride);
-    HIPCHK(hipMemcpy(tmp.data(), b->out_blob.p, tmp.size(), hipMemcpyDeviceToHost));
-    // compact the fixed-stride device blob into the caller's blob
-    bool overflow = false;
-    auto put = [&](uint64_t& off, uint64_t len) {
-      if (len == 0) { off = 0; return; }
-      if (!out_blob || used + len > out_blob_cap) { overflow = true; off = 0; used += len; return; }
-      memcpy(out_blob + used, tmp.data() + off, len);
-      off = used;
-      used += len;
-    };
-    for (int i = 0; i < b->n; ++i) {
-      dellyhip_result& R = results[i];
-      put(R.cons_off, (uint64_t)std::max(R.cons_len, 0));
-      put(R.allele_off, (uint64_t)std::max(R.allele_len, 0));
-      put(R.aln_off, 2ull * (uint64_t)std::max(R.aln_len, 0));
-    }
-    if (overflow) {
+    // compact on the device, move only the bytes that are used (a few hundred per junction
+    // instead of the fixed slot)
+    if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
+    hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, b->res.p, b->n, b->blob_off.p);
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> off((size_t)b->n + 1);
+    HIPCHK(hipMemcpyAsync(off.data(), b->blob_off.p, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    used = off[b->n];
+    if (used > 0 && (!out_blob || used > out_blob_cap)) {
       if (out_blob_len) *out_blob_len = used;
       return fail(DELLYHIP_E_ARG, "out_blob too small");
+    }
+    if (used > 0) {
+      if ((rc = b->blob_compact.reserve(used))) return rc;
+      hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, c->stream, b->res.p,
+                         b->out_blob.p, b->blob_off.p, b->blob_compact.p, b->n);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(out_blob, b->blob_compact.p, used, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < b->n; ++i) {
+      dellyhip_result& R = results[i];
+      uint64_t at = off[i];
+      const uint64_t l0 = (uint64_t)std::max(R.cons_len, 0), l1 = (uint64_t)std::max(R.allele_len, 0),
+                     l2 = 2ull * (uint64_t)std::max(R.aln_len, 0);
+      R.cons_off = l0 ? at : 0;
+      at += l0;
+      R.allele_off = l1 ? at : 0;
+      at += l1;
+      R.aln_off = l2 ? at : 0;
     }
   }
   if (out_blob_len) *out_blob_len = used;
