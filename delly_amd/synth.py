@@ -179,7 +179,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             h = int(rng.integers(2, 11))
             G[e:e + h] = G[s:s + h]
         # ALT haplotype around the junction (left part ‖ right part), 150+150
-        L = 1200 if mode == "lr" else 150
+        L = max(1200 if mode == "lr" else 150, flankL, flankR)
         if kind in ("del", "nrun", "hom"):
             left, right = G[s - L:s], G[e:e + L]
         elif kind == "noref":

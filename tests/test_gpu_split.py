@@ -152,3 +152,33 @@ def test_full_size_properties(gpu_ctx):
     for f in ("ok", "ci_wiggle", "hom_len", "cons_bp", "sr_align_quality", "matches", "mismatches"):
         assert np.array_equal(r2[f], res[f][4096:4096 + 512]), f
     assert np.array_equal(r2["sv_start"] + base, res["sv_start"][4096:4096 + 512])
+
+
+def test_empty_batch_and_size_boundaries(gpu_ctx, port):
+    """n = 0; consensus of exactly 319 (last short-read shape) and 320..420 bp (routed to the strip
+    kernel with the short-read parameters); consensus shorter than 2*minimumFlankSize."""
+    b0 = synth.make_batch(0, mode="c2")
+    gpu_ctx.set_chromosomes(synth.make_batch(1, mode="c2").chroms)
+    r0, bl0 = gpu_ctx.align_consensus_batch(b0.junctions, np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    assert r0.shape[0] == 0 and bl0.size == 0
+    for flank in (159, 160, 165, 210):   # m = 2*flank: 318, 320, 330, 420  (+ one batch at 319 below)
+        b = synth.make_batch(24, mode="c2", cons_flank=flank, seed=9)
+        gr, gb = _run(gpu_ctx, b)
+        pr, pb = port.refine_batch(b)
+        compare(gr, gb, pr, pb, fields=CORE + INTERNAL, label="flank=%d" % flank)
+        assert int(gr["ok"].sum()) >= 20
+    b = synth.make_batch(12, mode="c2", cons_flank=160, seed=10)
+    # trim one base: m = 319
+    seqs = [b.seqs_of(i)[0][:319] for i in range(b.n)]
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    b319 = synth.Batch(b.chroms, b.junctions, np.frombuffer(b"".join(seqs), dtype=np.uint8), off, False, b.truth)
+    gr, gb = _run(gpu_ctx, b319)
+    pr, pb = port.refine_batch(b319)
+    compare(gr, gb, pr, pb, fields=CORE + INTERNAL, label="m=319")
+    assert set(gr["cons_len"].tolist()) == {319}
+    short = synth.make_batch(8, mode="c2", cons_flank=10)   # 20 bp < 2*13: alignConsensus false (split.h:647)
+    gr, gb = _run(gpu_ctx, short)
+    pr, pb = port.refine_batch(short)
+    compare(gr, gb, pr, pb, fields=CORE + INTERNAL)
+    assert int(gr["ok"].sum()) == 0
