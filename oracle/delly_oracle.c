@@ -966,7 +966,13 @@ typedef struct {
   int aln_len;
 } ed_res;
 
-static int32_t* ed_fill(const char* q, int qn, const char* t, int tn, int hw) {
+/* additional equalities (edlib.cpp:58-89): eq[a*256+b] != 0 when a and b count as equal; NULL = identity */
+static inline int ed_neq(const unsigned char* eq, char a, char b) {
+  if (a == b) return 0;
+  return eq ? !eq[(size_t)(unsigned char)a * 256 + (unsigned char)b] : 1;
+}
+
+static int32_t* ed_fill_eq(const char* q, int qn, const char* t, int tn, int hw, const unsigned char* eq) {
   size_t W = (size_t)tn + 1;
   int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qn + 1) * W);
   for (int j = 0; j <= tn; ++j) D[j] = hw ? 0 : j;
@@ -975,7 +981,7 @@ static int32_t* ed_fill(const char* q, int qn, const char* t, int tn, int hw) {
     const int32_t* u = r - W;
     r[0] = i;
     for (int j = 1; j <= tn; ++j) {
-      int v = u[j - 1] + (q[i - 1] != t[j - 1]);
+      int v = u[j - 1] + ed_neq(eq, q[i - 1], t[j - 1]);
       if (u[j] + 1 < v) v = u[j] + 1;
       if (r[j - 1] + 1 < v) v = r[j - 1] + 1;
       r[j] = v;
@@ -984,12 +990,32 @@ static int32_t* ed_fill(const char* q, int qn, const char* t, int tn, int hw) {
   return D;
 }
 
-/* obtainAlignmentTraceback on an exact NW matrix, forward op order */
-static void ed_trace(const char* q, int qn, const char* t, int tn, ed_res* r) {
-  (void)q; (void)t;
-  int32_t* D = ed_fill(q, qn, t, tn, 0);
+/* last column of the NW matrix: out[i] = distance(q[0..i), t[0..tn)), i = 0..qn (two rolling rows) */
+static void ed_last_column(const char* q, int qn, const char* t, int tn, const unsigned char* eq, int32_t* out) {
+  int32_t* prev = (int32_t*)malloc(sizeof(int32_t) * ((size_t)tn + 1));
+  int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * ((size_t)tn + 1));
+  for (int j = 0; j <= tn; ++j) prev[j] = j;
+  out[0] = tn;
+  for (int i = 1; i <= qn; ++i) {
+    cur[0] = i;
+    for (int j = 1; j <= tn; ++j) {
+      int v = prev[j - 1] + ed_neq(eq, q[i - 1], t[j - 1]);
+      if (prev[j] + 1 < v) v = prev[j] + 1;
+      if (cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+      cur[j] = v;
+    }
+    out[i] = cur[tn];
+    int32_t* x = prev; prev = cur; cur = x;
+  }
+  free(prev);
+  free(cur);
+}
+
+/* obtainAlignmentTraceback (edlib.cpp:943-1143) on an exact NW matrix; appends the ops (forward order) */
+static void ed_trace_append(const char* q, int qn, const char* t, int tn, const unsigned char* eq, unsigned char* out, int* outn) {
+  int32_t* D = ed_fill_eq(q, qn, t, tn, 0, eq);
   size_t W = (size_t)tn + 1;
-  unsigned char* ops = (unsigned char*)malloc((size_t)qn + (size_t)tn + 1);
+  unsigned char* ops = out + *outn;
   int L = 0, i = qn, j = tn;
   while (i > 0 && j > 0) {
     int cur = D[(size_t)i * W + j];
@@ -1001,12 +1027,50 @@ static void ed_trace(const char* q, int qn, const char* t, int tn, ed_res* r) {
   while (i > 0) { ops[L++] = OP_INSERT; --i; }  /* target exhausted: edlib.cpp:1057-1062,1079-1084 */
   for (int a = 0, b = L - 1; a < b; ++a, --b) { unsigned char x = ops[a]; ops[a] = ops[b]; ops[b] = x; }
   free(D);
-  r->aln = ops;
-  r->aln_len = L;
+  *outn += L;
+}
+
+/* obtainAlignment (edlib.cpp:1163-1201): traceback below 1 MiB of alignment data, otherwise
+ * obtainAlignmentHirschberg (:1220-1389): split the target in the middle, take the FIRST query
+ * index (ascending; then the two boundary cases) whose left + right scores add up to the optimum,
+ * recurse on the upper-left and lower-right rectangles, concatenate.  edlib searches only inside
+ * its Ukkonen bands; cells on optimal paths are always inside them and exact, so the exact score
+ * columns give the same index. */
+static void ed_path_append(const char* q, int qn, const char* t, int tn, const unsigned char* eq, unsigned char* out, int* outn) {
+  if (qn == 0 || tn == 0) {
+    memset(out + *outn, qn == 0 ? OP_DELETE : OP_INSERT, (size_t)(qn + tn));
+    *outn += qn + tn;
+    return;
+  }
+  long long blocks = (qn + 63) / 64;
+  long long sz = (2ll * 8 + 4) * blocks * tn + 2ll * 4 * tn;
+  if (sz < 1024 * 1024) {
+    ed_trace_append(q, qn, t, tn, eq, out, outn);
+    return;
+  }
+  const int lw = tn / 2, rw = tn - lw;
+  int32_t* left = (int32_t*)malloc(sizeof(int32_t) * ((size_t)qn + 1));
+  int32_t* rightr = (int32_t*)malloc(sizeof(int32_t) * ((size_t)qn + 1));
+  char* rq = (char*)malloc((size_t)qn + 1);
+  char* rt = (char*)malloc((size_t)rw + 1);
+  for (int i = 0; i < qn; ++i) rq[i] = q[qn - 1 - i];
+  for (int j = 0; j < rw; ++j) rt[j] = t[tn - 1 - j];
+  ed_last_column(q, qn, t, lw, eq, left);      /* left[i]  : q[0..i) vs t[0..lw)      */
+  ed_last_column(rq, qn, rt, rw, eq, rightr);  /* rightr[k]: q[qn-k..qn) vs t[lw..tn) */
+  int bestScore = 1 << 30;
+  for (int i = 0; i <= qn; ++i) if (left[i] + rightr[qn - i] < bestScore) bestScore = left[i] + rightr[qn - i];
+  int ul = -2; /* number of query letters in the upper-left part */
+  for (int qi = 0; qi <= qn - 2; ++qi)          /* queryIdx = qi: left part holds qi + 1 letters */
+    if (left[qi + 1] + rightr[qn - (qi + 1)] == bestScore) { ul = qi + 1; break; }
+  if (ul == -2 && left[0] + rightr[qn] == bestScore) ul = 0;        /* queryIdx = -1 */
+  if (ul == -2 && left[qn] + rightr[0] == bestScore) ul = qn;       /* queryIdx = qn - 1 */
+  free(left); free(rightr); free(rq); free(rt);
+  ed_path_append(q, ul, t, lw, eq, out, outn);
+  ed_path_append(q + ul, qn - ul, t + lw, rw, eq, out, outn);
 }
 
 /* edlibAlign(query, target, edlibNewAlignConfig(-1, mode, task, NULL, 0)); task 0 DISTANCE, 1 LOC, 2 PATH */
-static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int task, ed_res* r) {
+static int ed_align_eq(const char* q, int qn, const char* t, int tn, int mode, int task, const unsigned char* eq, ed_res* r) {
   r->ed = -1; r->num_loc = 0; r->end_loc = r->start_loc = -2; r->aln = NULL; r->aln_len = 0;
   if (qn == 0 || tn == 0) { /* edlib.cpp:160-178 */
     if (mode == ED_NW) { r->ed = imax(qn, tn); r->end_loc = tn - 1; }
@@ -1016,7 +1080,7 @@ static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int 
   }
   const int pad = ((qn + 63) / 64) * 64 - qn; /* W */
   const int j0 = pad >= 1 ? 0 : 1;
-  int32_t* D = ed_fill(q, qn, t, tn, mode == ED_HW);
+  int32_t* D = ed_fill_eq(q, qn, t, tn, mode == ED_HW, eq);
   const int32_t* last = D + (size_t)qn * ((size_t)tn + 1);
   if (mode == ED_NW) {
     r->ed = last[tn];
@@ -1038,7 +1102,7 @@ static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int 
       char* rt = (char*)malloc((size_t)tl + 1);
       for (int i = 0; i < qn; ++i) rq[i] = q[qn - 1 - i];
       for (int j = 0; j < tl; ++j) rt[j] = t[r->end_loc - j];
-      int32_t* R = ed_fill(rq, qn, rt, tl, 0);
+      int32_t* R = ed_fill_eq(rq, qn, rt, tl, 0, eq);
       const int32_t* rl = R + (size_t)qn * ((size_t)tl + 1);
       int best = rl[j0], lastj = j0;
       for (int j = j0; j <= tl; ++j) {
@@ -1058,18 +1122,41 @@ static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int 
       memset(r->aln, OP_INSERT, (size_t)qn);
       return 0;
     }
-    long long blocks = (qn + 63) / 64;
-    long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
-    if (!(sz < 1024 * 1024)) return DOR_ED_LIMIT;
-    ed_trace(q, qn, t + s0, tl, r);
+    r->aln = (unsigned char*)malloc((size_t)qn + (size_t)tl + 1);
+    r->aln_len = 0;
+    ed_path_append(q, qn, t + s0, tl, eq, r->aln, &r->aln_len);
   }
   return 0;
 }
 
+static int ed_align(const char* q, int qn, const char* t, int tn, int mode, int task, ed_res* r) {
+  return ed_align_eq(q, qn, t, tn, mode, task, NULL, r);
+}
+
+/* the 20 extended-IUPAC pairs of msaEdlib / msaWfa (src/assemble.h:425, :660) as an equality table */
+static const unsigned char* iupac_equalities(void) {
+  static unsigned char tab[256 * 256];
+  static int ready = 0;
+  if (!ready) {
+    static const char pairs[20][2] = {{'M', 'A'}, {'M', 'C'}, {'R', 'A'}, {'R', 'G'}, {'W', 'A'}, {'W', 'T'}, {'B', 'A'},
+                                      {'B', '-'}, {'S', 'C'}, {'S', 'G'}, {'Y', 'C'}, {'Y', 'T'}, {'D', 'C'}, {'D', '-'},
+                                      {'K', 'G'}, {'K', 'T'}, {'E', 'G'}, {'E', '-'}, {'F', 'T'}, {'F', '-'}};
+    for (int i = 0; i < 20; ++i) {
+      tab[(size_t)(unsigned char)pairs[i][0] * 256 + (unsigned char)pairs[i][1]] = 1;
+      tab[(size_t)(unsigned char)pairs[i][1] * 256 + (unsigned char)pairs[i][0] ] = 1;
+    }
+    ready = 1;
+  }
+  return tab;
+}
+
+/* mode | 16: with the extended-IUPAC additional equalities */
 int dor_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int task, int* out,
                     unsigned char* aln, int cap) {
   ed_res r;
-  int rc = ed_align(q, qn, t, tn, mode, task, &r);
+  const unsigned char* eq = (mode & 16) ? iupac_equalities() : NULL;
+  mode &= 15;
+  int rc = ed_align_eq(q, qn, t, tn, mode, task, eq, &r);
   if (rc) return rc;
   out[0] = r.ed; out[1] = r.num_loc; out[2] = r.end_loc; out[3] = r.start_loc;
   int L = r.aln_len;
@@ -1205,6 +1292,144 @@ int dor_split_align(const char* cons, int m, const char* ref, int n, char* rows,
   memcpy(rows + cap, g.d + g.cols, (size_t)g.cols);
   amat_free(&g);
   return 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* msaEdlib  src/assemble.h:383-473 (long-read consensus, `delly lr` non-INS)  */
+
+/* consensusEdlib  src/assemble.h:198-259: per column the majority of A,C,G,T,'-' or, when the
+ * runner-up has at least half the majority's count, the two-letter extended-IUPAC code */
+static void consensus_edlib(const amat* al, char* cons) {
+  for (int j = 0; j < al->cols; ++j) {
+    int count[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < al->rows; ++i) {
+      char ch = AT(*al, i, j);
+      if (ch == 'A' || ch == 'a') ++count[0];
+      else if (ch == 'C' || ch == 'c') ++count[1];
+      else if (ch == 'G' || ch == 'g') ++count[2];
+      else if (ch == 'T' || ch == 't') ++count[3];
+      else ++count[4];
+    }
+    uint32_t maxIdx = 0, sndIdx = 1;
+    if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
+    for (uint32_t i = 2; i < 5; ++i) {
+      if (count[i] > count[maxIdx]) { sndIdx = maxIdx; maxIdx = i; }
+      else if (count[i] > count[sndIdx]) sndIdx = i;
+    }
+    if (2 * count[sndIdx] < count[maxIdx]) {
+      cons[j] = maxIdx < 4 ? "ACGT"[maxIdx] : '-';
+    } else {
+      uint32_t k1 = maxIdx, k2 = sndIdx;
+      if (k1 > k2) { k1 = sndIdx; k2 = maxIdx; }
+      static const char code[5][5] = {{'-', 'M', 'R', 'W', 'B'}, {'-', '-', 'S', 'Y', 'D'}, {'-', '-', '-', 'K', 'E'},
+                                      {'-', '-', '-', '-', 'F'}, {'-', '-', '-', '-', '-'}};
+      cons[j] = code[k1][k2];
+    }
+  }
+}
+
+/* convertAlignment(query, align, EDLIB_MODE_NW, cigar)  src/assemble.h:24-88 */
+static amat convert_alignment_nw(const char* query, const amat* in, const unsigned char* ops, int nops) {
+  amat out = amat_new(in->rows + 1, nops);
+  int tIdx = -1, qIdx = -1;
+  for (int j = 0; j < nops; ++j) {
+    if (ops[j] == OP_INSERT) {
+      for (int r = 0; r < in->rows; ++r) AT(out, r, j) = '-';
+    } else {
+      ++tIdx;
+      for (int r = 0; r < in->rows; ++r) AT(out, r, j) = AT(*in, r, tIdx);
+    }
+  }
+  for (int j = 0; j < nops; ++j) AT(out, in->rows, j) = (ops[j] == OP_DELETE) ? '-' : query[++qIdx];
+  return out;
+}
+
+static int cmp_int(const void* a, const void* b) { int x = *(const int*)a, y = *(const int*)b; return (x > y) - (x < y); }
+static int cmp_pair(const void* a, const void* b) {
+  const int32_t* x = (const int32_t*)a; const int32_t* y = (const int32_t*)b;
+  if (x[0] != y[0]) return (x[0] > y[0]) - (x[0] < y[0]);
+  return (x[1] > y[1]) - (x[1] < y[1]);
+}
+
+static int msa_edlib_core(const dellyhip_params* p, int n, const char* blob, const uint64_t* off, char** cs_out, int* cs_len) {
+  const unsigned char* eq = iupac_equalities();
+  int32_t* edit = (int32_t*)calloc((size_t)n * n, sizeof(int32_t));
+  int maxlen = 0;
+  for (int i = 0; i < n; ++i) maxlen = imax(maxlen, (int)(off[i + 1] - off[i]));
+  int32_t* col = (int32_t*)malloc(sizeof(int32_t) * ((size_t)maxlen + 2));
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      const int li = (int)(off[i + 1] - off[i]), lj = (int)(off[j + 1] - off[j]);
+      int d;
+      if (li == 0 || lj == 0) d = imax(li, lj);
+      else { ed_last_column(blob + off[i], li, blob + off[j], lj, NULL, col); d = col[li]; }
+      edit[i * n + j] = edit[j * n + i] = d;
+    }
+  free(col);
+  /* medoid: smallest median distance, first wins (assemble.h:397-408) */
+  uint32_t bestIdx = 0;
+  int32_t bestVal = (int32_t)(off[1] - off[0]);
+  int* dist = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) dist[j] = edit[i * n + j];
+    qsort(dist, (size_t)n, sizeof(int), cmp_int);
+    if (dist[n / 2] < bestVal) { bestVal = dist[n / 2]; bestIdx = (uint32_t)i; }
+  }
+  free(dist);
+  /* order by distance to the medoid, drop the poorest 20 % (keep >= 3) (:410-424) */
+  int32_t* qs = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n);
+  int nq = 0;
+  qs[0] = 0; qs[1] = (int32_t)bestIdx; nq = 1;
+  for (int j = 0; j < n; ++j)
+    if ((uint32_t)j != bestIdx) { qs[2 * nq] = edit[bestIdx * n + j]; qs[2 * nq + 1] = j; ++nq; }
+  qsort(qs, (size_t)nq, 2 * sizeof(int32_t), cmp_pair);
+  uint32_t lastIdx = (uint32_t)(0.8 * nq);
+  if (lastIdx < 3) lastIdx = 3;
+  int nsel = 0;
+  int* sel = (int*)malloc(sizeof(int) * (size_t)n);
+  for (uint32_t i = 0; i < (uint32_t)nq && i < lastIdx; ++i) sel[nsel++] = qs[2 * i + 1];
+  free(qs);
+  free(edit);
+  /* progressive alignment against the running 2-allele consensus (:426-447) */
+  const int l0 = (int)(off[sel[0] + 1] - off[sel[0]]);
+  amat al = amat_new(1, l0);
+  memcpy(al.d, blob + off[sel[0]], (size_t)l0);
+  for (int i = 1; i < nsel; ++i) {
+    char* astr = (char*)malloc((size_t)al.cols + 1);
+    consensus_edlib(&al, astr);
+    const char* q = blob + off[sel[i]];
+    const int qn = (int)(off[sel[i] + 1] - off[sel[i]]);
+    ed_res c;
+    ed_align_eq(q, qn, astr, al.cols, ED_NW, 2, eq, &c);
+    amat nx = convert_alignment_nw(q, &al, c.aln, c.aln_len);
+    free(c.aln);
+    free(astr);
+    amat_free(&al);
+    al = nx;
+  }
+  free(sel);
+  /* consensus(c, align, gapped, cs) (src/msa.h:111-173), then trim 5 % per side, <= 50 (:465-469) */
+  char* cs = (char*)malloc((size_t)al.cols + 1);
+  int L = consensus_core(p, &al, cs);
+  int32_t trim = (int32_t)(0.05 * L);
+  if (trim > 50) trim = 50;
+  int32_t len = L - 2 * trim;
+  if (len > 100) { memmove(cs, cs + trim, (size_t)len); L = len; }
+  const int rows = al.rows;
+  amat_free(&al);
+  *cs_out = cs;
+  *cs_len = L;
+  return rows;
+}
+
+int dor_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs, int cap, int* cs_len) {
+  char* c = NULL;
+  int L = 0;
+  int rows = msa_edlib_core(p, n_reads, blob, off, &c, &L);
+  *cs_len = L;
+  if (L <= cap) memcpy(cs, c, (size_t)L);
+  free(c);
+  return rows;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -10,10 +10,10 @@
  * bit-identical outputs on seeded inputs (the reference ships no tests or
  * golden vectors of its own -- SURVEY.md F8).
  *
- * edlib (vendored by the reference, src/edlib.cpp) is restated as a plain
- * unit-cost DP for the traceback regime (alignment data < 1 MiB); Hirschberg
- * mode and the long-read MSA (msaEdlib/msaWfa) are NOT restated:
- * dor_refine_batch reports DELLYHIP_E_LIMIT in result.status for those.
+ * edlib (vendored by the reference, src/edlib.cpp) is restated as the exact
+ * unit-cost DP it evaluates, including additional equalities and the
+ * Hirschberg split of obtainAlignment; msaEdlib is restated on top of it.
+ * msaWfa (long-read insertions) is NOT restated.
  */
 #ifndef DELLY_ORACLE_H
 #define DELLY_ORACLE_H
@@ -46,6 +46,9 @@ int dor_consensus(const dellyhip_params* p, const char* a, int r, int m, char* c
 int dor_guide_tree(int n_reads, const char* blob, const uint64_t* off, int* dflat, int* pflat);
 int dor_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
             int cap, int* cs_len);
+/* msaEdlib(c, sps, cs)  src/assemble.h:383-473 */
+int dor_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
+                  int cap, int* cs_len);
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

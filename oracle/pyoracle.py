@@ -171,6 +171,16 @@ class Oracle:
                               cap, C.byref(ln))
         return rows, cs[:ln.value].tobytes()
 
+    def msa_edlib(self, reads):
+        """msaEdlib(c, sps, cs) -> (rows, consensus)"""
+        blob, off = self._pack(reads)
+        cap = int(off[-1]) + 8
+        cs = np.zeros(cap, dtype=np.uint8)
+        ln = C.c_int(0)
+        rows = self._f("msa_edlib")(C.byref(self.params), len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)), _p(cs),
+                                    cap, C.byref(ln))
+        return rows, cs[:ln.value].tobytes()
+
     def unordered_set_order(self, reads):
         assert self.kind == "reference"
         blob, off = self._pack(reads)

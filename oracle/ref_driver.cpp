@@ -61,6 +61,8 @@ inline void reverseComplement(std::string& sequence) {
 
 #include "msa.h"
 #include "split.h"
+#include <numeric>          // std::iota (src/assemble.h:374 relies on a transitive include)
+#include "assemble_msa.h"   // src/assemble.h up to assemble(): derived into a temp dir at build time (oracle/Makefile)
 
 #include "../include/dellyhip.h"
 
@@ -255,7 +257,11 @@ int dref_long_needle(const char* s1, int m, const char* s2, int n, char* rows, i
 // Returns alignmentLength (ops copied to aln when it fits cap).
 int dref_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int task, int* out,
                      unsigned char* aln, int cap) {
-  EdlibAlignResult r = edlibAlign(q, qn, t, tn, edlibNewAlignConfig(-1, (EdlibAlignMode)mode, (EdlibAlignTask)task, NULL, 0));
+  // mode | 16: with the 20 extended-IUPAC equality pairs of msaEdlib (src/assemble.h:425)
+  EdlibEqualityPair additionalEqualities[20] = {{'M', 'A'}, {'M', 'C'}, {'R', 'A'}, {'R', 'G'}, {'W', 'A'}, {'W', 'T'}, {'B', 'A'}, {'B', '-'}, {'S', 'C'}, {'S', 'G'}, {'Y', 'C'}, {'Y', 'T'}, {'D', 'C'}, {'D', '-'}, {'K', 'G'}, {'K', 'T'}, {'E', 'G'}, {'E', '-'}, {'F', 'T'}, {'F', '-'}};
+  const bool iupac = (mode & 16) != 0;
+  mode &= 15;
+  EdlibAlignResult r = edlibAlign(q, qn, t, tn, edlibNewAlignConfig(-1, (EdlibAlignMode)mode, (EdlibAlignTask)task, iupac ? additionalEqualities : NULL, iupac ? 20 : 0));
   out[0] = r.editDistance;
   out[1] = r.numLocations;
   out[2] = r.endLocations ? r.endLocations[0] : -2;
@@ -322,6 +328,20 @@ int dref_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint
   for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
   std::string s;
   int rows = msa(c, sps, s);
+  *cs_len = (int)s.size();
+  if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
+  return rows;
+}
+
+// msaEdlib(c, sps, cs)  src/assemble.h:383-473; returns rows, consensus in cs
+int dref_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
+                   int cap, int* cs_len) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  std::vector<std::string> sps;
+  for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
+  std::string s;
+  int rows = msaEdlib(c, sps, s);
   *cs_len = (int)s.size();
   if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
   return rows;

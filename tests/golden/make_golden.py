@@ -101,12 +101,59 @@ def edlib_vectors(ref):
     print("edlib ok: %d alignments, %d splitAlign (%d true)" % (len(q_l), len(c_l), int(np.sum(np.array(rc_l) == 1))))
 
 
+def long_read_vectors(ref):
+    """edlib in its Hirschberg regime / with the extended-IUPAC equalities, and msaEdlib -> longread.npz"""
+    rng = np.random.default_rng(20260927)
+
+    def ont(s, rate):
+        out = bytearray()
+        for ch in s:
+            u = rng.random()
+            if u < rate / 3:
+                continue
+            if u < 2 * rate / 3:
+                out.append(rng.choice(list(b"ACGT")))
+                out.append(ch)
+                continue
+            if u < rate:
+                out.append(rng.choice(list(b"ACGT")))
+                continue
+            out.append(ch)
+        return bytes(out)
+
+    q_l, t_l, mode_l, out_l, ops_l = [], [], [], [], []
+    for it in range(10):
+        tn = int(rng.integers(1500, 3600))
+        t = random_seq(rng, tn, b"ACGT" if it % 2 else b"ACGTMRWBSYDKEF-")
+        q = ont(bytes(c for c in t if c in b"ACGT"), float(rng.choice([0.02, 0.06, 0.12])))
+        for mode in ((0, 16) if it % 2 == 0 else (0, 2, 1)):
+            ed, nl, el, sl, ops = ref.edlib_align(q, t, mode, 2)
+            q_l.append(q); t_l.append(t); mode_l.append(mode); out_l.append((ed, nl, el, sl)); ops_l.append(ops)
+    d = dict(q=np.array(q_l, dtype=object), t=np.array(t_l, dtype=object), mode=np.array(mode_l, dtype=np.int32),
+             out=np.array(out_l, dtype=np.int32), ops=np.array(ops_l, dtype=object))
+    ref.params = abi.params_lr()
+    sets, rows_l, cs_l = [], [], []
+    for it in range(6):
+        L = int(rng.integers(400, 2300))
+        base = random_seq(rng, L + 200)
+        n = int(rng.integers(3, 13))
+        reads = [ont(base[int(rng.integers(0, 100)):L + 100 + int(rng.integers(0, 100))], 0.06 if it % 2 else 0.02) for _ in range(n)]
+        rows, cs = ref.msa_edlib(reads)
+        sets.append(np.array(reads, dtype=object)); rows_l.append(rows); cs_l.append(cs)
+    ref.params = abi.params_sr()
+    d.update(msa_sets=np.array(sets, dtype=object), msa_rows=np.array(rows_l, dtype=np.int32), msa_cs=np.array(cs_l, dtype=object))
+    np.savez_compressed(os.path.join(HERE, "longread.npz"), **d)
+    print("longread ok: %d alignments, %d msaEdlib sets" % (len(q_l), len(sets)))
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Oracle("reference")
     only = sys.argv[1:]  # e.g. "u_ins edlib": regenerate just these (zip timestamps churn otherwise)
     if not only or "edlib" in only:
         edlib_vectors(ref)
+    if not only or "longread" in only:
+        long_read_vectors(ref)
     # --- batches ---------------------------------------------------------------
     for name, (n, kw) in BATCHES.items():
         if only and name not in only:

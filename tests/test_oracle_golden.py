@@ -65,6 +65,21 @@ def test_port_reproduces_golden_edlib(port):
         assert (prc, p0, p1) == (int(rc), r0, r1)
 
 
+def test_port_reproduces_golden_long_read_vectors(port):
+    """edlib's Hirschberg regime, the extended-IUPAC equalities, and msaEdlib (src/assemble.h:383-473)"""
+    g = np.load(os.path.join(GOLD, "longread.npz"), allow_pickle=True)
+    for q, t, mode, out, ops in zip(g["q"], g["t"], g["mode"], g["out"], g["ops"]):
+        r = port.edlib_align(q, t, int(mode), 2)
+        assert tuple(r[:4]) == tuple(int(x) for x in out) and r[4] == ops, (len(q), len(t), int(mode))
+    old = port.params
+    port.params = abi.params_lr()
+    try:
+        for reads, rows, cs in zip(g["msa_sets"], g["msa_rows"], g["msa_cs"]):
+            assert port.msa_edlib(list(reads)) == (int(rows), cs)
+    finally:
+        port.params = old
+
+
 def test_port_edlib_vs_reference_fresh(port, reference):
     rng = np.random.default_rng(99)
     for it in range(300):
