@@ -796,9 +796,28 @@ int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const c
     out[3] = -2;
     return 0;
   }
-  if (tn > dh::MMAX || qn > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "edlibAlign operand exceeds the insertion-kernel limits");
   HIPCHK(hipSetDevice(c->device));
   int rc;
+  if (mode == 0 && task == 0 && std::min(qn, tn) <= dh::MYERS_ROWS) {
+    // NW distance: Myers bit-vector kernel, pattern = the shorter string (the distance is symmetric)
+    DevBuf<uint8_t> dq, dt;
+    DevBuf<int32_t> dout;
+    if ((rc = dq.alloc(qn)) || (rc = dt.alloc(tn)) || (rc = dout.alloc(2))) return rc;
+    HIPCHK(hipMemcpy(dq.p, query, qn, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dt.p, target, tn, hipMemcpyHostToDevice));
+    if (qn <= tn) hipLaunchKernelGGL(dh::myers_single_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, dq.p, qn, dt.p, tn, dout.p);
+    else hipLaunchKernelGGL(dh::myers_single_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, dt.p, tn, dq.p, qn, dout.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int32_t d = 0;
+    HIPCHK(hipMemcpy(&d, dout.p, sizeof d, hipMemcpyDeviceToHost));
+    out[0] = d;
+    out[1] = 1;
+    out[2] = tn - 1;
+    out[3] = -2;
+    return 0;
+  }
+  if (tn > dh::MMAX || qn > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "edlibAlign operand exceeds the insertion-kernel limits");
   if ((rc = ensure_scratch(c))) return rc;
   DevBuf<uint8_t> dq, dt, dops;
   DevBuf<int32_t> dout;

@@ -21,6 +21,7 @@
 // like the free first row itself.  The M pass mirrors the slots inside a strip (lane 63 leads)
 // and visits the strips in reverse order, so M row r = m - rho pops exactly what R pushed.
 #pragma once
+#include "myers_kernel.hpp"
 #include "split_main.hpp"
 
 namespace dh {
@@ -507,8 +508,9 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int dF = lr_nw_distance(S.cons, m, S.ref, n, bnd0, bnd1, lane);
-    const int dR = lr_nw_distance(S.rcons, m, S.ref, n, bnd0, bnd1, lane);
+    // (bit-vector distance, myers_kernel.hpp; the plain strip recurrence lr_nw_distance gives the same numbers)
+    const int dF = rfl(myers_nw(S.cons, m, S.ref, n, lane));
+    const int dR = rfl(myers_nw(S.rcons, m, S.ref, n, lane));
     if (dR < dF) {   // consensus = revc
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];

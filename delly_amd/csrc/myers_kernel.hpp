@@ -1,0 +1,188 @@
+// myers_kernel.hpp -- gfx950 device code: global (NW) edit DISTANCE with Myers' bit-vector
+// recurrences, the arithmetic edlib itself uses (src/edlib.cpp:390-470 calculateBlock,
+// :728-930 myersCalcEditDistanceNW); the distance is unique, so no tie-breaking is involved.
+// Callers: all-pairs distances of msaEdlib (src/assemble.h:386-395), the orientation test of
+// _alignConsensus (src/split.h:564-572), dellyhip_edlib_align(NW, DISTANCE).
+//
+// One alignment per 64-lane wavefront.  The pattern (rows) is cut into 32-row words; lane l owns
+// NW consecutive words (rows 32*NW*l + 1 ...), text columns advance one per step with one
+// column of skew per lane, the horizontal delta (-1/0/+1) leaving a lane's last word travels
+// to the next lane by DPP -- the same systolic arrangement as the DP kernels, 32 cells per
+// ~25 VALU instructions instead of one.  Rows <= 64*32*MYERS_NW = 6144.
+#pragma once
+#include "split_kernel.hpp"
+
+namespace dh {
+
+constexpr int MYERS_NW = 3;                    // 32-bit words per lane
+constexpr int MYERS_ROWS = WAVE * 32 * MYERS_NW;
+
+// equality masks of one 32-row word for the letters A, C, G, T, N; other bytes are compared
+// on the fly (rare)
+struct MyersWord {
+  uint32_t eq[5];
+};
+
+__device__ __forceinline__ int myers_code(int c) {
+  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1;
+}
+
+// Returns the NW edit distance of pattern[0..pn) vs text[0..tn) (both > 0, pn <= 64*32*NWORDS).
+// pattern / text: any address space (LDS or global); exact byte comparison.
+template <int NWORDS>
+__device__ __forceinline__ int myers_nw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
+  MyersWord W[NWORDS];
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+  const int row0 = lane * 32 * NWORDS;   // zero-based first row of this lane
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) W[w].eq[k] = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int r = row0 + w * 32 + b;
+      if (r < pn) {
+        const int code = myers_code((int)pattern[r]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (code == k) W[w].eq[k] |= 1u << b;
+      }
+    }
+    Pv[w] = 0xffffffffu;   // D[i][0] = i
+    Mv[w] = 0;
+  }
+  // score at the bottom row of this lane's last word, column 0
+  int score = row0 + 32 * NWORDS;
+  const int lastlane = (pn - 1) / (32 * NWORDS);
+  const int T = tn + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 1;      // horizontal delta entering this lane (lane 0: D[0][j] - D[0][j-1] = +1)
+  int b = NOMATCH;
+  int c = -lane;
+  int fin = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int ci = blk * 16 + (lane & 15);
+    const int chunk = (ci < tn) ? (int)text[ci] : NOMATCH;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const int newc = __builtin_amdgcn_readlane(chunk, f);
+      b = dpp_from_prev(b, newc);
+      const int hin0 = dpp_from_prev(hcarry, 1);
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)tn) {
+        const int code = myers_code(b);
+        int hin = hin0;
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) {
+          uint32_t Eq;
+          if (code >= 0) {
+            Eq = code == 0 ? W[w].eq[0] : code == 1 ? W[w].eq[1] : code == 2 ? W[w].eq[2] : code == 3 ? W[w].eq[3] : W[w].eq[4];
+          } else {   // foreign byte: exact comparison against the pattern rows of this word
+            Eq = 0;
+            for (int q = 0; q < 32; ++q) {
+              const int r = row0 + w * 32 + q;
+              if (r < pn && (int)pattern[r] == b) Eq |= 1u << q;
+            }
+          }
+          // edlib.cpp:390-470 (Hyyro's block step), 32-bit words
+          const uint32_t hinNeg = (hin < 0) ? 1u : 0u;
+          const uint32_t Xv = Eq | Mv[w];
+          Eq |= hinNeg;
+          const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+          uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+          uint32_t Mh = Pv[w] & Xh;
+          const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+          Ph <<= 1;
+          Mh <<= 1;
+          Mh |= hinNeg;
+          Ph |= (hin > 0) ? 1u : 0u;
+          Pv[w] = Mh | ~(Xv | Ph);
+          Mv[w] = Ph & Xv;
+          hin = hout;
+        }
+        hcarry = hin;
+        score += hin;
+        if (c == tn) {
+          // D[pn][tn] lives in lane `lastlane`: bottom score minus the vertical deltas of the rows below pn
+          const int below = row0 + 32 * NWORDS - pn;   // rows of this lane beyond the pattern
+          int s = score;
+          if (below > 0) {
+#pragma unroll
+            for (int w = 0; w < NWORDS; ++w) {
+              const int lo = row0 + w * 32;             // zero-based first row of word w
+              const int nb = min(32, max(0, lo + 32 - pn));   // how many of its rows are >= pn
+              if (nb > 0) {
+                const uint32_t mk = (nb >= 32) ? 0xffffffffu : (~0u << (32 - nb));
+                s -= __popc(Pv[w] & mk);
+                s += __popc(Mv[w] & mk);
+              }
+            }
+          }
+          fin = s;
+        }
+      }
+    }
+  }
+  return __shfl(fin, lastlane);
+}
+
+__device__ __forceinline__ int myers_nw(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
+  if (pn <= WAVE * 32) return myers_nw_distance<1>(pattern, pn, text, tn, lane);
+  if (pn <= WAVE * 64) return myers_nw_distance<2>(pattern, pn, text, tn, lane);
+  return myers_nw_distance<3>(pattern, pn, text, tn, lane);
+}
+
+// ---- single call (dellyhip_edlib_align, NW + DISTANCE beyond the insertion-kernel shapes) ----
+__global__ __launch_bounds__(WAVE) void myers_single_kernel(const uint8_t* q, int qn, const uint8_t* t, int tn, int32_t* out) {
+  const int lane = threadIdx.x;
+  // rows = the shorter of the two strings would be cheaper; edlib's distance is symmetric
+  const int d = myers_nw(q, qn, t, tn, lane);
+  if (lane == 0) out[0] = d;
+}
+
+// ---- all pairs of a junction's reads: msaEdlib's distance matrix (src/assemble.h:386-395) ----
+struct PairArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  const int32_t* pair_first;   // first work item of junction j (prefix sums of n(n-1)/2), n_junc + 1 entries
+  int32_t n_junc;
+  int32_t n_items;
+  int32_t nrmax;               // row stride of a junction's matrix
+  int32_t* edit;               // edit[j*nrmax*nrmax + a*nrmax + b]
+};
+
+__global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
+  const int lane = threadIdx.x;
+  for (int item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+    // junction of this item: binary search in pair_first
+    int lo = 0, hi = A.n_junc;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (A.pair_first[mid] <= item) lo = mid;
+      else hi = mid;
+    }
+    const int j = lo;
+    const dellyhip_junction J = A.junc[j];
+    const int N = J.n_seq;
+    int rem = item - A.pair_first[j], a = 0;
+    while (rem >= N - 1 - a) {
+      rem -= N - 1 - a;
+      ++a;
+    }
+    const int bb = a + 1 + rem;
+    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + bb];
+    const int la = (int)(A.seq_off[J.seq_first + a + 1] - oa), lb = (int)(A.seq_off[J.seq_first + bb + 1] - ob);
+    int d;
+    if (la == 0 || lb == 0) d = max(la, lb);                 // edlib.cpp:160-166
+    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = -1;     // beyond the kernel limit (flagged by the consumer)
+    else if (la <= lb || lb > MYERS_ROWS) d = myers_nw(A.seq_blob + oa, la, A.seq_blob + ob, lb, lane);
+    else d = myers_nw(A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
+    if (lane == 0) {
+      int32_t* E = A.edit + (size_t)j * A.nrmax * A.nrmax;
+      E[a * A.nrmax + bb] = d;
+      E[bb * A.nrmax + a] = d;
+    }
+  }
+}
+
+}  // namespace dh

@@ -202,7 +202,8 @@ int dellyhip_long_needle(dellyhip_ctx* ctx, const char* s1, int32_t m, const cha
  * numLocations, endLocations[0], startLocations[0]} (start = -2 for DISTANCE);
  * ops receives the EDLIB_EDOP_* alignment of the first location (PATH).
  * Limits of this wrapper: targetLength <= 319, queryLength <= 2048 (the shapes
- * of the short-read insertion path; edlib's Hirschberg regime is not reached). */
+ * of the short-read insertion path; edlib's Hirschberg regime is not reached);
+ * NW + DISTANCE (bit-vector kernel): min(queryLength, targetLength) <= 6144. */
 int dellyhip_edlib_align(dellyhip_ctx* ctx, const char* query, int32_t query_len, const char* target,
                          int32_t target_len, int32_t mode, int32_t task, int32_t out[4],
                          unsigned char* ops, int32_t ops_cap, int32_t* ops_len);

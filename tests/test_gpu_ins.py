@@ -51,3 +51,28 @@ def test_edlib_align_limits(gpu_ctx):
     from delly_amd.refine import DellyHipError
     with pytest.raises(DellyHipError):
         gpu_ctx.edlib_align(b"ACGT", b"A" * 400, 2, 2)   # target beyond the 319-row kernel limit
+
+
+def test_nw_distance_bitvector_long_strings(gpu_ctx, port):
+    """edlibAlign(NW, DISTANCE) on long-read sized strings (Myers bit-vector kernel): golden vectors of the
+    reference's edlib, plus word / lane boundary lengths against the C restatement"""
+    g = np.load(os.path.join(GOLD, "longread.npz"), allow_pickle=True)
+    n = 0
+    for q, t, mode, out in zip(g["q"], g["t"], g["mode"], g["out"]):
+        if int(mode) != 0:
+            continue
+        r = gpu_ctx.edlib_align(q, t, 0, 0)
+        assert r[0] == int(out[0]), (len(q), len(t))
+        n += 1
+    assert n >= 5
+    rng = np.random.default_rng(23)
+    for ln in (1, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 4095, 4097, 6144):
+        t = bytes(rng.choice(list(b"ACGTNacgtR"), ln, p=[.24, .24, .24, .24, .01, .01, .005, .005, .005, .005]).astype(np.uint8))
+        q = bytearray(t)
+        for k in range(0, len(q), 7):
+            if rng.random() < 0.3:
+                q[k] = rng.choice(list(b"ACGT"))
+        q = bytes(q[: max(1, ln - int(rng.integers(0, 5)))]) + b"ACGT" * int(rng.integers(0, 3))
+        want = port.edlib_align(q, t, 0, 0)
+        got = gpu_ctx.edlib_align(q, t, 0, 0)
+        assert got[0] == want[0], (ln, got[0], want[0])
