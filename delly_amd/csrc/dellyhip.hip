@@ -17,6 +17,7 @@
 #include "split_pk.hpp"
 #include "ins_kernel.hpp"
 #include "lr_kernel.hpp"
+#include "lrmsa_kernel.hpp"
 
 namespace {
 
@@ -102,6 +103,11 @@ struct dellyhip_batch {
   int lr_first = 0, lr_count = 0, lr_blocks = 0;
   dh::LrArgs lr{};
   DevBuf<uint8_t> lr_ws;
+  // long-read MSA (with_msa == 2: msaEdlib)
+  DevBuf<int32_t> lm_edit, lm_pair_first;
+  DevBuf<uint8_t> lm_ws;
+  dh::LrMsaArgs lm{};
+  int lm_items = 0, lm_blocks = 0;
   // dellyhip_batch_fetch: device-side compaction
   DevBuf<uint64_t> blob_off;
   DevBuf<uint8_t> blob_compact;
@@ -264,6 +270,33 @@ int host_window_len(const dellyhip_params& P, const dellyhip_junction& J, int m,
 }
 
 bool is_lr_shape(const dellyhip_junction& J, int m, int n) { return J.svt != 4 && (m > dh::MMAX || n > dh::NMAX); }
+
+// per-block workspace of the long-read strip kernel for consensus <= lr_m, window <= lr_n
+int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, int lr_cnt) {
+  dh::LrArgs& R = b->lr;
+  R.mcap = (lr_m + 64) & ~63;
+  R.ncap = (lr_n + 64) & ~63;
+  const int Q = (lr_m + 1 + dh::LRS - 1) / dh::LRS;
+  R.strip_words = dh::lr_strip_words(R.ncap);
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take(R.mcap);                               // cons at 0
+  R.off_rcons = take(R.mcap);
+  R.off_ref = take(R.ncap);
+  R.off_rref = take(R.ncap);
+  R.off_bnd0 = take(((uint64_t)R.ncap + 128) * 4);
+  R.off_bnd1 = take(((uint64_t)R.ncap + 128) * 4);
+  R.off_br = take((uint64_t)dh::LR_QMAX * dh::LRS * 4);
+  R.off_trF = take((uint64_t)R.mcap + R.ncap + 64);
+  R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
+  R.off_stack = take((uint64_t)Q * R.strip_words * 4);
+  R.ws_stride = o;
+  b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * 4));
+  int rc = b->lr_ws.reserve((size_t)R.ws_stride * b->lr_blocks);
+  if (rc) return rc;
+  R.ws = b->lr_ws.p;
+  return 0;
+}
 
 // K-bins junctions by consensus length and pairs them (two junctions per wavefront, packed
 // 16-bit DP).  Within a bin junctions are sorted by their approximate reference-window length
@@ -440,7 +473,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -477,6 +510,11 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         ++lr_cnt;
       }
     }
+  }
+  if (with_msa == 2) {  // long-read MSA: consensus / window lengths are only bounded at upload time
+    b->out_cons_cap = (dh::LR_MMAX + 1 + 15) & ~15;
+    b->out_allele_cap = (dh::LR_MMAX + dh::LR_NMAX + 8 + 15) & ~15;
+    b->out_aln_cap = 2 * b->out_allele_cap;
   }
   if (lr_cnt) {
     b->out_cons_cap = std::max<int>(dh::OUT_CONS_CAP, (lr_m + 16) & ~15);
@@ -521,29 +559,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       e = hipMemcpy(b->cons_len.p, b->h_cons_len.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
     }
-    if (lr_cnt) {
-      dh::LrArgs& R = b->lr;
-      R.mcap = (lr_m + 64) & ~63;
-      R.ncap = (lr_n + 64) & ~63;
-      const int Q = (lr_m + 1 + dh::LRS - 1) / dh::LRS;
-      R.strip_words = dh::lr_strip_words(R.ncap);
-      uint64_t o = 0;
-      auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
-      take(R.mcap);                               // cons at 0
-      R.off_rcons = take(R.mcap);
-      R.off_ref = take(R.ncap);
-      R.off_rref = take(R.ncap);
-      R.off_bnd0 = take(((uint64_t)R.ncap + 128) * 4);
-      R.off_bnd1 = take(((uint64_t)R.ncap + 128) * 4);
-      R.off_br = take((uint64_t)dh::LR_QMAX * dh::LRS * 4);
-      R.off_trF = take((uint64_t)R.mcap + R.ncap + 64);
-      R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
-      R.off_stack = take((uint64_t)Q * R.strip_words * 4);
-      R.ws_stride = o;
-      b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * 4));
-      if ((rc = b->lr_ws.alloc((size_t)R.ws_stride * b->lr_blocks))) return bail(rc);
-      R.ws = b->lr_ws.p;
-    }
+    if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return bail(rc);
     if ((rc = build_bins(b, c->params))) return bail(rc);
   } else {
     // consensus is produced on the device at out_blob + i*stride
@@ -553,8 +569,42 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
     }
-    if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
-    if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+    if (with_msa == 2) {
+      // msaEdlib: all-pairs work list + per-block workspace sized from the longest read
+      std::vector<int32_t> pf(n + 1, 0);
+      int maxlen = 1;
+      for (int i = 0; i < n; ++i) {
+        const int N = std::max(0, std::min(junc[i].n_seq, (int)dh::LM_NR));
+        pf[i + 1] = pf[i] + ((junc[i].n_seq <= dh::LM_NR) ? N * (N - 1) / 2 : 0);
+        for (int k = 0; k < junc[i].n_seq; ++k)
+          maxlen = std::max<int>(maxlen, (int)std::min<uint64_t>(seq_off[junc[i].seq_first + k + 1] - seq_off[junc[i].seq_first + k], 1u << 20));
+      }
+      b->lm_items = pf[n];
+      if ((rc = b->lm_pair_first.alloc(n + 1)) || (rc = b->lm_edit.alloc(std::max<size_t>((size_t)n * dh::LM_NR * dh::LM_NR, 1)))) return bail(rc);
+      e = hipMemcpy(b->lm_pair_first.p, pf.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D pair list", e));
+      dh::LrMsaArgs& M = b->lm;
+      M.acap = (dh::LR_MMAX + 1 + 63) & ~63;
+      M.ncap = std::min<int>((maxlen + 64) & ~63, (dh::LR_NMAX + 64) & ~63);
+      M.strip_words = dh::lr_strip_words(M.ncap);
+      uint64_t o = 0;
+      auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+      take((uint64_t)dh::LM_NR * M.acap);                  // alnA at 0
+      M.off_alnB = take((uint64_t)dh::LM_NR * M.acap);
+      M.off_astr = take(M.acap);
+      M.off_bnd = take(4ull * ((uint64_t)M.ncap + 128) * 4);
+      M.off_ops = take((uint64_t)M.acap + M.ncap + 64);
+      M.off_tmp = take((uint64_t)M.acap + M.ncap + 64);
+      M.off_cons = take(M.acap);
+      M.off_dirs = take((uint64_t)(M.acap / dh::LRS + 1) * M.strip_words * 4);
+      M.ws_stride = o;
+      b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4));
+      if ((rc = b->lm_ws.alloc((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
+      M.ws = b->lm_ws.p;
+    } else {
+      if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
+      if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+    }
   }
   *out = b;
   return 0;
@@ -576,7 +626,46 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   for (int q = 0; q < 4; ++q) b->ev.push_back(e3[q]);
   b->mid = e3[3];
   HIPCHK(hipEventRecord(e3[0], s));
-  if (b->with_msa) {
+  if (b->with_msa == 2) {
+    // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
+    if (b->lm_items > 0) {
+      dh::PairArgs pa{b->junc.p, b->seq_blob.p, b->seq_off.p, b->lm_pair_first.p, b->n, b->lm_items, dh::LM_NR, b->lm_edit.p};
+      hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(std::min(b->lm_items, c->n_cu * 16)), dim3(dh::WAVE), 0, s, pa);
+      HIPCHK(hipGetLastError());
+    }
+    dh::LrMsaArgs M = b->lm;
+    M.junc = b->junc.p;
+    M.seq_blob = b->seq_blob.p;
+    M.seq_off = b->seq_off.p;
+    M.p = c->params;
+    M.res = b->res.p;
+    M.out_blob = b->out_blob.p;
+    M.out_stride = b->out_stride;
+    M.out_cons_cap = b->out_cons_cap;
+    M.cons_len = b->cons_len.p;
+    M.edit = b->lm_edit.p;
+    M.n_work = b->n;
+    hipLaunchKernelGGL(dh::lrmsa_kernel, dim3(b->lm_blocks), dim3(dh::WAVE), 0, s, M);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // consensus lengths known: window lengths, routing, strip-kernel workspace
+    int lr_m = 0, lr_n = 0, lr_cnt = 0;
+    b->h_win_len.resize(b->n);
+    for (int i = 0; i < b->n; ++i) {
+      const int m = b->h_cons_len[i];
+      const int w = host_window_len(c->params, b->h_junc[i], m, c->chr_len);
+      b->h_win_len[i] = w;
+      if (is_lr_shape(b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
+        lr_m = std::max(lr_m, m);
+        lr_n = std::max(lr_n, w);
+        ++lr_cnt;
+      }
+    }
+    b->lr_blocks = 0;
+    if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return rc;
+    if ((rc = build_bins(b, c->params))) return rc;
+  } else if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
     HIPCHK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(int32_t), s));
     dh::MsaArgs ma{};
@@ -728,6 +817,83 @@ int dellyhip_refine_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* j
                           const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results, char* out_blob,
                           uint64_t cap, uint64_t* used, int want_alignment) {
   return run_host_batch(c, n, junc, seq_blob, seq_off, n_seq, results, out_blob, cap, used, 1, want_alignment);
+}
+
+int dellyhip_refine_batch_lr(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                             const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results, char* out_blob,
+                             uint64_t cap, uint64_t* used, int want_alignment) {
+  return run_host_batch(c, n, junc, seq_blob, seq_off, n_seq, results, out_blob, cap, used, 2, want_alignment);
+}
+
+int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off, char* cs,
+                       int32_t cs_cap, int32_t* cs_len, int32_t* rows) {
+  if (!c || !cs_len || !rows || n_reads < 0 || (n_reads && (!seq_blob || !seq_off))) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (n_reads > dh::LM_NR) return fail(DELLYHIP_E_LIMIT, "msaEdlib: more reads than the kernel holds");
+  HIPCHK(hipSetDevice(c->device));
+  *cs_len = 0;
+  *rows = 0;
+  if (n_reads == 0) return 0;
+  int rc;
+  const uint64_t blob_bytes = seq_off[n_reads];
+  int maxlen = 1;
+  for (int k = 0; k < n_reads; ++k) maxlen = std::max<int>(maxlen, (int)(seq_off[k + 1] - seq_off[k]));
+  if (maxlen > dh::LR_NMAX) return fail(DELLYHIP_E_LIMIT, "msaEdlib: read longer than the kernel limit");
+  dellyhip_junction J{};
+  J.svt = 2;
+  J.n_seq = n_reads;
+  J.seq_first = 0;
+  const int32_t pf[2] = {0, n_reads * (n_reads - 1) / 2};
+  DevBuf<dellyhip_junction> dj;
+  DevBuf<uint8_t> dblob, dout, dws;
+  DevBuf<uint64_t> doff;
+  DevBuf<int32_t> dpf, dedit, dlen;
+  DevBuf<dellyhip_result> dres;
+  dh::LrMsaArgs M{};
+  M.acap = (dh::LR_MMAX + 1 + 63) & ~63;
+  M.ncap = (maxlen + 64) & ~63;
+  M.strip_words = dh::lr_strip_words(M.ncap);
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take((uint64_t)dh::LM_NR * M.acap);
+  M.off_alnB = take((uint64_t)dh::LM_NR * M.acap);
+  M.off_astr = take(M.acap);
+  M.off_bnd = take(4ull * ((uint64_t)M.ncap + 128) * 4);
+  M.off_ops = take((uint64_t)M.acap + M.ncap + 64);
+  M.off_tmp = take((uint64_t)M.acap + M.ncap + 64);
+  M.off_cons = take(M.acap);
+  M.off_dirs = take((uint64_t)(M.acap / dh::LRS + 1) * M.strip_words * 4);
+  M.ws_stride = o;
+  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(std::max<uint64_t>(blob_bytes, 1))) || (rc = doff.alloc(n_reads + 1)) ||
+      (rc = dpf.alloc(2)) || (rc = dedit.alloc(dh::LM_NR * dh::LM_NR)) || (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) ||
+      (rc = dout.alloc(M.acap)) || (rc = dws.alloc(M.ws_stride)))
+    return rc;
+  HIPCHK(hipMemcpy(dj.p, &J, sizeof J, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dblob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(doff.p, seq_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dpf.p, pf, sizeof pf, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
+  HIPCHK(hipMemset(dedit.p, 0, dh::LM_NR * dh::LM_NR * sizeof(int32_t)));
+  if (pf[1] > 0) {
+    dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p};
+    hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(pf[1]), dim3(dh::WAVE), 0, c->stream, pa);
+    HIPCHK(hipGetLastError());
+  }
+  M.junc = dj.p; M.seq_blob = dblob.p; M.seq_off = doff.p; M.p = c->params; M.res = dres.p;
+  M.out_blob = dout.p; M.out_stride = M.acap; M.out_cons_cap = M.acap; M.cons_len = dlen.p; M.edit = dedit.p;
+  M.n_work = 1; M.ws = dws.p;
+  hipLaunchKernelGGL(dh::lrmsa_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, M);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dellyhip_result R{};
+  int32_t L = 0;
+  HIPCHK(hipMemcpy(&R, dres.p, sizeof R, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&L, dlen.p, sizeof L, hipMemcpyDeviceToHost));
+  if (R.status) return fail(R.status, "msaEdlib: kernel limit");
+  *rows = R.sr_support;
+  *cs_len = L;
+  if (L > cs_cap) return fail(DELLYHIP_E_ARG, "consensus buffer too small");
+  if (L > 0) HIPCHK(hipMemcpy(cs, dout.p, L, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,

@@ -1,0 +1,452 @@
+// lrmsa_kernel.hpp -- gfx950 device code for msaEdlib (src/assemble.h:383-473), the long-read
+// consensus of `delly lr` (non-insertion junctions):
+//   all-pairs NW distances              -> myers_pairs_kernel (myers_kernel.hpp)
+//   medoid, order, drop the worst 20 %  -> lane-parallel ranks (N <= 16)
+//   progressive alignment of each read to the running 2-allele consensus:
+//     consensusEdlib (:198-259), edlibAlign(read, consensus, NW, PATH, 20 extended-IUPAC
+//     equalities) (:425-444), convertAlignment (:24-88)
+//   consensus (src/msa.h:111-173) + trim (:465-469)
+//
+// One junction per wavefront.  edlib's NW PATH is reproduced exactly: unit-cost DP with the
+// equality relation, rows = consensus letters in strips of 320 (lr_kernel.hpp geometry), columns
+// = read letters, per-cell op codes with edlib's traceback preference.  For alignments above
+// 1 MiB of edlib "alignment data" edlib switches to Hirschberg (src/edlib.cpp:1188-1389): the
+// target is split in the middle and the FIRST query index whose forward + backward scores reach
+// the optimum is taken; the same split is made here (the two score rows are strip boundary rows),
+// recursively, so the op string equals edlib's byte for byte.
+#pragma once
+#include "ins_kernel.hpp"
+#include "lr_kernel.hpp"
+#include "msa_kernel.hpp"
+
+namespace dh {
+
+constexpr int LM_NR = 16;                 // reads per junction (delly lr: maxReadPerSV = 15, src/tegua.h:241)
+constexpr int LM_STACK = 12;              // Hirschberg sub-problems in flight
+
+struct LrMsaArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  dellyhip_params p;
+  dellyhip_result* res;
+  uint8_t* out_blob;
+  uint64_t out_stride;
+  int32_t out_cons_cap;
+  int32_t* cons_len;
+  const int32_t* edit;      // all-pairs distances, LM_NR x LM_NR per junction
+  int32_t n_work;
+  uint8_t* ws;              // per resident block
+  uint64_t ws_stride;
+  int32_t acap;             // alignment columns capacity (<= LR_MMAX + 1)
+  int32_t ncap;             // read length capacity
+  uint64_t off_alnB, off_astr, off_bnd, off_ops, off_tmp, off_cons, off_dirs;   // alnA at 0
+  uint64_t strip_words;
+};
+
+struct __attribute__((aligned(16))) LrMsaLds {
+  int32_t first[NRMAX], last[NRMAX];      // consensus_node
+  int32_t med[LM_NR];
+  int32_t sel[LM_NR];
+  int32_t rlen[LM_NR];
+  uint64_t roff[LM_NR];
+};
+
+// index of a letter in the extended-IUPAC equality relation of msaEdlib (src/assemble.h:425), -1 = none
+__device__ __forceinline__ int iupac_index(int c) {
+  switch (c) {
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case '-': return 4;
+    case 'M': return 5; case 'R': return 6; case 'W': return 7; case 'B': return 8; case 'S': return 9;
+    case 'Y': return 10; case 'D': return 11; case 'K': return 12; case 'E': return 13; case 'F': return 14;
+    default: return -1;
+  }
+}
+// bit y of iupac_partners(x): letters x and y are declared equal (symmetric closure of the 20 pairs)
+__device__ __forceinline__ uint32_t iupac_partners(int x) {
+  //            A        C        G        T        -
+  // M={A,C} R={A,G} W={A,T} B={A,-} S={C,G} Y={C,T} D={C,-} K={G,T} E={G,-} F={T,-}
+  switch (x) {
+    case 0: return (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8);      // A ~ M R W B
+    case 1: return (1u << 5) | (1u << 9) | (1u << 10) | (1u << 11);    // C ~ M S Y D
+    case 2: return (1u << 6) | (1u << 9) | (1u << 12) | (1u << 13);    // G ~ R S K E
+    case 3: return (1u << 7) | (1u << 10) | (1u << 12) | (1u << 14);   // T ~ W Y K F
+    case 4: return (1u << 8) | (1u << 11) | (1u << 13) | (1u << 14);   // - ~ B D E F
+    case 5: return (1u << 0) | (1u << 1);
+    case 6: return (1u << 0) | (1u << 2);
+    case 7: return (1u << 0) | (1u << 3);
+    case 8: return (1u << 0) | (1u << 4);
+    case 9: return (1u << 1) | (1u << 2);
+    case 10: return (1u << 1) | (1u << 3);
+    case 11: return (1u << 1) | (1u << 4);
+    case 12: return (1u << 2) | (1u << 3);
+    case 13: return (1u << 2) | (1u << 4);
+    case 14: return (1u << 3) | (1u << 4);
+    default: return 0u;
+  }
+}
+
+// Unit-cost strip pass with the equality relation.  Target letter of global slot g = q*320 + ls
+// is row r = g - pad (rows < 0: +infinity dummies above row 0), t[r-1] = tp[(r-1)*tstep];
+// query letters qp[c*qstep].  E[r][0] = r, E[0][c] = c.  DIRS: edlib op code per cell
+// (preference INSERT > DELETE > diagonal) into `dirs`; bout: last slot of the strip per column.
+template <bool DIRS>
+__device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
+                                     int pad, const int32_t* bin, int32_t* bout, uint32_t* dirs, int lane) {
+  constexpr int K = LRK;
+  constexpr int POS = 1 << 28;
+  int a[K], h[K];
+  uint32_t part[K], acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int r = q * LRS + lane * K + i - pad;
+    a[i] = (r >= 1 && r <= tlen) ? (int)tp[(r - 1) * tstep] : NOMATCH;
+    h[i] = (r >= 0) ? r : POS;
+    const int ix = iupac_index(a[i]);
+    part[i] = iupac_partners(ix);
+    acc[i] = 0;
+  }
+  const int lastrow = min(LRS - 1, tlen + pad - q * LRS);   // local slot of the last real row in this strip
+  const int lastlane = lastrow / K;
+  const int T = qlen + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int upPrev = bin ? (q * LRS - pad - 1) : POS;   // E[row above][0]
+  int b = NOMATCH;
+  int c = -lane;
+  int outv = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int ci = blk * 16 + (lane & 15);
+    const int chunk = (ci < qlen) ? (int)qp[ci * qstep] : NOMATCH;
+    const int bchunk = (bin && ci + 1 <= qlen) ? bin[ci + 1] : POS;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      const int newc = __builtin_amdgcn_readlane(chunk, f);
+      const int bnd = __builtin_amdgcn_readlane(bchunk, f);
+      b = dpp_from_prev(b, newc);
+      const int recv = dpp_from_prev(h[K - 1], bnd);
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)qlen) {
+        const int iy = iupac_index(b);
+        const uint32_t ybit = (iy >= 0) ? (1u << iy) : 0u;
+        int diag = upPrev, up = recv;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          const bool eq = (a[i] == b) || ((part[i] & ybit) != 0u);
+          const int x = diag + (eq ? 0 : 1);
+          const int y = up + 1;     // consumes a target letter only : DELETE
+          const int z = h[i] + 1;   // consumes a query letter only  : INSERT
+          const int nv = min(min(x, y), z);
+          if (DIRS) {
+            const uint32_t code = (z == nv) ? (uint32_t)ED_INSERT
+                                            : ((y == nv) ? (uint32_t)ED_DELETE
+                                                         : ((diag == nv) ? (uint32_t)ED_MATCH : (uint32_t)ED_MISMATCH));
+            acc[i] |= code << (2 * f);
+          }
+          diag = h[i];
+          up = nv;
+          h[i] = nv;
+        }
+      }
+      upPrev = recv;
+      if (bout) outv = writelane16(__builtin_amdgcn_readlane(h[K - 1], 63), f, outv);
+    }
+    if (DIRS) {
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        dirs[((size_t)blk * K + i) * WAVE + lane] = acc[i];
+        acc[i] = 0;
+      }
+    }
+    if (bout) {
+      const int col = blk * 16 + lane - 62;
+      if (lane < 16 && col >= 1 && col <= qlen) bout[col] = outv;
+    }
+  }
+}
+
+// row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
+// (row_out[c] = distance(t, q[0..c))).  bndA / bndB: strip boundary scratch.
+__device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
+                                            int32_t* bndA, int32_t* bndB, int32_t* row_out, int lane) {
+  const int Q = (tlen + 1 + LRS - 1) / LRS;
+  const int pad = Q * LRS - (tlen + 1);   // row tlen = last slot of the last strip
+  for (int q = 0; q < Q; ++q) {
+    const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
+    int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : row_out;
+    lm_pass<false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, bin, bout, nullptr, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (lane == 0) row_out[0] = tlen;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// plain (traceback-regime) NW path of t[0..tlen) vs q[0..qlen): direction strips + windowed
+// run-length traceback; ops appended to `ops` (forward order) at position pos; returns new pos
+__device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const uint8_t* qy, int qlen, int32_t* bndA,
+                                             int32_t* bndB, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                             uint8_t* ops, int pos, int lane) {
+  const int Q = tlen / LRS + 1;
+  for (int q = 0; q < Q; ++q) {
+    const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
+    int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
+    lm_pass<true>(t, 1, tlen, qy, 1, qlen, q, 0, bin, bout, dirs + (size_t)q * strip_words, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  GeoLR G{dirs, strip_words};
+  int rr = tlen, cc = qlen;
+  int tl = traceback_runs<true>(G, rr, cc, tmp, lane);
+  // border runs: target exhausted -> INSERTs, query exhausted -> DELETEs (edlib.cpp:1027-1091)
+  const int tail = (rr > 0) ? rr : cc;
+  const uint8_t op = (rr > 0) ? (uint8_t)ED_DELETE : (uint8_t)ED_INSERT;
+  for (int k = lane; k < tail; k += WAVE) tmp[tl + k] = op;
+  tl += tail;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int k = lane; k < tl; k += WAVE) ops[pos + k] = tmp[tl - 1 - k];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return pos + tl;
+}
+
+// edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment  (obtainAlignment,
+// edlib.cpp:1163-1389).  Returns the op count, ops[] in forward order; -1 on overflow.
+__device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int32_t* bnd,
+                                          int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                          uint8_t* ops, int ops_cap, int lane) {
+  // explicit stack of rectangles (t0, tlen, q0, qlen), processed left to right
+  int st[LM_STACK][4];
+  int sp = 0;
+  st[sp][0] = 0; st[sp][1] = tn; st[sp][2] = 0; st[sp][3] = qn;
+  ++sp;
+  int pos = 0;
+  int32_t* bndA = bnd;
+  int32_t* bndB = bnd + bnd_stride;
+  int32_t* left = bnd + 2 * bnd_stride;
+  int32_t* right = bnd + 3 * bnd_stride;
+  while (sp > 0) {
+    --sp;
+    const int t0 = rfl(st[sp][0]), tl = rfl(st[sp][1]), q0 = rfl(st[sp][2]), ql = rfl(st[sp][3]);
+    if (pos + tl + ql > ops_cap) return -1;
+    if (ql == 0 || tl == 0) {   // edlib.cpp:1169-1176
+      const uint8_t op = (ql == 0) ? (uint8_t)ED_DELETE : (uint8_t)ED_INSERT;
+      for (int k = lane; k < tl + ql; k += WAVE) ops[pos + k] = op;
+      pos += tl + ql;
+      continue;
+    }
+    const long long blocks = (ql + 63) / 64;
+    const long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
+    if (sz < 1024 * 1024) {
+      pos = lm_plain_path(target + t0, tl, query + q0, ql, bndA, bndB, dirs, strip_words, tmp, ops, pos, lane);
+      continue;
+    }
+    // Hirschberg step
+    const int lw = tl / 2, rw = tl - lw;
+    lm_last_row(target + t0, 1, lw, query + q0, 1, ql, bndA, bndB, left, lane);                        // left[i]  : q[0..i) vs t[0..lw)
+    lm_last_row(target + t0 + tl - 1, -1, rw, query + q0 + ql - 1, -1, ql, bndA, bndB, right, lane);   // right[k] : last k letters of q vs t[lw..)
+    // optimum and the first query index that reaches it (ascending), then the two boundary cases
+    int best = 1 << 30;
+    for (int i = lane; i <= ql; i += WAVE) best = min(best, left[i] + right[ql - i]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o));
+    best = rfl(best);
+    int ul = -1;
+    for (int base = 1; base <= ql - 1 && ul < 0; base += WAVE) {
+      const int i = base + lane;
+      const bool hit = (i <= ql - 1) && (left[i] + right[ql - i] == best);
+      const unsigned long long bm = __ballot(hit);
+      if (bm) ul = base + __builtin_ctzll(bm);
+    }
+    if (ul < 0) ul = (left[0] + right[ql] == best) ? 0 : ql;
+    ul = rfl(ul);
+    if (sp + 2 > LM_STACK) return -1;
+    st[sp][0] = t0 + lw; st[sp][1] = rw; st[sp][2] = q0 + ul; st[sp][3] = ql - ul;   // lower right (second)
+    ++sp;
+    st[sp][0] = t0; st[sp][1] = lw; st[sp][2] = q0; st[sp][3] = ul;                  // upper left (first)
+    ++sp;
+  }
+  return pos;
+}
+
+// msaEdlib for one junction
+__device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* ws, int lane) {
+  const dellyhip_junction J = A.junc[j];
+  dellyhip_result* out = &A.res[j];
+  uint8_t* cons_out = A.out_blob + (size_t)j * A.out_stride;
+  const int N = J.n_seq;
+  int status = 0, cons_len = 0, rows = 0;
+  uint8_t* alnA = ws;
+  uint8_t* alnB = ws + A.off_alnB;
+  uint8_t* astr = ws + A.off_astr;
+  int32_t* bnd = reinterpret_cast<int32_t*>(ws + A.off_bnd);
+  uint8_t* ops = ws + A.off_ops;
+  uint8_t* tmp = ws + A.off_tmp;
+  uint8_t* cbuf = ws + A.off_cons;
+  uint32_t* dirs = reinterpret_cast<uint32_t*>(ws + A.off_dirs);
+  const int bnd_stride = A.ncap + 128;
+  const int acap = A.acap;
+  if (N >= 1) {
+    if (N > LM_NR || J.svt == 4) status = DELLYHIP_E_LIMIT;   // (insertions use msaWfa: not on the device)
+    if (!status) {
+      for (int r = lane; r < N; r += WAVE) {
+        const uint64_t a = A.seq_off[J.seq_first + r], b = A.seq_off[J.seq_first + r + 1];
+        L.roff[r] = a;
+        L.rlen[r] = (int32_t)(b - a);
+      }
+      __syncthreads();
+      for (int r = 0; r < N; ++r)
+        if (L.rlen[r] > A.ncap || L.rlen[r] < 1) status = DELLYHIP_E_LIMIT;
+    }
+    const int32_t* E = A.edit + (size_t)j * LM_NR * LM_NR;
+    if (!status) {
+      for (int q = lane; q < N * N; q += WAVE) {
+        const int a = q / N, b = q - a * N;
+        if (a != b && E[a * LM_NR + b] < 0) status = DELLYHIP_E_LIMIT;
+      }
+      status = (__ballot(status != 0) != 0ull) ? DELLYHIP_E_LIMIT : 0;
+    }
+    if (!status) {
+      // ---- medoid (assemble.h:397-408): median = element of rank N/2 of each row (diagonal = 0)
+      if (lane < N) {
+        int med = 0;
+        for (int x = 0; x < N; ++x) {
+          const int vx = (x == lane) ? 0 : E[lane * LM_NR + x];
+          int rank = 0;
+          for (int y = 0; y < N; ++y) {
+            const int vy = (y == lane) ? 0 : E[lane * LM_NR + y];
+            rank += (vy < vx || (vy == vx && y < x)) ? 1 : 0;
+          }
+          if (rank == N / 2) med = vx;
+        }
+        L.med[lane] = med;
+      }
+      __syncthreads();
+      int bestIdx = 0, bestVal = L.rlen[0];
+      for (int i = 0; i < N; ++i)
+        if (L.med[i] < bestVal) { bestVal = L.med[i]; bestIdx = i; }
+      // ---- order by (distance to the medoid, index), medoid first; keep 80 % (>= 3) (:410-424)
+      uint32_t lastIdx = (uint32_t)(0.8 * N);
+      if (lastIdx < 3) lastIdx = 3;
+      const int nsel = min((int)lastIdx, N);
+      if (lane < N) {
+        const int kx = (lane == bestIdx) ? 0 : E[bestIdx * LM_NR + lane];
+        int rank = 0;
+        for (int y = 0; y < N; ++y) {
+          const int ky = (y == bestIdx) ? 0 : E[bestIdx * LM_NR + y];
+          // pair order (score, index); the medoid's pair is (0, bestIdx)
+          rank += (ky < kx || (ky == kx && y < lane)) ? 1 : 0;
+        }
+        if (rank < LM_NR) L.sel[rank] = lane;
+      }
+      __syncthreads();
+      // ---- progressive alignment (:426-447)
+      const uint8_t* blob = A.seq_blob;
+      uint8_t* cur = alnA;
+      uint8_t* nxt = alnB;
+      int arows = 1, acols = L.rlen[L.sel[0]];
+      if (acols > acap - 1) status = DELLYHIP_E_LIMIT;
+      if (!status) {
+        const uint8_t* r0 = blob + L.roff[L.sel[0]];
+        for (int k = lane; k < acols; k += WAVE) cur[k] = r0[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      for (int step = 1; step < nsel && !status; ++step) {
+        // consensusEdlib (:198-259)
+        for (int col = lane; col < acols; col += WAVE) {
+          int count[5] = {0, 0, 0, 0, 0};
+          for (int r = 0; r < arows; ++r) {
+            const uint8_t ch = cur[(size_t)r * acap + col];
+            if (ch == 'A' || ch == 'a') ++count[0];
+            else if (ch == 'C' || ch == 'c') ++count[1];
+            else if (ch == 'G' || ch == 'g') ++count[2];
+            else if (ch == 'T' || ch == 't') ++count[3];
+            else ++count[4];
+          }
+          int maxIdx = 0, sndIdx = 1;
+          if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
+#pragma unroll
+          for (int i = 2; i < 5; ++i) {
+            if (count[i] > count[maxIdx]) { sndIdx = maxIdx; maxIdx = i; }
+            else if (count[i] > count[sndIdx]) sndIdx = i;
+          }
+          uint8_t letter;
+          if (2 * count[sndIdx] < count[maxIdx]) letter = (maxIdx < 4) ? (uint8_t)("ACGT"[maxIdx]) : (uint8_t)'-';
+          else {
+            const int k1 = min(maxIdx, sndIdx), k2 = max(maxIdx, sndIdx);
+            // ACGT- pairs: M R W B / S Y D / K E / F
+            const int code = k1 * 5 + k2;
+            letter = code == 1 ? 'M' : code == 2 ? 'R' : code == 3 ? 'W' : code == 4 ? 'B' : code == 7 ? 'S' : code == 8 ? 'Y'
+                   : code == 9 ? 'D' : code == 13 ? 'K' : code == 14 ? 'E' : code == 19 ? 'F' : '-';
+          }
+          astr[col] = letter;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int rd = L.sel[step];
+        const uint8_t* qy = blob + L.roff[rd];
+        const int qn = L.rlen[rd];
+        const int nops = lm_nw_path(astr, acols, qy, qn, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
+        if (nops < 0 || nops > acap - 1) { status = DELLYHIP_E_LIMIT; break; }   // (the next target must fit the strips)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // convertAlignment(query, align, NW, cigar) (:24-88)
+        int tbase = 0, qbase = 0;
+        for (int base = 0; base < nops; base += WAVE) {
+          const int jc = base + lane;
+          const int op = (jc < nops) ? (int)ops[jc] : ED_MATCH;
+          const unsigned long long mt = __ballot(jc < nops && op != ED_INSERT);
+          const unsigned long long mq = __ballot(jc < nops && op != ED_DELETE);
+          const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int ti = tbase + __popcll(mt & below), qi = qbase + __popcll(mq & below);
+          if (jc < nops) {
+            for (int r = 0; r < arows; ++r) nxt[(size_t)r * acap + jc] = (op != ED_INSERT) ? cur[(size_t)r * acap + ti] : (uint8_t)'-';
+            nxt[(size_t)arows * acap + jc] = (op != ED_DELETE) ? qy[qi] : (uint8_t)'-';
+          }
+          tbase += __popcll(mt);
+          qbase += __popcll(mq);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint8_t* sw = cur; cur = nxt; nxt = sw;
+        arows += 1;
+        acols = nops;
+      }
+      if (!status) {
+        // consensus (src/msa.h:111-173), then trim 5 % per side, at most 50 (:465-469)
+        Node nd{cur, arows, acols, acap};
+        int Lc = consensus_node(nd, A.p, cbuf, acap, L, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int trim = (int)(0.05 * Lc);
+        if (trim > 50) trim = 50;
+        const int len = Lc - 2 * trim;
+        int o = 0;
+        if (len > 100) { o = trim; Lc = len; }
+        if (Lc > A.out_cons_cap) status = DELLYHIP_E_LIMIT;
+        else {
+          for (int k = lane; k < Lc; k += WAVE) cons_out[k] = cbuf[o + k];
+          cons_len = Lc;
+          rows = arows;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    out->sr_support = rows;
+    out->status = status;
+    A.cons_len[j] = status ? 0 : cons_len;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(WAVE) void lrmsa_kernel(LrMsaArgs A) {
+  __shared__ LrMsaLds L;
+  const int lane = threadIdx.x;
+  uint8_t* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) lrmsa_junction(A, w, L, ws, lane);
+}
+
+}  // namespace dh

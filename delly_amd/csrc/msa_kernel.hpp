@@ -667,7 +667,8 @@ __device__ __forceinline__ int merge_nodes(const Node& a1, const Node& a2, uint8
 }
 
 // ---- K7: consensus  src/msa.h:111-173.  Writes the ungapped consensus (<= cap bytes), returns its length.
-__device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_params& P, uint8_t* cs, int cap, MsaLds& L,
+template <typename LT>
+__device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_params& P, uint8_t* cs, int cap, LT& L,
                                               int lane) {
   for (int i = 0; i < a.rows; ++i) {
     int first = a.len, last = -1;

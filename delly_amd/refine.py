@@ -26,7 +26,7 @@ EXPORTS = [
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
     "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
-    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align",
+    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib",
 ]
 
 
@@ -122,8 +122,14 @@ class Context:
         """msa() + alignConsensus() for every junction: loop body of src/shortpe.h:183-197."""
         return self._run_host(self.lib.dellyhip_refine_batch, junctions, seq_blob, seq_off, want_alignment)
 
+    def refine_batch_lr(self, junctions, seq_blob, seq_off, want_alignment=False):
+        """msaEdlib() + alignConsensus(..., realign): loop body of src/assemble.h:833-872 (non-insertion junctions)."""
+        return self._run_host(self.lib.dellyhip_refine_batch_lr, junctions, seq_blob, seq_off, want_alignment)
+
     def refine(self, batch, want_alignment=False):
         """Convenience for a synth.Batch."""
+        if batch.with_msa == 2:
+            return self.refine_batch_lr(batch.junctions, batch.seq_blob, batch.seq_off, want_alignment)
         fn = self.refine_batch if batch.with_msa else self.align_consensus_batch
         return fn(batch.junctions, batch.seq_blob, batch.seq_off, want_alignment)
 
@@ -185,6 +191,21 @@ class Context:
         return rows.value, cs[:ln.value].tobytes()
 
 
+    def _msa_like(self, fn, reads):
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        blob = _u8(b"".join(reads))
+        cap = int(off[-1]) + 8
+        cs = np.zeros(cap, dtype=np.uint8)
+        ln, rows = C.c_int32(0), C.c_int32(0)
+        self._check(fn(self._ctx, len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)), _p(cs), cap, C.byref(ln), C.byref(rows)))
+        return rows.value, cs[:ln.value].tobytes()
+
+    def msa_edlib(self, reads):
+        """msaEdlib(c, sps, cs) -> (rows, consensus)"""
+        return self._msa_like(self.lib.dellyhip_msa_edlib, reads)
+
+
 class ResidentBatch:
     """Junction batch kept in HBM (bench / pipelined callers)."""
 
@@ -194,11 +215,11 @@ class ResidentBatch:
         self._b = C.c_void_p()
         junc = np.ascontiguousarray(batch.junctions)
         blob = _u8(batch.seq_blob)
-        self._blob_bytes = 0 if batch.with_msa else int(blob.size)
+        self._blob_bytes = int(blob.size) if batch.with_msa != 1 else 0
         off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
         rc = ctx.lib.dellyhip_batch_upload(ctx._ctx, self.n, _p(junc, C.c_void_p), _p(blob),
                                            _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1),
-                                           int(bool(batch.with_msa)), C.byref(self._b))
+                                           int(batch.with_msa), C.byref(self._b))
         ctx._check(rc)
 
     def run(self, stream=None):

@@ -185,6 +185,17 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_sp
  * dellyhip_batch_kernel_ms() call (HIP events on the launch stream). */
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
+/* Long-read flavour of dellyhip_refine_batch: the loop body of src/assemble.h:833-872 for
+ * non-insertion junctions -- msaEdlib(c, seqStore[svid], consensus) (src/assemble.h:383-473)
+ * followed by alignConsensus(c, hdr, seq, NULL, sv, realign) with the `delly lr` parameters
+ * (dellyhip_default_params_lr; realign = bit 0 of params.reserved).  Reads: at most 16 per
+ * junction, each <= 24000 bytes and -- for the all-pairs distances -- at least one of every
+ * two <= 6144 bytes.  svt 4 junctions (msaWfa) are flagged DELLYHIP_E_LIMIT. */
+int dellyhip_refine_batch_lr(dellyhip_ctx* ctx, int32_t n_junctions, const dellyhip_junction* junctions,
+                             const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq,
+                             dellyhip_result* results, char* out_blob, uint64_t out_blob_cap,
+                             uint64_t* out_blob_len, int want_alignment);
+
 /* ---- single-item wrappers (parity tests, assemble.h / asmode.h call sites) */
 
 /* bool longNeedle(s1, s2, align, AlignConfig<true,false>, DnaScore(1,-1,-1,-1))
@@ -222,6 +233,10 @@ int dellyhip_gotoh(dellyhip_ctx* ctx, const char* a1, int32_t r1, int32_t m, con
 /* int msa(c, sps, cs)  src/msa.h:185-239: returns rows in *rows, consensus in cs. */
 int dellyhip_msa(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,
                  char* cs, int32_t cs_cap, int32_t* cs_len, int32_t* rows);
+
+/* int msaEdlib(c, sps, cs)  src/assemble.h:383-473: returns rows in *rows, consensus in cs. */
+int dellyhip_msa_edlib(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,
+                       char* cs, int32_t cs_cap, int32_t* cs_len, int32_t* rows);
 
 #ifdef __cplusplus
 }
