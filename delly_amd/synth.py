@@ -30,6 +30,19 @@ def _rng(seed, j):
     return np.random.Generator(np.random.Philox(key=[seed, 0x5eed], counter=[j, 0, 0, 0]))
 
 
+def _ont(rng, seq, rate):
+    """ONT-like errors: one third each substitution / insertion / deletion"""
+    u = rng.random(seq.size)
+    keep = u >= rate / 3                      # deletions
+    seq = seq[keep]
+    u = u[keep]
+    sub = (u >= rate / 3) & (u < 2 * rate / 3)
+    seq = seq.copy()
+    seq[sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+    at = np.nonzero(u >= 1 - rate / 3)[0]     # insertions
+    return np.insert(seq, at, ACGT[rng.integers(0, 4, at.size)])
+
+
 def _mutate(rng, seq, rate):
     seq = seq.copy()
     if rate > 0:
@@ -237,11 +250,16 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         else:
             seen = set()
             lo, hi = 25, alt.size - read_len - 25
+            if mode == "lr":   # long reads span the junction: ~L - 100 bases of each flank
+                lo, hi = 0, 100
             tries = 0
             while len(seen) < n_reads and tries < 50 * n_reads:
                 tries += 1
                 o = int(rng.integers(lo, hi + 1))
-                r = _mutate(rng, alt[o:o + read_len], sub_rate)
+                if mode == "lr":
+                    r = _ont(rng, alt[o:alt.size - int(rng.integers(0, 101))], sub_rate)
+                else:
+                    r = _mutate(rng, alt[o:o + read_len], sub_rate)
                 key = r.tobytes()
                 if key in seen:
                     continue
@@ -253,4 +271,4 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
     off[1:] = np.cumsum([x.size for x in seqs], dtype=np.uint64)
     blob = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
     chroms = [chrA, chrB] if two_chr else [chrA]
-    return Batch(chroms, junc, blob, off, n_reads > 0, truth)
+    return Batch(chroms, junc, blob, off, (2 if mode == "lr" else 1) if n_reads > 0 else 0, truth)

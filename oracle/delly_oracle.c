@@ -1472,7 +1472,11 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   char* cons = NULL;
   int m = 0;
   if (b->with_msa) {
-    if (J->n_seq <= 1) return; /* shortpe.h:166-171 */
+    if (b->with_msa != 2 && J->n_seq <= 1) return; /* shortpe.h:166-171 */
+    if (b->with_msa == 2) { /* long-read loop body: src/assemble.h:839 */
+      if (J->n_seq < 1) return;
+      R->sr_support = msa_edlib_core(c, J->n_seq, b->blob, b->off + J->seq_first, &cons, &m);
+    } else
     R->sr_support = msa_core(c, J->n_seq, b->blob, b->off + J->seq_first, &cons, &m);
     /* NOTE: off + seq_first keeps absolute offsets into blob */
   } else {

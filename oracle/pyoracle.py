@@ -208,7 +208,7 @@ class Oracle:
         rc = self._f("refine_batch")(
             C.byref(p), nchr, chr_ptrs, _p(chr_len, C.POINTER(C.c_int64)), n,
             _p(junc, C.c_void_p), _p(batch.seq_blob), _p(batch.seq_off, C.POINTER(C.c_uint64)),
-            _p(res, C.c_void_p), _p(out), C.c_uint64(cap), C.byref(used), int(bool(with_msa)),
+            _p(res, C.c_void_p), _p(out), C.c_uint64(cap), C.byref(used), int(with_msa),
             int(bool(want_alignment)), int(n_threads))
         assert rc == 0, "oracle out_blob overflow"
         return res, out[:used.value]

@@ -131,11 +131,13 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
 
   if (with_msa) {
     // src/shortpe.h:166-171: <=1 read -> no consensus, junction skipped
-    if (J.n_seq <= 1) return;
+    if (with_msa != 2 && J.n_seq <= 1) return;
+    if (J.n_seq < 1) return;
     std::vector<std::string> sps;  // iteration order == the host's set order
     for (int32_t k = 0; k < J.n_seq; ++k)
       sps.push_back(std::string(blob + off[J.seq_first + k], blob + off[J.seq_first + k + 1]));
-    R.sr_support = msa(c, sps, sv.consensus);  // src/shortpe.h:185
+    if (with_msa == 2) R.sr_support = msaEdlib(c, sps, sv.consensus);  // src/assemble.h:839
+    else R.sr_support = msa(c, sps, sv.consensus);  // src/shortpe.h:185
   } else {
     sv.consensus = std::string(blob + off[J.seq_first], blob + off[J.seq_first + 1]);
     R.sr_support = 0;

@@ -31,8 +31,10 @@ BATCHES = {
     "full_ins_n6": (30, dict(mode="ins", seed=47, first=0, n_reads=6)),
     # long-read shapes (BASELINE config C4) with `delly lr` parameters and realign=true
     "u_lr": (10, dict(mode="lr", seed=48, first=0, sub_rate=0.01)),
+    # long-read loop body: msaEdlib over 8 ONT-like reads (6 % errors) + alignConsensus(realign)
+    "full_lr_n8": (4, dict(mode="lr", seed=49, first=0, n_reads=8, sub_rate=0.06)),
 }
-LR_BATCHES = {"u_lr"}
+LR_BATCHES = {"u_lr", "full_lr_n8"}
 
 
 def random_seq(rng, n, alphabet=b"ACGT"):

@@ -58,3 +58,22 @@ def test_msa_edlib_vs_port_small_and_edge(lr_ctx, port):
             assert lr_ctx.msa_edlib(reads) == port.msa_edlib(reads), (it, n, L)
     finally:
         port.params = old
+
+
+def test_refine_batch_lr_reproduces_reference_golden_vectors(lr_ctx):
+    """msaEdlib + alignConsensus(realign) vs the committed outputs of the reference (batch_full_lr_n8.npz)"""
+    g = np.load(os.path.join(GOLD, "batch_full_lr_n8.npz"), allow_pickle=True)
+    b = synth.make_batch(int(g["n"]), **eval(str(g["kwargs"])))
+    assert b.with_msa == 2
+    lr_ctx.set_chromosomes(b.chroms)
+    gr, gb = lr_ctx.refine(b, want_alignment=True)
+    compare(gr, gb, g["results"], g["blob"], label="batch_full_lr_n8.npz")
+    assert int(gr["ok"].sum()) == b.n
+
+
+def test_refine_batch_lr_vs_port(lr_ctx, port):
+    b = synth.make_batch(6, mode="lr", n_reads=5, sub_rate=0.05, seed=77, first=20)
+    lr_ctx.set_chromosomes(b.chroms)
+    gr, gb = lr_ctx.refine(b, want_alignment=False)
+    pr, pb = port.refine_batch(b, params=abi.params_lr(realign=True), want_alignment=False)
+    compare(gr, gb, pr, pb, fields=CORE + INTERNAL, blobs=("cons", "allele"), label="hip-vs-port")
