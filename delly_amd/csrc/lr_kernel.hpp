@@ -113,10 +113,13 @@ __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref,
   int b = NOMATCH;
   int c = -lane;
   int outv = 0;
+  // the column letters / boundary values of block blk+1 are loaded while block blk computes
+  // (one wavefront per SIMD cannot hide a dependent HBM/L2 load per 16 steps)
+  auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < n) ? (int)rref[ci] : NOMATCH; };
+  auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= n) ? bin[ci + 1] : NEGBIG; };
+  int chunk = ld_chunk(0), bchunk = ld_bnd(0);   // column of lane 0 at step 16*blk+f is 16*blk+f+1
   for (int blk = 0; blk < nblk; ++blk) {
-    const int ci = blk * 16 + (lane & 15);
-    const int chunk = (ci < n) ? (int)rref[ci] : NOMATCH;
-    const int bchunk = (bin && ci + 1 <= n) ? bin[ci + 1] : NEGBIG;   // column of lane 0 at step 16*blk+f is 16*blk+f+1
+    const int chunk_n = ld_chunk(blk + 1), bchunk_n = ld_bnd(blk + 1);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
       const int newc = __builtin_amdgcn_readlane(chunk, f);
@@ -152,6 +155,8 @@ __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref,
       const int col = blk * 16 + lane - 62;
       if (lane < 16 && col >= 0 && col <= n) bout[col] = outv;
     }
+    chunk = chunk_n;
+    bchunk = bchunk_n;
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) brout[q * LRS + lane * K + i] = br[i];
@@ -186,16 +191,28 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
   int b = NOMATCH;
   int c = (T - nblk * 16) - 63 + lane;
   int outv = 0;
+  auto ld_chunk = [&](int blk) { const int ci = T - blk * 16 - 16 + (lane & 15); return (blk >= 0 && ci >= 0 && ci < n) ? (int)ref[ci] : NOMATCH; };
+  auto ld_bnd = [&](int blk) {   // lane 63's column = ci + 1
+    const int ci = T - blk * 16 - 16 + (lane & 15);
+    return (bin && blk >= 0 && ci + 1 >= 0 && ci + 1 <= n) ? bin[ci + 1] : NEGBIG;
+  };
+  uint32_t wn[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) wn[i] = ld_scratch(&stack[((size_t)(nblk - 1) * K + i) * WAVE + lane]);
+  int chunk = ld_chunk(nblk - 1), bchunk = ld_bnd(nblk - 1);
   for (int blk = nblk - 1; blk >= 0; --blk) {
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const uint32_t w = ld_scratch(&stack[((size_t)blk * K + i) * WAVE + lane]);
+      const uint32_t w = wn[i];
       const uint32_t hi = (w >> 1) & 0x55555555u, lo = w & 0x55555555u;
       dw[i] = (hi & ~lo) | ((hi & lo) << 1);
     }
-    const int ci = T - blk * 16 - 16 + (lane & 15);
-    const int chunk = (ci >= 0 && ci < n) ? (int)ref[ci] : NOMATCH;
-    const int bchunk = (bin && ci + 1 >= 0 && ci + 1 <= n) ? bin[ci + 1] : NEGBIG;   // lane 63's column = ci + 1
+    // next block's code words / letters / boundary values are in flight while this block computes
+    if (blk > 0) {
+#pragma unroll
+      for (int i = 0; i < K; ++i) wn[i] = ld_scratch(&stack[((size_t)(blk - 1) * K + i) * WAVE + lane]);
+    }
+    const int chunk_n = ld_chunk(blk - 1), bchunk_n = ld_bnd(blk - 1);
 #pragma unroll
     for (int f = 15; f >= 0; --f) {
       const int newc = __builtin_amdgcn_readlane(chunk, 15 - f);
@@ -227,6 +244,8 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
       const int col = T - 63 - 16 * blk - 15 + lane;
       if (lane < 16 && col >= 0 && col <= n) bout[col] = outv;
     }
+    chunk = chunk_n;
+    bchunk = bchunk_n;
   }
   int hp = 0;
 #pragma unroll
@@ -267,10 +286,11 @@ __device__ __noinline__ void lr_pass_dir(const uint8_t* rowstr, const uint8_t* c
   int b = NOMATCH;
   int c = -lane;
   int outv = 0;
+  auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < ncols) ? (int)colstr[ci] : NOMATCH; };
+  auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= ncols) ? bin[ci + 1] : NEGBIG; };
+  int chunk = ld_chunk(0), bchunk = ld_bnd(0);
   for (int blk = 0; blk < nblk; ++blk) {
-    const int ci = blk * 16 + (lane & 15);
-    const int chunk = (ci < ncols) ? (int)colstr[ci] : NOMATCH;
-    const int bchunk = (bin && ci + 1 <= ncols) ? bin[ci + 1] : NEGBIG;
+    const int chunk_n = ld_chunk(blk + 1), bchunk_n = ld_bnd(blk + 1);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
       const int newc = __builtin_amdgcn_readlane(chunk, f);
@@ -304,6 +324,8 @@ __device__ __noinline__ void lr_pass_dir(const uint8_t* rowstr, const uint8_t* c
       const int col = blk * 16 + lane - 62;
       if (lane < 16 && col >= 0 && col <= ncols) bout[col] = outv;
     }
+    chunk = chunk_n;
+    bchunk = bchunk_n;
   }
 }
 

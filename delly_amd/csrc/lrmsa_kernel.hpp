@@ -113,10 +113,12 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
   int b = NOMATCH;
   int c = -lane;
   int outv = 0;
+  // block blk+1's letters / boundary values are loaded while block blk computes
+  auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < qlen) ? (int)qp[ci * qstep] : NOMATCH; };
+  auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= qlen) ? bin[ci + 1] : POS; };
+  int chunk = ld_chunk(0), bchunk = ld_bnd(0);
   for (int blk = 0; blk < nblk; ++blk) {
-    const int ci = blk * 16 + (lane & 15);
-    const int chunk = (ci < qlen) ? (int)qp[ci * qstep] : NOMATCH;
-    const int bchunk = (bin && ci + 1 <= qlen) ? bin[ci + 1] : POS;
+    const int chunk_n = ld_chunk(blk + 1), bchunk_n = ld_bnd(blk + 1);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
       const int newc = __builtin_amdgcn_readlane(chunk, f);
@@ -160,6 +162,8 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
       const int col = blk * 16 + lane - 62;
       if (lane < 16 && col >= 1 && col <= qlen) bout[col] = outv;
     }
+    chunk = chunk_n;
+    bchunk = bchunk_n;
   }
 }
 

@@ -27,10 +27,21 @@ __device__ __forceinline__ int myers_code(int c) {
   return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1;
 }
 
+// equality mask of a 32-row word for a text byte outside ACGTN (rare; kept out of line so that
+// the hot loop stays small enough for the instruction cache)
+__device__ __noinline__ uint32_t myers_eq_slow(const uint8_t* pattern, int pn, int lo, int b) {
+  uint32_t Eq = 0;
+  for (int q = 0; q < 32; ++q) {
+    const int r = lo + q;
+    if (r < pn && (int)pattern[r] == b) Eq |= 1u << q;
+  }
+  return Eq;
+}
+
 // Returns the NW edit distance of pattern[0..pn) vs text[0..tn) (both > 0, pn <= 64*32*NWORDS).
 // pattern / text: any address space (LDS or global); exact byte comparison.
 template <int NWORDS>
-__device__ __forceinline__ int myers_nw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
+__device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
   MyersWord W[NWORDS];
   uint32_t Pv[NWORDS], Mv[NWORDS];
   const int row0 = lane * 32 * NWORDS;   // zero-based first row of this lane
@@ -62,8 +73,8 @@ __device__ __forceinline__ int myers_nw_distance(const uint8_t* pattern, int pn,
   for (int blk = 0; blk < nblk; ++blk) {
     const int ci = blk * 16 + (lane & 15);
     const int chunk = (ci < tn) ? (int)text[ci] : NOMATCH;
-#pragma unroll
-    for (int f = 0; f < 16; ++f) {
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {   // rolled: ~60 instructions per step, the body must stay I-cache resident
       const int newc = __builtin_amdgcn_readlane(chunk, f);
       b = dpp_from_prev(b, newc);
       const int hin0 = dpp_from_prev(hcarry, 1);
@@ -77,11 +88,7 @@ __device__ __forceinline__ int myers_nw_distance(const uint8_t* pattern, int pn,
           if (code >= 0) {
             Eq = code == 0 ? W[w].eq[0] : code == 1 ? W[w].eq[1] : code == 2 ? W[w].eq[2] : code == 3 ? W[w].eq[3] : W[w].eq[4];
           } else {   // foreign byte: exact comparison against the pattern rows of this word
-            Eq = 0;
-            for (int q = 0; q < 32; ++q) {
-              const int r = row0 + w * 32 + q;
-              if (r < pn && (int)pattern[r] == b) Eq |= 1u << q;
-            }
+            Eq = myers_eq_slow(pattern, pn, row0 + w * 32, b);
           }
           // edlib.cpp:390-470 (Hyyro's block step), 32-bit words
           const uint32_t hinNeg = (hin < 0) ? 1u : 0u;
