@@ -96,9 +96,10 @@ def side_measurements(ctx, synth, device=0, steps=3):
     out = {}
     from delly_amd import abi, refine
     for name, n, kw in (("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
-                        ("ins_svt4", 5000, dict(mode="ins")), ("lr_c4", 256, dict(mode="lr", sub_rate=0.01))):
+                        ("ins_svt4", 5000, dict(mode="ins")), ("lr_c4_align_consensus", 2048, dict(mode="lr", sub_rate=0.01)),
+                        ("lr_c4_msaedlib_n15", 768, dict(mode="lr", n_reads=15, sub_rate=0.06))):
         b = synth.make_batch(n, **kw)
-        if name == "lr_c4":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
+        if name == "lr_c4_align_consensus":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
             ctx = refine.Context(params=abi.params_lr(realign=True), device=device)
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
