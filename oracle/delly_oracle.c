@@ -1433,6 +1433,311 @@ int dor_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const
 }
 
 /* ------------------------------------------------------------------------ */
+/* msaWfa  src/assemble.h:547-726 (long-read consensus of insertion junctions) */
+
+#define DOR_KMER 7                     /* DELLY_KMER, src/tags.h:19 */
+#define DOR_KTAB 65536                 /* std::pow(4, DELLY_KMER + 1) */
+#define DOR_DUP 0xffffffffu            /* DELLY_DUPLICATE, src/tags.h:15 */
+
+static uint32_t char_to_int(char c) { /* assemble.h:475-498 */
+  switch (c) {
+    case 'A': case 'B': return 0;
+    case 'C': case 'D': return 1;
+    case 'G': case 'E': return 2;
+    case 'T': case 'F': return 3;
+  }
+  return 0;
+}
+
+/* fillKmerTable  assemble.h:501-520 (uint32 arithmetic as written) */
+static void fill_kmer_table(const char* s, uint32_t len, uint32_t* kmerpos) {
+  memset(kmerpos, 0, sizeof(uint32_t) * DOR_KTAB);
+  uint32_t hash = 0;
+  for (uint32_t ki = 0; ki < len && ki < DOR_KMER; ++ki) { hash *= 4; hash += char_to_int(s[ki]); }
+  for (uint32_t ki = DOR_KMER; ki < len; ++ki) {
+    if (kmerpos[hash]) kmerpos[hash] = DOR_DUP;
+    else kmerpos[hash] = ki - DOR_KMER + 1;
+    hash -= char_to_int(s[ki - DOR_KMER]) * 4 * 4 * 4 * 4 * 4 * 4;
+    hash *= 4;
+    hash += char_to_int(s[ki]);
+  }
+  if (kmerpos[hash]) kmerpos[hash] = DOR_DUP;
+  else kmerpos[hash] = len - DOR_KMER + 1;
+}
+
+/* bestDiagonal  assemble.h:522-545 */
+static int32_t best_diagonal(const uint32_t* hitI, const uint32_t* hitJ, uint32_t lenI, uint32_t lenJ) {
+  uint32_t dn = lenI + lenJ;
+  uint32_t* diag = (uint32_t*)calloc((size_t)dn + 1, sizeof(uint32_t));
+  for (uint32_t k = 0; k < DOR_KTAB; ++k)
+    if (hitI[k] && hitJ[k] && hitI[k] != DOR_DUP && hitJ[k] != DOR_DUP) ++diag[lenJ + hitI[k] - hitJ[k]];
+  uint32_t window = 20, windowVal = 0;
+  for (uint32_t d = 0; d < dn && d < window; ++d) windowVal += diag[d];
+  uint32_t bestDiag = window / 2, bestWindowVal = windowVal;
+  for (uint32_t d = window; d < dn; ++d) {
+    windowVal -= diag[d - window];
+    windowVal += diag[d];
+    if (windowVal > bestWindowVal) { bestWindowVal = windowVal; bestDiag = d - window / 2; }
+  }
+  free(diag);
+  return (int)bestDiag - (int)lenJ;
+}
+
+/* buildSuperstring  assemble.h:90-133 */
+static char* build_superstring(const char* seqI, const char* seqJ, const ed_res* cg, uint32_t preI, uint32_t postI,
+                               uint32_t preJ, uint32_t postJ, size_t cap, int* outn) {
+  char* out = (char*)malloc(cap + 1);
+  int n = 0;
+  int32_t iIdx = 0, jIdx = 0;
+  int firstSeq = 0;
+  if (preI > preJ) {
+    firstSeq = 1;
+    for (uint32_t j = 0; j < preI; ++j) out[n++] = seqI[iIdx++];
+    for (uint32_t j = 0; j < preJ; ++j) ++jIdx;
+  } else {
+    for (uint32_t j = 0; j < preI; ++j) ++iIdx;
+    for (uint32_t j = 0; j < preJ; ++j) out[n++] = seqJ[jIdx++];
+  }
+  int32_t bp = cg->aln_len / 2;
+  for (int32_t j = 0; j < cg->aln_len; ++j) {
+    if (bp == j) firstSeq = !firstSeq;
+    if (cg->aln[j] == OP_DELETE) { if (!firstSeq) out[n++] = seqJ[jIdx]; ++jIdx; }
+    else if (cg->aln[j] == OP_INSERT) { if (firstSeq) out[n++] = seqI[iIdx]; ++iIdx; }
+    else { out[n++] = firstSeq ? seqI[iIdx] : seqJ[jIdx]; ++iIdx; ++jIdx; }
+  }
+  if (postI > postJ) { for (uint32_t j = 0; j < postI; ++j) out[n++] = seqI[iIdx++]; }
+  else { for (uint32_t j = 0; j < postJ; ++j) out[n++] = seqJ[jIdx++]; }
+  *outn = n;
+  return out;
+}
+
+/* consensusWfa  assemble.h:262-336: like consensusEdlib but only rows that span the column vote */
+static void consensus_wfa(const amat* al, char* cons) {
+  uint32_t* rs = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)al->rows);
+  uint32_t* re = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)al->rows);
+  for (int i = 0; i < al->rows; ++i) {
+    rs[i] = (uint32_t)al->cols; re[i] = 0;
+    for (int j = 0; j < al->cols; ++j)
+      if (AT(*al, i, j) != '-') { if ((uint32_t)j < rs[i]) rs[i] = (uint32_t)j; if ((uint32_t)j > re[i]) re[i] = (uint32_t)j; }
+  }
+  for (int j = 0; j < al->cols; ++j) {
+    int count[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < al->rows; ++i) {
+      if ((uint32_t)j >= rs[i] && (uint32_t)j <= re[i]) {
+        char ch = AT(*al, i, j);
+        if (ch == 'A' || ch == 'a') ++count[0];
+        else if (ch == 'C' || ch == 'c') ++count[1];
+        else if (ch == 'G' || ch == 'g') ++count[2];
+        else if (ch == 'T' || ch == 't') ++count[3];
+        else ++count[4];
+      }
+    }
+    uint32_t maxIdx = 0, sndIdx = 1;
+    if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
+    for (uint32_t i = 2; i < 5; ++i) {
+      if (count[i] > count[maxIdx]) { sndIdx = maxIdx; maxIdx = i; }
+      else if (count[i] > count[sndIdx]) sndIdx = i;
+    }
+    if (2 * count[sndIdx] < count[maxIdx]) cons[j] = maxIdx < 4 ? "ACGT"[maxIdx] : '-';
+    else {
+      uint32_t k1 = maxIdx, k2 = sndIdx;
+      if (k1 > k2) { k1 = sndIdx; k2 = maxIdx; }
+      static const char code[5][5] = {{'-', 'M', 'R', 'W', 'B'}, {'-', '-', 'S', 'Y', 'D'}, {'-', '-', '-', 'K', 'E'},
+                                      {'-', '-', '-', '-', 'F'}, {'-', '-', '-', '-', '-'}};
+      cons[j] = code[k1][k2];
+    }
+  }
+  free(rs); free(re);
+}
+
+/* convertAlignment(query, align, EDLIB_MODE_HW, cigar)  assemble.h:24-88 */
+static amat convert_alignment_hw(const char* query, const amat* in, const ed_res* cg) {
+  int32_t tIdx = cg->end_loc, qIdx = -1;
+  uint32_t missingEnd = 0, missingStart = 0;
+  if (tIdx < in->cols) missingEnd = (uint32_t)(in->cols - tIdx - 1);
+  for (int i = 0; i < cg->aln_len; ++i) if (cg->aln[i] != OP_INSERT) --tIdx;
+  if (tIdx >= 0) missingStart = (uint32_t)tIdx + 1;
+  const int rows = in->rows;
+  amat out = amat_new(rows + 1, (int)(missingStart + (uint32_t)cg->aln_len + missingEnd));
+  for (uint32_t j = 0; j < missingStart; ++j) {
+    for (int r = 0; r < rows; ++r) AT(out, r, j) = AT(*in, r, j);
+    AT(out, rows, j) = '-';
+  }
+  for (int j = 0; j < cg->aln_len; ++j) {
+    if (cg->aln[j] == OP_INSERT) { for (int r = 0; r < rows; ++r) AT(out, r, j + missingStart) = '-'; }
+    else { ++tIdx; for (int r = 0; r < rows; ++r) AT(out, r, j + missingStart) = AT(*in, r, tIdx); }
+  }
+  for (int j = 0; j < cg->aln_len; ++j) AT(out, rows, j + missingStart) = (cg->aln[j] == OP_DELETE) ? '-' : query[++qIdx];
+  for (uint32_t j = (uint32_t)cg->aln_len + missingStart; j < (uint32_t)cg->aln_len + missingStart + missingEnd; ++j) {
+    ++tIdx;
+    for (int r = 0; r < rows; ++r) AT(out, r, j) = AT(*in, r, tIdx);
+    AT(out, rows, j) = '-';
+  }
+  return out;
+}
+
+/* _trimConsensus  assemble.h:338-365; cs is modified in place, returns the new length */
+static int trim_consensus(const char* prefix, int pn, const char* suffix, int sn, char* cs, int L) {
+  char* prev = (char*)malloc((size_t)pn + 1);
+  memcpy(prev, prefix, (size_t)pn);
+  dor_reverse_complement(prev, pn);
+  ed_res f, r;
+  ed_align(prefix, pn, cs, L, ED_HW, 0, &f);
+  ed_align(prev, pn, cs, L, ED_HW, 0, &r);
+  free(prev);
+  if (f.ed > r.ed) dor_reverse_complement(cs, L);
+  ed_res cp, csuf;
+  ed_align(prefix, pn, cs, L, ED_HW, 2, &cp);
+  uint32_t csStart = infix_start(&cp);
+  free(cp.aln);
+  ed_align(suffix, sn, cs, L, ED_HW, 2, &csuf);
+  uint32_t csEnd = (uint32_t)csuf.end_loc;
+  free(csuf.aln);
+  if (csStart < csEnd && csEnd < (uint32_t)L) {
+    memmove(cs, cs + csStart, (size_t)(csEnd - csStart));
+    L = (int)(csEnd - csStart);
+  }
+  return L;
+}
+
+static int msa_wfa_core(const dellyhip_params* p, int n, const char* blob, const uint64_t* off, const char* prefix, int pn,
+                        const char* suffix, int sn, char** cs_out, int* cs_len) {
+  const unsigned char* eq = iupac_equalities();
+  uint32_t* hitI = (uint32_t*)malloc(sizeof(uint32_t) * DOR_KTAB);
+  uint32_t* hitJ = (uint32_t*)malloc(sizeof(uint32_t) * DOR_KTAB);
+  int32_t* edit = (int32_t*)calloc((size_t)n * n, sizeof(int32_t));
+#define RD(k) (blob + off[k])
+#define RL(k) ((uint32_t)(off[(k) + 1] - off[k]))
+  for (int i = 0; i < n; ++i) {
+    uint32_t lenI = RL(i);
+    fill_kmer_table(RD(i), lenI, hitI);
+    for (int j = i + 1; j < n; ++j) {
+      uint32_t lenJ = RL(j);
+      fill_kmer_table(RD(j), lenJ, hitJ);
+      int32_t bd = best_diagonal(hitI, hitJ, lenI, lenJ);
+      const char *sI, *sJ;
+      uint32_t seqlen;
+      if (bd >= 0) { seqlen = (lenI - (uint32_t)bd < lenJ) ? lenI - (uint32_t)bd : lenJ; sI = RD(i) + bd; sJ = RD(j); }
+      else { seqlen = (lenJ + (uint32_t)bd < lenI) ? lenJ + (uint32_t)bd : lenI; sI = RD(i); sJ = RD(j) + (-bd); }
+      /* std::string::substr clamps the length to what is left (and throws past the end: not mirrored) */
+      uint32_t lI = seqlen, lJ = seqlen;
+      { uint32_t oI = (bd >= 0) ? (uint32_t)bd : 0, oJ = (bd >= 0) ? 0 : (uint32_t)(-bd);
+        if (lI > lenI - oI) lI = lenI - oI;
+        if (lJ > lenJ - oJ) lJ = lenJ - oJ; }
+      ed_res a;
+      ed_align(sI, (int)lI, sJ, (int)lJ, ED_NW, 0, &a);
+      int32_t mx = (int32_t)(lI > lJ ? lI : lJ);
+      int32_t score = (a.ed * 1000) / mx;
+      edit[i * n + j] = edit[j * n + i] = score;
+    }
+  }
+  uint32_t bestIdx = 0;
+  int32_t bestVal = (int32_t)RL(0);
+  int* dist = (int*)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) dist[j] = edit[i * n + j];
+    qsort(dist, (size_t)n, sizeof(int), cmp_int);
+    if (dist[n / 2] < bestVal) { bestVal = dist[n / 2]; bestIdx = (uint32_t)i; }
+  }
+  free(dist);
+  int32_t* qs = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n);
+  int nq = 1;
+  qs[0] = 0; qs[1] = (int32_t)bestIdx;
+  for (int j = 0; j < n; ++j)
+    if ((uint32_t)j != bestIdx) { qs[2 * nq] = edit[bestIdx * n + j]; qs[2 * nq + 1] = j; ++nq; }
+  qsort(qs, (size_t)nq, 2 * sizeof(int32_t), cmp_pair);
+  uint32_t lastIdx = (uint32_t)(0.8 * nq);
+  if (lastIdx < 3) lastIdx = 3;
+  int nsel = 0;
+  int* sel = (int*)malloc(sizeof(int) * (size_t)n);
+  for (uint32_t i = 0; i < (uint32_t)nq && i < lastIdx; ++i) sel[nsel++] = qs[2 * i + 1];
+  free(qs);
+  free(edit);
+  /* superstring (assemble.h:598-660) */
+  int sl = (int)RL(sel[0]);
+  char* super = (char*)malloc((size_t)sl + 1);
+  memcpy(super, RD(sel[0]), (size_t)sl);
+  for (int i = 1; i < nsel; ++i) {
+    uint32_t lenI = (uint32_t)sl;
+    fill_kmer_table(super, lenI, hitI);
+    uint32_t lenJ = RL(sel[i]);
+    fill_kmer_table(RD(sel[i]), lenJ, hitJ);
+    int32_t bd = best_diagonal(hitI, hitJ, lenI, lenJ);
+    uint32_t preI = 0, postI = 0, preJ = 0, postJ = 0, seqlen = 0;
+    if (bd >= 0) {
+      seqlen = (lenI - (uint32_t)bd < lenJ) ? lenI - (uint32_t)bd : lenJ;
+      preI = (uint32_t)bd; postI = lenI - ((uint32_t)bd + seqlen); preJ = 0; postJ = lenJ - seqlen;
+    } else {
+      seqlen = (lenJ + (uint32_t)bd < lenI) ? lenJ + (uint32_t)bd : lenI;
+      preI = 0; postI = lenI - seqlen; preJ = (uint32_t)(-bd); postJ = lenJ - ((uint32_t)(-bd) + seqlen);
+    }
+    if (preI > preJ && postI > postJ) {
+      /* nested */
+    } else if (preJ > preI && postJ > postI) {
+      free(super);
+      sl = (int)lenJ;
+      super = (char*)malloc((size_t)sl + 1);
+      memcpy(super, RD(sel[i]), (size_t)sl);
+    } else {
+      const char* sI = (bd >= 0) ? super + bd : super;
+      const char* sJ = (bd >= 0) ? RD(sel[i]) : RD(sel[i]) + (-bd);
+      ed_res cg;
+      ed_align(sI, (int)seqlen, sJ, (int)seqlen, ED_NW, 2, &cg);
+      int on = 0;
+      char* outStr = build_superstring(super, RD(sel[i]), &cg, preI, postI, preJ, postJ, (size_t)lenI + lenJ + 8, &on);
+      free(cg.aln);
+      free(super);
+      super = outStr;
+      sl = on;
+    }
+  }
+  free(hitI);
+  free(hitJ);
+  /* progressive HW alignment of every selected read to the running consensus (:662-686) */
+  amat al = amat_new(1, sl);
+  memcpy(al.d, super, (size_t)sl);
+  free(super);
+  for (int i = 0; i < nsel; ++i) {
+    char* astr = (char*)malloc((size_t)al.cols + 1);
+    consensus_wfa(&al, astr);
+    ed_res c;
+    ed_align_eq(RD(sel[i]), (int)RL(sel[i]), astr, al.cols, ED_HW, 2, eq, &c);
+    amat nx = convert_alignment_hw(RD(sel[i]), &al, &c);
+    free(c.aln);
+    free(astr);
+    amat_free(&al);
+    al = nx;
+  }
+  char* cs = (char*)malloc((size_t)al.cols + 1);
+  int L = consensus_core(p, &al, cs);
+  amat_free(&al);
+  if (pn > 0 && sn > 0) L = trim_consensus(prefix, pn, suffix, sn, cs, L);
+  else {
+    int32_t trim = (int32_t)(0.05 * L);
+    if (trim > 50) trim = 50;
+    int32_t len = L - 2 * trim;
+    if (len > 100) { memmove(cs, cs + trim, (size_t)len); L = len; }
+  }
+  free(sel);
+#undef RD
+#undef RL
+  *cs_out = cs;
+  *cs_len = L;
+  return nsel;
+}
+
+int dor_msa_wfa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, const char* prefix, int pn,
+                const char* suffix, int sn, char* cs, int cap, int* cs_len) {
+  char* c = NULL;
+  int L = 0;
+  int rows = msa_wfa_core(p, n_reads, blob, off, prefix, pn, suffix, sn, &c, &L);
+  *cs_len = L;
+  if (L <= cap) memcpy(cs, c, (size_t)L);
+  free(c);
+  return rows;
+}
+
+/* ------------------------------------------------------------------------ */
 /* batch driver: loop body of src/shortpe.h:183-197 (msa + alignConsensus)    */
 
 typedef struct {
@@ -1473,8 +1778,21 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   int m = 0;
   if (b->with_msa) {
     if (b->with_msa != 2 && J->n_seq <= 1) return; /* shortpe.h:166-171 */
-    if (b->with_msa == 2) { /* long-read loop body: src/assemble.h:839 */
+    if (b->with_msa == 2) { /* long-read loop body: src/assemble.h:836-861 (the small-inversion
+                             * substring of :842-854 is not mirrored) */
       if (J->n_seq < 1) return;
+      if (J->svt == 4) {
+        const char* seq = b->chr_seq[J->chr];
+        const int32_t seqlen = (int32_t)(uint32_t)b->chr_len[J->chr];
+        const int32_t p0 = imax(J->sv_start - c->min_cons_window, 0), p1 = J->sv_start;
+        const int32_t s0 = J->sv_start, s1 = imin(seqlen, J->sv_start + c->min_cons_window);
+        sbuf pre, suf;
+        sb_init(&pre); sb_init(&suf);
+        sb_upper(&pre, seq, p0, p1);
+        sb_upper(&suf, seq, s0, s1);
+        R->sr_support = msa_wfa_core(c, J->n_seq, b->blob, b->off + J->seq_first, pre.d, (int)pre.n, suf.d, (int)suf.n, &cons, &m);
+        free(pre.d); free(suf.d);
+      } else
       R->sr_support = msa_edlib_core(c, J->n_seq, b->blob, b->off + J->seq_first, &cons, &m);
     } else
     R->sr_support = msa_core(c, J->n_seq, b->blob, b->off + J->seq_first, &cons, &m);
@@ -1512,7 +1830,7 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   R->ref_len = n;
 
   /* _alignConsensus split.h:560-642; realign (split.h:564-572) = bit 0 of params.reserved */
-  if (c->reserved & 1) {
+  if ((c->reserved & 1) && !(b->with_msa == 2 && J->svt == 4)) { /* assemble.h:859: insertions pass realign = false */
     char* revc = (char*)malloc((size_t)m + 1);
     memcpy(revc, cons, (size_t)m);
     dor_reverse_complement(revc, m);

@@ -13,7 +13,7 @@
  * edlib (vendored by the reference, src/edlib.cpp) is restated as the exact
  * unit-cost DP it evaluates, including additional equalities and the
  * Hirschberg split of obtainAlignment; msaEdlib is restated on top of it.
- * msaWfa (long-read insertions) is NOT restated.
+ * msaWfa (long-read insertions) is restated too (dor_msa_wfa).
  */
 #ifndef DELLY_ORACLE_H
 #define DELLY_ORACLE_H
@@ -49,6 +49,9 @@ int dor_msa(const dellyhip_params* p, int n_reads, const char* blob, const uint6
 /* msaEdlib(c, sps, cs)  src/assemble.h:383-473 */
 int dor_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, char* cs,
                   int cap, int* cs_len);
+/* msaWfa(c, sps, cs, prefix, suffix)  src/assemble.h:547-726 */
+int dor_msa_wfa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, const char* prefix, int pn,
+                const char* suffix, int sn, char* cs, int cap, int* cs_len);
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

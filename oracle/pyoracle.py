@@ -181,6 +181,17 @@ class Oracle:
                                     cap, C.byref(ln))
         return rows, cs[:ln.value].tobytes()
 
+    def msa_wfa(self, reads, prefix=b"", suffix=b""):
+        """msaWfa(c, sps, cs, prefix, suffix) -> (rows, consensus)"""
+        blob, off = self._pack(reads)
+        cap = 2 * int(off[-1]) + 8
+        cs = np.zeros(cap, dtype=np.uint8)
+        ln = C.c_int(0)
+        pre, suf = _u8(prefix), _u8(suffix)
+        rows = self._f("msa_wfa")(C.byref(self.params), len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)),
+                                  _p(pre), pre.size, _p(suf), suf.size, _p(cs), cap, C.byref(ln))
+        return rows, cs[:ln.value].tobytes()
+
     def unordered_set_order(self, reads):
         assert self.kind == "reference"
         blob, off = self._pack(reads)

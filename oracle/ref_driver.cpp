@@ -136,7 +136,14 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
     std::vector<std::string> sps;  // iteration order == the host's set order
     for (int32_t k = 0; k < J.n_seq; ++k)
       sps.push_back(std::string(blob + off[J.seq_first + k], blob + off[J.seq_first + k + 1]));
-    if (with_msa == 2) R.sr_support = msaEdlib(c, sps, sv.consensus);  // src/assemble.h:839
+    if (with_msa == 2 && sv.svt == 4) {  // src/assemble.h:855-857
+      const char* sq = chr_seq[J.chr];
+      int32_t seqlen = (int32_t)hdr->target_len[J.chr];
+      std::string prefix = boost::to_upper_copy(std::string(sq + std::max(sv.svStart - (int32_t)c.minConsWindow, 0), sq + sv.svStart));
+      std::string suffix = boost::to_upper_copy(std::string(sq + sv.svStart, sq + std::min(seqlen, sv.svStart + c.minConsWindow)));
+      R.sr_support = msaWfa(c, sps, sv.consensus, prefix, suffix);
+      realign = false;                   // :859
+    } else if (with_msa == 2) R.sr_support = msaEdlib(c, sps, sv.consensus);  // src/assemble.h:839
     else R.sr_support = msa(c, sps, sv.consensus);  // src/shortpe.h:185
   } else {
     sv.consensus = std::string(blob + off[J.seq_first], blob + off[J.seq_first + 1]);
@@ -344,6 +351,20 @@ int dref_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, cons
   for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
   std::string s;
   int rows = msaEdlib(c, sps, s);
+  *cs_len = (int)s.size();
+  if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
+  return rows;
+}
+
+// msaWfa(c, sps, cs, prefix, suffix)  src/assemble.h:547-726; returns rows, consensus in cs
+int dref_msa_wfa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, const char* prefix, int pn,
+                 const char* suffix, int sn, char* cs, int cap, int* cs_len) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  std::vector<std::string> sps;
+  for (int k = 0; k < n_reads; ++k) sps.push_back(std::string(blob + off[k], blob + off[k + 1]));
+  std::string s;
+  int rows = msaWfa(c, sps, s, std::string(prefix, prefix + pn), std::string(suffix, suffix + sn));
   *cs_len = (int)s.size();
   if ((int)s.size() <= cap) std::memcpy(cs, s.data(), s.size());
   return rows;

@@ -142,10 +142,24 @@ def long_read_vectors(ref):
         reads = [ont(base[int(rng.integers(0, 100)):L + 100 + int(rng.integers(0, 100))], 0.06 if it % 2 else 0.02) for _ in range(n)]
         rows, cs = ref.msa_edlib(reads)
         sets.append(np.array(reads, dtype=object)); rows_l.append(rows); cs_l.append(cs)
+    # msaWfa (src/assemble.h:547-726): insertion haplotypes, with and without reference anchors
+    wsets, wpre, wsuf, wrows, wcs = [], [], [], [], []
+    for it in range(5):
+        F = int(rng.integers(300, 1200))
+        left, right = random_seq(rng, F + 600), random_seq(rng, F + 600)
+        hap = left + random_seq(rng, int(rng.integers(100, 700))) + right
+        n = int(rng.integers(3, 10))
+        reads = [ont(hap[600 - int(rng.integers(0, min(F, 500))):len(hap) - 600 + int(rng.integers(0, min(F, 500)))],
+                     0.06 if it % 2 else 0.02) for _ in range(n)]
+        pre, suf = (left[-300:], right[:300]) if it % 2 == 0 else (b"", b"")
+        rows, cs = ref.msa_wfa(reads, pre, suf)
+        wsets.append(np.array(reads, dtype=object)); wpre.append(pre); wsuf.append(suf); wrows.append(rows); wcs.append(cs)
     ref.params = abi.params_sr()
-    d.update(msa_sets=np.array(sets, dtype=object), msa_rows=np.array(rows_l, dtype=np.int32), msa_cs=np.array(cs_l, dtype=object))
+    d.update(msa_sets=np.array(sets, dtype=object), msa_rows=np.array(rows_l, dtype=np.int32), msa_cs=np.array(cs_l, dtype=object),
+             wfa_sets=np.array(wsets, dtype=object), wfa_pre=np.array(wpre, dtype=object), wfa_suf=np.array(wsuf, dtype=object),
+             wfa_rows=np.array(wrows, dtype=np.int32), wfa_cs=np.array(wcs, dtype=object))
     np.savez_compressed(os.path.join(HERE, "longread.npz"), **d)
-    print("longread ok: %d alignments, %d msaEdlib sets" % (len(q_l), len(sets)))
+    print("longread ok: %d alignments, %d msaEdlib sets, %d msaWfa sets" % (len(q_l), len(sets), len(wsets)))
 
 
 def main():

@@ -76,6 +76,8 @@ def test_port_reproduces_golden_long_read_vectors(port):
     try:
         for reads, rows, cs in zip(g["msa_sets"], g["msa_rows"], g["msa_cs"]):
             assert port.msa_edlib(list(reads)) == (int(rows), cs)
+        for reads, pre, suf, rows, cs in zip(g["wfa_sets"], g["wfa_pre"], g["wfa_suf"], g["wfa_rows"], g["wfa_cs"]):
+            assert port.msa_wfa(list(reads), pre, suf) == (int(rows), cs)
     finally:
         port.params = old
 
@@ -125,3 +127,32 @@ def test_edge_cases(port, reference):
     pr, pb = port.refine_batch(b)
     compare(pr, pb, rr, rb)
     assert int(rr["sr_support"].sum()) == 0
+
+
+def test_port_long_read_insertion_loop_vs_reference(port, reference):
+    """src/assemble.h:855-860: msaWfa with reference anchors, then alignConsensus(realign=false) whose
+    splitAlign runs edlib in its Hirschberg regime"""
+    rng = np.random.default_rng(1)
+    b0 = synth.make_batch(2, mode="lr", n_reads=5, sub_rate=0.04)
+    junc = b0.junctions.copy()
+    seqs = []
+    for k in range(2):
+        G = b0.chroms[0][k * synth.WINDOW_LR:(k + 1) * synth.WINDOW_LR]
+        s0 = 6000
+        hap = np.concatenate([G[s0 - 1200:s0], synth.ACGT[rng.integers(0, 4, 500)], G[s0:s0 + 1200]])
+        junc[k]["svt"] = 4
+        junc[k]["sv_start"] = k * synth.WINDOW_LR + s0
+        junc[k]["sv_end"] = k * synth.WINDOW_LR + s0 + 1
+        junc[k]["ins_len"] = 500
+        junc[k]["seq_first"] = len(seqs)
+        junc[k]["n_seq"] = 5
+        for _ in range(5):
+            seqs.append(synth._ont(rng, hap[int(rng.integers(0, 100)):hap.size - int(rng.integers(0, 100))], 0.04))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs])
+    b = synth.Batch(b0.chroms, junc, np.concatenate(seqs), off, 2, None)
+    pl = abi.params_lr(realign=True)
+    rr, rb = reference.refine_batch(b, params=pl)
+    pr, pb = port.refine_batch(b, params=pl)
+    compare(pr, pb, rr, rb, label="port-vs-reference LR INS")
+    assert int(rr["ok"].sum()) == 2
