@@ -18,6 +18,7 @@
 #include "ins_kernel.hpp"
 #include "lr_kernel.hpp"
 #include "lrmsa_kernel.hpp"
+#include "lrins_kernel.hpp"
 
 namespace {
 
@@ -103,6 +104,10 @@ struct dellyhip_batch {
   int lr_first = 0, lr_count = 0, lr_blocks = 0;
   dh::LrArgs lr{};
   DevBuf<uint8_t> lr_ws;
+  // long-read insertions (svt 4 beyond the short-read shapes)
+  int lri_first = 0, lri_count = 0, lri_blocks = 0;
+  dh::LrInsArgs lri{};
+  DevBuf<uint8_t> lri_ws;
   // long-read MSA (with_msa == 2: msaEdlib)
   DevBuf<int32_t> lm_edit, lm_pair_first;
   DevBuf<uint8_t> lm_ws;
@@ -235,6 +240,16 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     hipLaunchKernelGGL(dh::lr_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, lr);
     HIPCHK(hipGetLastError());
   }
+  if (b->lri_count > 0 && !direct) {
+    a.work_list = b->work.p + b->lri_first;
+    a.n_work = b->lri_count;
+    const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
+    const int grid = (b->lri_count + rounds - 1) / rounds;
+    dh::LrInsArgs li = b->lri;
+    li.realign = (c->params.reserved & 1) ? 1 : 0;
+    hipLaunchKernelGGL(dh::lr_ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, li);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -269,7 +284,12 @@ int host_window_len(const dellyhip_params& P, const dellyhip_junction& J, int m,
   }
 }
 
-bool is_lr_shape(const dellyhip_junction& J, int m, int n) { return J.svt != 4 && (m > dh::MMAX || n > dh::NMAX); }
+// long-read kernels: shapes beyond the short-read limits, and every junction when the orientation test
+// (realign, src/split.h:564-572) is requested -- only they implement it
+bool is_lr_shape(const dellyhip_params& P, const dellyhip_junction& J, int m, int n) {
+  (void)J;
+  return (P.reserved & 1) || m > dh::MMAX || n > dh::NMAX;
+}
 
 // per-block workspace of the long-read strip kernel for consensus <= lr_m, window <= lr_n
 int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, int lr_cnt) {
@@ -298,6 +318,32 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   return 0;
 }
 
+// per-block workspace of the long-read insertion kernel
+int setup_lri_workspace(dellyhip_ctx* c, dellyhip_batch* b, int m_max, int n_max, int cnt) {
+  dh::LrInsArgs& R = b->lri;
+  R.mcap = (m_max + 64) & ~63;
+  R.ncap = (n_max + 64) & ~63;
+  R.strip_words = dh::lr_strip_words(R.ncap);
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take(R.mcap);
+  R.off_rcons = take(R.mcap);
+  R.off_ref = take(R.ncap);
+  R.off_rref = take(R.ncap);
+  R.off_bnd = take(4ull * ((uint64_t)R.ncap + 128) * 4);
+  R.off_opsL = take((uint64_t)R.mcap + R.ncap + 64);
+  R.off_opsR = take((uint64_t)R.mcap + R.ncap + 64);
+  R.off_tmp = take((uint64_t)R.mcap + R.ncap + 64);
+  R.off_dist = take(2ull * ((uint64_t)R.ncap + 64) * 4);
+  R.off_dirs = take((uint64_t)(R.mcap / dh::LRS + 1) * R.strip_words * 4);
+  R.ws_stride = o;
+  b->lri_blocks = std::max(1, std::min(cnt, c->n_cu * 4));
+  int rc = b->lri_ws.reserve((size_t)R.ws_stride * b->lri_blocks);
+  if (rc) return rc;
+  R.ws = b->lri_ws.p;
+  return 0;
+}
+
 // K-bins junctions by consensus length and pairs them (two junctions per wavefront, packed
 // 16-bit DP).  Within a bin junctions are sorted by their approximate reference-window length
 // so that partners need (almost) the same number of DP steps.  bin_count[] counts PAIRS; a
@@ -307,18 +353,21 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
   std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
-  std::vector<int32_t> ins, lrv;
+  std::vector<int32_t> ins, lrv, lriv;
   const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
     int kk = (m + 1 + dh::WAVE - 1) / dh::WAVE;
     kk = std::max(1, std::min(kk, dh::KMAX));
     const dellyhip_junction& J = b->h_junc[i];
-    if (!direct && J.svt == 4) {  // splitAlign path: own kernel, one junction per wavefront
-      ins.push_back(i);
+    if (!direct && J.svt == 4) {  // splitAlign path: own kernels, one junction per wavefront
+      if (!b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
+          b->lri_blocks > 0)
+        lriv.push_back(i);
+      else ins.push_back(i);
       continue;
     }
-    if (!direct && !b->h_win_len.empty() && is_lr_shape(J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
+    if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
         b->h_win_len[i] <= dh::LR_NMAX && b->lr_blocks > 0) {  // strip kernel (else: E_LIMIT in the short-read kernels)
       lrv.push_back(i);
       continue;
@@ -345,6 +394,9 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->lr_first = (int)work.size();
   b->lr_count = (int)lrv.size();
   work.insert(work.end(), lrv.begin(), lrv.end());
+  b->lri_first = (int)work.size();
+  b->lri_count = (int)lriv.size();
+  work.insert(work.end(), lriv.begin(), lriv.end());
   int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 2));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -473,7 +525,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -497,17 +549,16 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->with_msa = with_msa;
   b->want_alignment = want_alignment;
   b->h_junc.assign(junc, junc + n);
-  int lr_m = 0, lr_n = 0, lr_cnt = 0;
+  int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
   if (!with_msa) {  // |svRefStr| per junction; long-read shapes get larger output slots and a workspace
     b->h_win_len.resize(n);
     for (int i = 0; i < n; ++i) {
       const int m = (int)(seq_off[junc[i].seq_first + 1] - seq_off[junc[i].seq_first]);
       const int w = host_window_len(c->params, junc[i], m, c->chr_len);
       b->h_win_len[i] = w;
-      if (is_lr_shape(junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
-        lr_m = std::max(lr_m, m);
-        lr_n = std::max(lr_n, w);
-        ++lr_cnt;
+      if (is_lr_shape(c->params, junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
+        if (junc[i].svt == 4) { lri_m = std::max(lri_m, m); lri_n = std::max(lri_n, w); ++lri_cnt; }
+        else { lr_m = std::max(lr_m, m); lr_n = std::max(lr_n, w); ++lr_cnt; }
       }
     }
   }
@@ -516,10 +567,11 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     b->out_allele_cap = (dh::LR_MMAX + dh::LR_NMAX + 8 + 15) & ~15;
     b->out_aln_cap = 2 * b->out_allele_cap;
   }
-  if (lr_cnt) {
-    b->out_cons_cap = std::max<int>(dh::OUT_CONS_CAP, (lr_m + 16) & ~15);
-    b->out_allele_cap = std::max<int>(dh::OUT_ALLELE_CAP, (lr_m + lr_n + 8 + 15) & ~15);
-    b->out_aln_cap = std::max<int>(dh::OUT_ALN_CAP, 2 * ((lr_m + lr_n + 8 + 15) & ~15));
+  if (lr_cnt || lri_cnt) {
+    const int mm = std::max(lr_m, lri_m), nn = std::max(lr_n, lri_n);
+    b->out_cons_cap = std::max<int>(dh::OUT_CONS_CAP, (mm + 16) & ~15);
+    b->out_allele_cap = std::max<int>(dh::OUT_ALLELE_CAP, (mm + nn + 8 + 15) & ~15);
+    b->out_aln_cap = std::max<int>(dh::OUT_ALN_CAP, 2 * ((mm + nn + 8 + 15) & ~15));
   }
   b->out_stride = (uint64_t)b->out_cons_cap + b->out_allele_cap + (want_alignment ? b->out_aln_cap : 0);
   b->out_stride = (b->out_stride + 15) & ~15ull;
@@ -560,6 +612,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
     }
     if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return bail(rc);
+    if (lri_cnt && (rc = setup_lri_workspace(c, b, lri_m, lri_n, lri_cnt))) return bail(rc);
     if ((rc = build_bins(b, c->params))) return bail(rc);
   } else {
     // consensus is produced on the device at out_blob + i*stride
@@ -656,7 +709,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
       const int m = b->h_cons_len[i];
       const int w = host_window_len(c->params, b->h_junc[i], m, c->chr_len);
       b->h_win_len[i] = w;
-      if (is_lr_shape(b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
+      if (is_lr_shape(c->params, b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
         lr_m = std::max(lr_m, m);
         lr_n = std::max(lr_n, w);
         ++lr_cnt;

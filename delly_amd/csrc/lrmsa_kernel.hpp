@@ -89,19 +89,31 @@ __device__ __forceinline__ uint32_t iupac_partners(int x) {
 // is row r = g - pad (rows < 0: +infinity dummies above row 0), t[r-1] = tp[(r-1)*tstep];
 // query letters qp[c*qstep].  E[r][0] = r, E[0][c] = c.  DIRS: edlib op code per cell
 // (preference INSERT > DELETE > diagonal) into `dirs`; bout: last slot of the strip per column.
-template <bool DIRS>
-__device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
-                                     int pad, const int32_t* bin, int32_t* bout, uint32_t* dirs, int lane) {
+struct LmKeys {
+  unsigned kf;   // min over rows r0..tlen of (E[r][qlen] << 13) | r           (first optimal end)
+  unsigned kl;   // min over rows r0..tlen of (E[r][qlen] << 13) | (8191 - r)  (last optimal end)
+};
+
+// mode bits of lm_pass
+constexpr int LM_HW = 1;    // E[r][0] = 0 (edlib HW: the query may start anywhere in the target)
+constexpr int LM_EQ = 2;    // extended-IUPAC additional equalities
+
+template <bool DIRS, bool LOC>
+__device__ __noinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
+                                       int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
+                                       int lane) {
   constexpr int K = LRK;
   constexpr int POS = 1 << 28;
-  int a[K], h[K];
+  const bool hw = (mode & LM_HW) != 0, useeq = (mode & LM_EQ) != 0;
+  int a[K], h[K], colq[K];
   uint32_t part[K], acc[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     const int r = q * LRS + lane * K + i - pad;
     a[i] = (r >= 1 && r <= tlen) ? (int)tp[(r - 1) * tstep] : NOMATCH;
-    h[i] = (r >= 0) ? r : POS;
-    const int ix = iupac_index(a[i]);
+    h[i] = (r >= 0) ? (hw ? 0 : r) : POS;
+    colq[i] = h[i];
+    const int ix = useeq ? iupac_index(a[i]) : -1;
     part[i] = iupac_partners(ix);
     acc[i] = 0;
   }
@@ -109,7 +121,7 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
   const int lastlane = lastrow / K;
   const int T = qlen + lastlane;
   const int nblk = (T + 15) >> 4;
-  int upPrev = bin ? (q * LRS - pad - 1) : POS;   // E[row above][0]
+  int upPrev = bin ? (hw ? 0 : (q * LRS - pad - 1)) : POS;   // E[row above][0]
   int b = NOMATCH;
   int c = -lane;
   int outv = 0;
@@ -127,7 +139,7 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
       const int recv = dpp_from_prev(h[K - 1], bnd);
       c += 1;
       if ((unsigned)(c - 1) < (unsigned)qlen) {
-        const int iy = iupac_index(b);
+        const int iy = useeq ? iupac_index(b) : -1;
         const uint32_t ybit = (iy >= 0) ? (1u << iy) : 0u;
         int diag = upPrev, up = recv;
 #pragma unroll
@@ -147,6 +159,10 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
           up = nv;
           h[i] = nv;
         }
+        if (LOC && c == qlen) {
+#pragma unroll
+          for (int i = 0; i < K; ++i) colq[i] = h[i];
+        }
       }
       upPrev = recv;
       if (bout) outv = writelane16(__builtin_amdgcn_readlane(h[K - 1], 63), f, outv);
@@ -165,18 +181,39 @@ __device__ __noinline__ void lm_pass(const uint8_t* tp, int tstep, int tlen, con
     chunk = chunk_n;
     bchunk = bchunk_n;
   }
+  LmKeys k;
+  k.kf = k.kl = 0xffffffffu;
+  if (LOC) {
+    unsigned kf = 0xffffffffu, kl = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int r = q * LRS + lane * K + i - pad;
+      if (r >= r0 && r <= tlen) {
+        kf = min(kf, ((unsigned)colq[i] << 13) | (unsigned)r);
+        kl = min(kl, ((unsigned)colq[i] << 13) | (unsigned)(8191 - r));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      kf = min(kf, (unsigned)__shfl_xor((int)kf, o));
+      kl = min(kl, (unsigned)__shfl_xor((int)kl, o));
+    }
+    k.kf = (unsigned)rfl((int)kf);
+    k.kl = (unsigned)rfl((int)kl);
+  }
+  return k;
 }
 
 // row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
 // (row_out[c] = distance(t, q[0..c))).  bndA / bndB: strip boundary scratch.
 __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
-                                            int32_t* bndA, int32_t* bndB, int32_t* row_out, int lane) {
+                                            int mode, int32_t* bndA, int32_t* bndB, int32_t* row_out, int lane) {
   const int Q = (tlen + 1 + LRS - 1) / LRS;
   const int pad = Q * LRS - (tlen + 1);   // row tlen = last slot of the last strip
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : row_out;
-    lm_pass<false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, bin, bout, nullptr, lane);
+    (void)lm_pass<false, false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode & LM_EQ, 0, bin, bout, nullptr, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -187,14 +224,14 @@ __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tl
 
 // plain (traceback-regime) NW path of t[0..tlen) vs q[0..qlen): direction strips + windowed
 // run-length traceback; ops appended to `ops` (forward order) at position pos; returns new pos
-__device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const uint8_t* qy, int qlen, int32_t* bndA,
+__device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const uint8_t* qy, int qlen, int mode, int32_t* bndA,
                                              int32_t* bndB, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                              uint8_t* ops, int pos, int lane) {
   const int Q = tlen / LRS + 1;
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
-    lm_pass<true>(t, 1, tlen, qy, 1, qlen, q, 0, bin, bout, dirs + (size_t)q * strip_words, lane);
+    (void)lm_pass<true, false>(t, 1, tlen, qy, 1, qlen, q, 0, mode & LM_EQ, 0, bin, bout, dirs + (size_t)q * strip_words, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -216,7 +253,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
 
 // edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment  (obtainAlignment,
 // edlib.cpp:1163-1389).  Returns the op count, ops[] in forward order; -1 on overflow.
-__device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int32_t* bnd,
+__device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int mode, int32_t* bnd,
                                           int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                           uint8_t* ops, int ops_cap, int lane) {
   // explicit stack of rectangles (t0, tlen, q0, qlen), processed left to right
@@ -242,13 +279,13 @@ __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const u
     const long long blocks = (ql + 63) / 64;
     const long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
     if (sz < 1024 * 1024) {
-      pos = lm_plain_path(target + t0, tl, query + q0, ql, bndA, bndB, dirs, strip_words, tmp, ops, pos, lane);
+      pos = lm_plain_path(target + t0, tl, query + q0, ql, mode, bndA, bndB, dirs, strip_words, tmp, ops, pos, lane);
       continue;
     }
     // Hirschberg step
     const int lw = tl / 2, rw = tl - lw;
-    lm_last_row(target + t0, 1, lw, query + q0, 1, ql, bndA, bndB, left, lane);                        // left[i]  : q[0..i) vs t[0..lw)
-    lm_last_row(target + t0 + tl - 1, -1, rw, query + q0 + ql - 1, -1, ql, bndA, bndB, right, lane);   // right[k] : last k letters of q vs t[lw..)
+    lm_last_row(target + t0, 1, lw, query + q0, 1, ql, mode, bndA, bndB, left, lane);                        // left[i]  : q[0..i) vs t[0..lw)
+    lm_last_row(target + t0 + tl - 1, -1, rw, query + q0 + ql - 1, -1, ql, mode, bndA, bndB, right, lane);   // right[k] : last k letters of q vs t[lw..)
     // optimum and the first query index that reaches it (ascending), then the two boundary cases
     int best = 1 << 30;
     for (int i = lane; i <= ql; i += WAVE) best = min(best, left[i] + right[ql - i]);
@@ -271,6 +308,82 @@ __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const u
     ++sp;
   }
   return pos;
+}
+
+// ---- edlibAlign HW / SHW on long strings (splitAlign of long-read insertions, msaWfa) ---------
+struct LmRes {
+  int ed, endLoc, startLoc, nops;   // ops (forward order) in the caller's buffer
+};
+
+__device__ __forceinline__ int lm_first_row(int qn) { return ((qn & 63) != 0) ? 0 : 1; }   // see ed_first_row (ins_kernel.hpp)
+
+// distance + end location over all target rows (strips); hw: LM_HW or 0 (SHW).  which = 0: first optimal end, 1: last
+__device__ __forceinline__ void lm_locate(const uint8_t* tp, int tstep, int tn, const uint8_t* qp, int qstep, int qn, int mode,
+                                          int32_t* bndA, int32_t* bndB, int lane, int& ed, int& first, int& last) {
+  const int Q = tn / LRS + 1;
+  const int r0 = lm_first_row(qn);
+  unsigned kf = 0xffffffffu, kl = 0xffffffffu;
+  for (int q = 0; q < Q; ++q) {
+    const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
+    int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
+    const LmKeys k = lm_pass<false, true>(tp, tstep, tn, qp, qstep, qn, q, 0, mode, r0, bin, bout, nullptr, lane);
+    kf = min(kf, k.kf);
+    kl = min(kl, k.kl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  ed = (int)(kf >> 13);
+  first = (int)(kf & 8191u);
+  last = 8191 - (int)(kl & 8191u);
+}
+
+__device__ __forceinline__ int lm_fill_inserts(uint8_t* ops, int qn, int lane) {
+  for (int k = lane; k < qn; k += WAVE) ops[k] = (uint8_t)ED_INSERT;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return qn;
+}
+
+// edlibAlign(Q, T, HW, {DISTANCE | LOC | PATH}) (edlib.cpp:139-300); tn >= 1, qn >= 1, tn <= 8190
+__device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* Qy, int qn, int mode, bool loc, bool path,
+                                       int32_t* bnd, int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                       uint8_t* ops, int ops_cap, int lane) {
+  LmRes o;
+  int first, last;
+  lm_locate(T, 1, tn, Qy, 1, qn, (mode & LM_EQ) | LM_HW, bnd, bnd + bnd_stride, lane, o.ed, first, last);
+  o.endLoc = first - 1;
+  o.startLoc = 0;
+  o.nops = 0;
+  if (!loc) return o;
+  if (o.endLoc == -1) {   // edlib.cpp:222-235
+    if (path) o.nops = lm_fill_inserts(ops, qn, lane);
+    return o;
+  }
+  int ed2, f2, l2;
+  lm_locate(T + o.endLoc, -1, o.endLoc + 1, Qy + (qn - 1), -1, qn, mode & LM_EQ, bnd, bnd + bnd_stride, lane, ed2, f2, l2);
+  o.startLoc = o.endLoc - (l2 - 1);
+  if (!path) return o;
+  const int tl2 = o.endLoc - o.startLoc + 1;
+  if (tl2 <= 0) {
+    o.nops = lm_fill_inserts(ops, qn, lane);
+    return o;
+  }
+  o.nops = lm_nw_path(T + o.startLoc, tl2, Qy, qn, mode & LM_EQ, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
+  return o;
+}
+
+// edlibAlign(Q, T, SHW, PATH)
+__device__ __forceinline__ LmRes lm_shw(const uint8_t* T, int tn, const uint8_t* Qy, int qn, int mode, int32_t* bnd,
+                                        int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp, uint8_t* ops,
+                                        int ops_cap, int lane) {
+  LmRes o;
+  int first, last;
+  lm_locate(T, 1, tn, Qy, 1, qn, mode & LM_EQ, bnd, bnd + bnd_stride, lane, o.ed, first, last);
+  o.endLoc = first - 1;
+  o.startLoc = 0;
+  if (o.endLoc == -1) o.nops = lm_fill_inserts(ops, qn, lane);
+  else o.nops = lm_nw_path(T, o.endLoc + 1, Qy, qn, mode & LM_EQ, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
+  return o;
 }
 
 // msaEdlib for one junction
@@ -391,7 +504,7 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int rd = L.sel[step];
         const uint8_t* qy = blob + L.roff[rd];
         const int qn = L.rlen[rd];
-        const int nops = lm_nw_path(astr, acols, qy, qn, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
+        const int nops = lm_nw_path(astr, acols, qy, qn, LM_EQ, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
         if (nops < 0 || nops > acap - 1) { status = DELLYHIP_E_LIMIT; break; }   // (the next target must fit the strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
