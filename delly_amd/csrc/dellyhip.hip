@@ -19,6 +19,7 @@
 #include "lr_kernel.hpp"
 #include "lrmsa_kernel.hpp"
 #include "lrins_kernel.hpp"
+#include "lrwfa_kernel.hpp"
 
 namespace {
 
@@ -108,6 +109,11 @@ struct dellyhip_batch {
   int lri_first = 0, lri_count = 0, lri_blocks = 0;
   dh::LrInsArgs lri{};
   DevBuf<uint8_t> lri_ws;
+  // long-read MSA of insertions (with_msa == 2, svt 4: msaWfa)
+  DevBuf<int32_t> wfa_list;
+  DevBuf<uint8_t> wfa_ws;
+  dh::LrWfaArgs wfa{};
+  int wfa_count = 0, wfa_blocks = 0;
   // long-read MSA (with_msa == 2: msaEdlib)
   DevBuf<int32_t> lm_edit, lm_pair_first;
   DevBuf<uint8_t> lm_ws;
@@ -246,7 +252,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
     const int grid = (b->lri_count + rounds - 1) / rounds;
     dh::LrInsArgs li = b->lri;
-    li.realign = (c->params.reserved & 1) ? 1 : 0;
+    li.realign = ((c->params.reserved & 1) && b->with_msa != 2) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions
     hipLaunchKernelGGL(dh::lr_ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, li);
     HIPCHK(hipGetLastError());
   }
@@ -342,6 +348,34 @@ int setup_lri_workspace(dellyhip_ctx* c, dellyhip_batch* b, int m_max, int n_max
   if (rc) return rc;
   R.ws = b->lri_ws.p;
   return 0;
+}
+
+// workspace layout of the msaWfa kernel for reads <= maxlen; returns the per-block stride
+uint64_t wfa_layout(dh::LrWfaArgs& W, int maxlen) {
+  W.ncap = std::max<int>((maxlen + 64) & ~63, 64);
+  const int acap = dh::WFA_ACAP;
+  const int qcap = std::max(W.ncap, acap);
+  W.strip_words = dh::lr_strip_words(qcap);
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take((uint64_t)(dh::LM_NR + 1) * acap);                 // alnA at 0
+  W.off_alnB = take((uint64_t)(dh::LM_NR + 1) * acap);
+  W.off_astr = take(acap);
+  W.off_bnd = take(4ull * ((uint64_t)qcap + 128) * 4);
+  W.off_ops = take(2ull * qcap + 128);
+  W.off_tmp = take(2ull * qcap + 128);
+  W.off_cons = take(acap);
+  W.off_dirs = take((uint64_t)(acap / dh::LRS + 1) * W.strip_words * 4);
+  W.off_tabI = take((uint64_t)dh::WFA_KTAB * 4);
+  W.off_tabJ = take((uint64_t)dh::WFA_KTAB * 4);
+  W.off_diag = take(((uint64_t)acap + W.ncap + 128) * 4);
+  W.off_supA = take(acap);
+  W.off_supB = take(acap);
+  W.off_pre = take(dh::WFA_PCAP);
+  W.off_suf = take(dh::WFA_PCAP);
+  W.off_edit = take((uint64_t)dh::LM_NR * dh::LM_NR * 4);
+  W.ws_stride = o;
+  return o;
 }
 
 // K-bins junctions by consensus length and pairs them (two junctions per wavefront, packed
@@ -525,7 +559,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -654,6 +688,21 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4));
       if ((rc = b->lm_ws.alloc((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
       M.ws = b->lm_ws.p;
+      // insertions: msaWfa kernel
+      std::vector<int32_t> wl;
+      for (int i = 0; i < n; ++i)
+        if (junc[i].svt == 4) wl.push_back(i);
+      b->wfa_count = (int)wl.size();
+      if (b->wfa_count) {
+        wfa_layout(b->wfa, maxlen);
+        b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 2));
+        if ((rc = b->wfa_list.alloc(wl.size())) || (rc = b->wfa_ws.alloc((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
+        e = hipMemcpy(b->wfa_list.p, wl.data(), wl.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa list", e));
+        e = hipMemset(b->wfa_ws.p, 0, (size_t)b->wfa.ws_stride * b->wfa_blocks);   // k-mer tables start (and are kept) all zero
+        if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa workspace", e));
+        b->wfa.ws = b->wfa_ws.p;
+      }
     } else {
       if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
       if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
@@ -700,23 +749,35 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     M.n_work = b->n;
     hipLaunchKernelGGL(dh::lrmsa_kernel, dim3(b->lm_blocks), dim3(dh::WAVE), 0, s, M);
     HIPCHK(hipGetLastError());
+    if (b->wfa_count > 0) {   // insertions: msaWfa with the reference anchors of src/assemble.h:855-856
+      if ((rc = ensure_chr_table(c))) return rc;
+      dh::LrWfaArgs W = b->wfa;
+      W.junc = b->junc.p; W.seq_blob = b->seq_blob.p; W.seq_off = b->seq_off.p;
+      W.chr_seq = c->d_chr_ptr.p; W.chr_len = c->d_chr_len.p;
+      W.p = c->params; W.res = b->res.p; W.out_blob = b->out_blob.p; W.out_stride = b->out_stride;
+      W.out_cons_cap = b->out_cons_cap; W.cons_len = b->cons_len.p;
+      W.work_list = b->wfa_list.p; W.n_work = b->wfa_count; W.use_anchors = 1;
+      hipLaunchKernelGGL(dh::lrwfa_kernel, dim3(b->wfa_blocks), dim3(dh::WAVE), 0, s, W);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     // consensus lengths known: window lengths, routing, strip-kernel workspace
-    int lr_m = 0, lr_n = 0, lr_cnt = 0;
+    int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
     b->h_win_len.resize(b->n);
     for (int i = 0; i < b->n; ++i) {
       const int m = b->h_cons_len[i];
       const int w = host_window_len(c->params, b->h_junc[i], m, c->chr_len);
       b->h_win_len[i] = w;
       if (is_lr_shape(c->params, b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
-        lr_m = std::max(lr_m, m);
-        lr_n = std::max(lr_n, w);
-        ++lr_cnt;
+        if (b->h_junc[i].svt == 4) { lri_m = std::max(lri_m, m); lri_n = std::max(lri_n, w); ++lri_cnt; }
+        else { lr_m = std::max(lr_m, m); lr_n = std::max(lr_n, w); ++lr_cnt; }
       }
     }
     b->lr_blocks = 0;
+    b->lri_blocks = 0;
     if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return rc;
+    if (lri_cnt && (rc = setup_lri_workspace(c, b, lri_m, lri_n, lri_cnt))) return rc;
     if ((rc = build_bins(b, c->params))) return rc;
   } else if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
@@ -942,6 +1003,65 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   HIPCHK(hipMemcpy(&R, dres.p, sizeof R, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&L, dlen.p, sizeof L, hipMemcpyDeviceToHost));
   if (R.status) return fail(R.status, "msaEdlib: kernel limit");
+  *rows = R.sr_support;
+  *cs_len = L;
+  if (L > cs_cap) return fail(DELLYHIP_E_ARG, "consensus buffer too small");
+  if (L > 0) HIPCHK(hipMemcpy(cs, dout.p, L, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off, const char* prefix,
+                     int32_t prefix_len, const char* suffix, int32_t suffix_len, char* cs, int32_t cs_cap, int32_t* cs_len,
+                     int32_t* rows) {
+  if (!c || !cs_len || !rows || n_reads < 0 || (n_reads && (!seq_blob || !seq_off)) || prefix_len < 0 || suffix_len < 0 ||
+      (prefix_len && !prefix) || (suffix_len && !suffix))
+    return fail(DELLYHIP_E_ARG, "bad argument");
+  if (n_reads > dh::LM_NR || prefix_len > dh::WFA_PCAP || suffix_len > dh::WFA_PCAP)
+    return fail(DELLYHIP_E_LIMIT, "msaWfa: more reads / longer anchors than the kernel holds");
+  HIPCHK(hipSetDevice(c->device));
+  *cs_len = 0;
+  *rows = 0;
+  if (n_reads == 0) return 0;
+  int rc;
+  const uint64_t blob_bytes = seq_off[n_reads];
+  int maxlen = 1;
+  for (int k = 0; k < n_reads; ++k) maxlen = std::max<int>(maxlen, (int)(seq_off[k + 1] - seq_off[k]));
+  if (maxlen > dh::LR_NMAX) return fail(DELLYHIP_E_LIMIT, "msaWfa: read longer than the kernel limit");
+  dellyhip_junction J{};
+  J.svt = 4;
+  J.n_seq = n_reads;
+  J.seq_first = 0;
+  DevBuf<dellyhip_junction> dj;
+  DevBuf<uint8_t> dblob, dout, dws, dpre, dsuf;
+  DevBuf<uint64_t> doff;
+  DevBuf<int32_t> dlen;
+  DevBuf<dellyhip_result> dres;
+  dh::LrWfaArgs W{};
+  wfa_layout(W, maxlen);
+  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(std::max<uint64_t>(blob_bytes, 1))) || (rc = doff.alloc(n_reads + 1)) ||
+      (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) || (rc = dout.alloc(dh::WFA_ACAP)) || (rc = dws.alloc(W.ws_stride)) ||
+      (rc = dpre.alloc(std::max(prefix_len, 1))) || (rc = dsuf.alloc(std::max(suffix_len, 1))))
+    return rc;
+  HIPCHK(hipMemcpy(dj.p, &J, sizeof J, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dblob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(doff.p, seq_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (prefix_len) HIPCHK(hipMemcpy(dpre.p, prefix, prefix_len, hipMemcpyHostToDevice));
+  if (suffix_len) HIPCHK(hipMemcpy(dsuf.p, suffix, suffix_len, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
+  HIPCHK(hipMemset(dws.p, 0, W.ws_stride));
+  W.junc = dj.p; W.seq_blob = dblob.p; W.seq_off = doff.p; W.p = c->params; W.res = dres.p;
+  W.out_blob = dout.p; W.out_stride = dh::WFA_ACAP; W.out_cons_cap = dh::WFA_ACAP; W.cons_len = dlen.p;
+  W.work_list = nullptr; W.n_work = 1; W.use_anchors = 0;
+  W.prefix = dpre.p; W.suffix = dsuf.p; W.prefix_len = prefix_len; W.suffix_len = suffix_len;
+  W.ws = dws.p;
+  hipLaunchKernelGGL(dh::lrwfa_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, W);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dellyhip_result R{};
+  int32_t L = 0;
+  HIPCHK(hipMemcpy(&R, dres.p, sizeof R, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&L, dlen.p, sizeof L, hipMemcpyDeviceToHost));
+  if (R.status) return fail(R.status, "msaWfa: kernel limit");
   *rows = R.sr_support;
   *cs_len = L;
   if (L > cs_cap) return fail(DELLYHIP_E_ARG, "consensus buffer too small");

@@ -392,6 +392,7 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
   dellyhip_result* out = &A.res[j];
   uint8_t* cons_out = A.out_blob + (size_t)j * A.out_stride;
   const int N = J.n_seq;
+  if (J.svt == 4) return;   // insertions: msaWfa (lrwfa_kernel.hpp)
   int status = 0, cons_len = 0, rows = 0;
   uint8_t* alnA = ws;
   uint8_t* alnB = ws + A.off_alnB;
@@ -404,7 +405,7 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
   const int bnd_stride = A.ncap + 128;
   const int acap = A.acap;
   if (N >= 1) {
-    if (N > LM_NR || J.svt == 4) status = DELLYHIP_E_LIMIT;   // (insertions use msaWfa: not on the device)
+    if (N > LM_NR) status = DELLYHIP_E_LIMIT;
     if (!status) {
       for (int r = lane; r < N; r += WAVE) {
         const uint64_t a = A.seq_off[J.seq_first + r], b = A.seq_off[J.seq_first + r + 1];

@@ -1,0 +1,476 @@
+// lrwfa_kernel.hpp -- gfx950 device code for msaWfa (src/assemble.h:547-726), the long-read
+// consensus of insertion junctions:
+//   7-mer diagonal seeding (fillKmerTable :501-520, bestDiagonal :522-545) + trimmed NW distances
+//   medoid order, 80 % cut                                    (:576-596)
+//   superstring of the selected reads (NW PATH + buildSuperstring :90-133)   (:598-660)
+//   progressive HW PATH alignment with the extended-IUPAC equalities, consensusWfa (:262-336),
+//   convertAlignment HW (:24-88)                                         (:662-686)
+//   consensus (src/msa.h:111-173), _trimConsensus against the reference anchors (:338-365)
+// One junction per wavefront, on the edlib-equivalent strip machinery of lrmsa_kernel.hpp.
+#pragma once
+#include "lrins_kernel.hpp"
+
+namespace dh {
+
+constexpr int WFA_KMER = 7;                 // DELLY_KMER, src/tags.h:19
+constexpr int WFA_KTAB = 65536;             // std::pow(4, DELLY_KMER + 1)
+constexpr uint32_t WFA_DUP = 0xffffffffu;   // DELLY_DUPLICATE, src/tags.h:15
+constexpr int WFA_ACAP = 8192;              // alignment columns / superstring capacity (row keys hold 13 bits)
+constexpr int WFA_PCAP = 4096;              // reference anchor (prefix / suffix) capacity
+
+struct LrWfaArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  const uint8_t* const* chr_seq;
+  const int64_t* chr_len;
+  dellyhip_params p;
+  dellyhip_result* res;
+  uint8_t* out_blob;
+  uint64_t out_stride;
+  int32_t out_cons_cap;
+  int32_t* cons_len;
+  const int32_t* work_list;  // junction indices (nullptr: 0..n_work-1)
+  int32_t n_work;
+  int32_t use_anchors;       // 1: prefix / suffix from the chromosome (src/assemble.h:855-856); 0: given / none
+  const uint8_t* prefix;     // single-call mode
+  const uint8_t* suffix;
+  int32_t prefix_len, suffix_len;
+  uint8_t* ws;
+  uint64_t ws_stride;
+  int32_t ncap;              // read length capacity
+  uint64_t off_alnB, off_astr, off_bnd, off_ops, off_tmp, off_cons, off_dirs, off_tabI, off_tabJ, off_diag, off_supA, off_supB,
+      off_pre, off_suf, off_edit;   // alnA at 0
+  uint64_t strip_words;
+};
+
+__device__ __forceinline__ uint32_t wfa_char_to_int(uint8_t c) {   // charToInt, assemble.h:475-498
+  return (c == 'A' || c == 'B') ? 0u : (c == 'C' || c == 'D') ? 1u : (c == 'G' || c == 'E') ? 2u : (c == 'T' || c == 'F') ? 3u : 0u;
+}
+__device__ __forceinline__ uint32_t wfa_hash(const uint8_t* s, int p) {
+  uint32_t h = 0;
+#pragma unroll
+  for (int t = 0; t < WFA_KMER; ++t) h = h * 4u + wfa_char_to_int(s[p + t]);
+  return h;
+}
+
+// fillKmerTable (len >= 7): tab[h] = 1-based start of the only occurrence, WFA_DUP when repeated, 0 when absent.
+// The table must be all zero on entry; wfa_clear_table undoes exactly what this call touched.
+__device__ __forceinline__ void wfa_fill_table(const uint8_t* s, int len, uint32_t* tab, int lane) {
+  for (int p = lane; p <= len - WFA_KMER; p += WAVE) {
+    const uint32_t h = wfa_hash(s, p);
+    const uint32_t old = atomicCAS(&tab[h], 0u, (uint32_t)(p + 1));
+    if (old != 0u) atomicMax(&tab[h], WFA_DUP);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__device__ __forceinline__ void wfa_clear_table(const uint8_t* s, int len, uint32_t* tab, int lane) {
+  for (int p = lane; p <= len - WFA_KMER; p += WAVE) tab[wfa_hash(s, p)] = 0u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// bestDiagonal (assemble.h:522-545).  tabI / tabJ filled for sI / sJ; diag: scratch of lenI + lenJ + 64 words.
+__device__ __forceinline__ int wfa_best_diagonal(const uint8_t* sJ, int lenI, int lenJ, const uint32_t* tabI,
+                                                 const uint32_t* tabJ, uint32_t* diag, int lane) {
+  const int dn = lenI + lenJ;
+  for (int d = lane; d < dn + 64; d += WAVE) diag[d] = 0u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // every k-mer that is unique in both reads votes once for its diagonal
+  for (int p = lane; p <= lenJ - WFA_KMER; p += WAVE) {
+    const uint32_t h = wfa_hash(sJ, p);
+    const uint32_t hj = tabJ[h], hi = tabI[h];
+    if (hj == (uint32_t)(p + 1) && hi != 0u && hi != WFA_DUP) atomicAdd(&diag[lenJ + (int)hi - (int)hj], 1u);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // window of 20 diagonals (:533-544): W(19) = sum diag[0..19] -> bestDiag 10; for d >= 20
+  // W(d) = sum diag[d-19..d] -> bestDiag d - 10, taken only when strictly larger: the first maximum wins
+  const int window = 20;
+  unsigned long long best = 0;   // (W + 1) << 20 | (0xfffff - d)
+  for (int d = window - 1 + lane; d < dn; d += WAVE) {
+    uint32_t W = 0;
+#pragma unroll
+    for (int x = 0; x < window; ++x) W += diag[d - x];
+    const unsigned long long key = ((unsigned long long)(W + 1u) << 20) | (unsigned long long)(0xfffff - d);
+    best = key > best ? key : best;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int lo = __shfl_xor((int)(best & 0xffffffffull), o), hi = __shfl_xor((int)(best >> 32), o);
+    const unsigned long long w = ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+    best = w > best ? w : best;
+  }
+  int bestDiag = window / 2;   // also the answer when there are fewer than 20 diagonals
+  if (best != 0ull) {
+    const int dstar = 0xfffff - (int)(best & 0xfffffull);
+    bestDiag = (dstar == window - 1) ? window / 2 : dstar - window / 2;
+  }
+  return rfl(bestDiag) - lenJ;
+}
+
+// msaWfa for one junction
+__device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* ws, int lane) {
+  const dellyhip_junction J = A.junc[j];
+  dellyhip_result* out = &A.res[j];
+  uint8_t* cons_out = A.out_blob + (size_t)j * A.out_stride;
+  const int N = J.n_seq;
+  int status = 0, cons_len = 0, rows = 0;
+  uint8_t* alnA = ws;
+  uint8_t* alnB = ws + A.off_alnB;
+  uint8_t* astr = ws + A.off_astr;
+  int32_t* bnd = reinterpret_cast<int32_t*>(ws + A.off_bnd);
+  uint8_t* ops = ws + A.off_ops;
+  uint8_t* tmp = ws + A.off_tmp;
+  uint8_t* cbuf = ws + A.off_cons;
+  uint32_t* dirs = reinterpret_cast<uint32_t*>(ws + A.off_dirs);
+  uint32_t* tabI = reinterpret_cast<uint32_t*>(ws + A.off_tabI);
+  uint32_t* tabJ = reinterpret_cast<uint32_t*>(ws + A.off_tabJ);
+  uint32_t* diag = reinterpret_cast<uint32_t*>(ws + A.off_diag);
+  uint8_t* supA = ws + A.off_supA;
+  uint8_t* supB = ws + A.off_supB;
+  uint8_t* pre = ws + A.off_pre;
+  uint8_t* suf = ws + A.off_suf;
+  int32_t* E = reinterpret_cast<int32_t*>(ws + A.off_edit);
+  const int bnd_stride = max(A.ncap, WFA_ACAP) + 128;
+  const int acap = WFA_ACAP;
+  const int ops_cap = 2 * max(acap, A.ncap) + 32;
+  const uint8_t* blob = A.seq_blob;
+  if (N >= 1) {
+    if (N > LM_NR) status = DELLYHIP_E_LIMIT;
+    if (!status) {
+      for (int r = lane; r < N; r += WAVE) {
+        const uint64_t a = A.seq_off[J.seq_first + r], b = A.seq_off[J.seq_first + r + 1];
+        L.roff[r] = a;
+        L.rlen[r] = (int32_t)(b - a);
+      }
+      __syncthreads();
+      for (int r = 0; r < N; ++r)
+        if (L.rlen[r] > A.ncap || L.rlen[r] > MYERS_ROWS || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = DELLYHIP_E_LIMIT;
+    }
+    // reference anchors (src/assemble.h:855-856)
+    int pn = 0, sn = 0;
+    if (!status) {
+      if (A.use_anchors) {
+        const uint8_t* seq = A.chr_seq[J.chr];
+        const int seqlen = (int)(uint32_t)A.chr_len[J.chr];
+        const int p0 = max(J.sv_start - A.p.min_cons_window, 0), p1 = J.sv_start;
+        const int s0 = J.sv_start, s1 = min(seqlen, J.sv_start + A.p.min_cons_window);
+        pn = max(0, p1 - p0);
+        sn = max(0, s1 - s0);
+        if (pn > WFA_PCAP || sn > WFA_PCAP) status = DELLYHIP_E_LIMIT;
+        else {
+          for (int k = lane; k < pn; k += WAVE) pre[k] = upc(seq[p0 + k]);
+          for (int k = lane; k < sn; k += WAVE) suf[k] = upc(seq[s0 + k]);
+        }
+      } else {
+        pn = A.prefix_len;
+        sn = A.suffix_len;
+        if (pn > WFA_PCAP || sn > WFA_PCAP) status = DELLYHIP_E_LIMIT;
+        else {
+          for (int k = lane; k < pn; k += WAVE) pre[k] = A.prefix[k];
+          for (int k = lane; k < sn; k += WAVE) suf[k] = A.suffix[k];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (!status) {
+      // ---- pairwise scores: diagonal seeding, trimmed NW distance, per mille of the length (:551-574)
+      for (int a = 0; a < N; ++a) {
+        const uint8_t* sI = blob + L.roff[a];
+        const int lenI = L.rlen[a];
+        wfa_fill_table(sI, lenI, tabI, lane);
+        for (int b = a + 1; b < N; ++b) {
+          const uint8_t* sJ = blob + L.roff[b];
+          const int lenJ = L.rlen[b];
+          wfa_fill_table(sJ, lenJ, tabJ, lane);
+          const int bd = wfa_best_diagonal(sJ, lenI, lenJ, tabI, tabJ, diag, lane);
+          wfa_clear_table(sJ, lenJ, tabJ, lane);
+          uint32_t oI, oJ, seqlen;
+          if (bd >= 0) { seqlen = min((uint32_t)lenI - (uint32_t)bd, (uint32_t)lenJ); oI = (uint32_t)bd; oJ = 0; }
+          else { seqlen = min((uint32_t)lenJ + (uint32_t)bd, (uint32_t)lenI); oI = 0; oJ = (uint32_t)(-bd); }
+          uint32_t lI = min(seqlen, (uint32_t)lenI - oI), lJ = min(seqlen, (uint32_t)lenJ - oJ);   // substr clamps
+          int d;
+          if (lI == 0 || lJ == 0) d = (int)max(lI, lJ);
+          else d = rfl(myers_nw(sI + oI, (int)lI, sJ + oJ, (int)lJ, lane));
+          const int score = (d * 1000) / (int)max(lI, lJ);
+          if (lane == 0) {
+            E[a * LM_NR + b] = score;
+            E[b * LM_NR + a] = score;
+          }
+        }
+        wfa_clear_table(sI, lenI, tabI, lane);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      // ---- medoid, order, 80 % cut (:576-596) -- as in msaEdlib
+      if (lane < N) {
+        int med = 0;
+        for (int x = 0; x < N; ++x) {
+          const int vx = (x == lane) ? 0 : E[lane * LM_NR + x];
+          int rank = 0;
+          for (int y = 0; y < N; ++y) {
+            const int vy = (y == lane) ? 0 : E[lane * LM_NR + y];
+            rank += (vy < vx || (vy == vx && y < x)) ? 1 : 0;
+          }
+          if (rank == N / 2) med = vx;
+        }
+        L.med[lane] = med;
+      }
+      __syncthreads();
+      int bestIdx = 0, bestVal = L.rlen[0];
+      for (int i = 0; i < N; ++i)
+        if (L.med[i] < bestVal) { bestVal = L.med[i]; bestIdx = i; }
+      uint32_t lastIdx = (uint32_t)(0.8 * N);
+      if (lastIdx < 3) lastIdx = 3;
+      const int nsel = min((int)lastIdx, N);
+      if (lane < N) {
+        const int kx = (lane == bestIdx) ? 0 : E[bestIdx * LM_NR + lane];
+        int rank = 0;
+        for (int y = 0; y < N; ++y) {
+          const int ky = (y == bestIdx) ? 0 : E[bestIdx * LM_NR + y];
+          rank += (ky < kx || (ky == kx && y < lane)) ? 1 : 0;
+        }
+        if (rank < LM_NR) L.sel[rank] = lane;
+      }
+      __syncthreads();
+      // ---- superstring (:598-660)
+      uint8_t* sup = supA;
+      uint8_t* sup2 = supB;
+      int sl = L.rlen[L.sel[0]];
+      {
+        const uint8_t* r0 = blob + L.roff[L.sel[0]];
+        for (int k = lane; k < sl; k += WAVE) sup[k] = r0[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      for (int step = 1; step < nsel && !status; ++step) {
+        const uint8_t* rd = blob + L.roff[L.sel[step]];
+        const uint32_t lenI = (uint32_t)sl, lenJ = (uint32_t)L.rlen[L.sel[step]];
+        wfa_fill_table(sup, (int)lenI, tabI, lane);
+        wfa_fill_table(rd, (int)lenJ, tabJ, lane);
+        const int bd = wfa_best_diagonal(rd, (int)lenI, (int)lenJ, tabI, tabJ, diag, lane);
+        wfa_clear_table(sup, (int)lenI, tabI, lane);
+        wfa_clear_table(rd, (int)lenJ, tabJ, lane);
+        uint32_t preI, postI, preJ, postJ, seqlen;
+        if (bd >= 0) {
+          seqlen = min(lenI - (uint32_t)bd, lenJ);
+          preI = (uint32_t)bd; postI = lenI - ((uint32_t)bd + seqlen); preJ = 0; postJ = lenJ - seqlen;
+        } else {
+          seqlen = min(lenJ + (uint32_t)bd, lenI);
+          preI = 0; postI = lenI - seqlen; preJ = (uint32_t)(-bd); postJ = lenJ - ((uint32_t)(-bd) + seqlen);
+        }
+        if (preI > preJ && postI > postJ) {
+          // nested: the superstring already contains the read
+        } else if (preJ > preI && postJ > postI) {
+          for (int k = lane; k < (int)lenJ; k += WAVE) sup[k] = rd[k];
+          sl = (int)lenJ;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        } else {
+          const uint8_t* sI = (bd >= 0) ? sup + bd : sup;
+          const uint8_t* sJ = (bd >= 0) ? rd : rd + (-bd);
+          if ((int)seqlen > acap - 2 || seqlen == 0) { status = DELLYHIP_E_LIMIT; break; }
+          // edlibAlign(seqI, seqJ, NW, PATH): query = seqI (columns), target = seqJ (rows)
+          const int nops = lm_nw_path(sJ, (int)seqlen, sI, (int)seqlen, 0, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+          if (nops < 0) { status = DELLYHIP_E_LIMIT; break; }
+          // buildSuperstring (:90-133)
+          const bool f0 = preI > preJ;
+          const int plen = f0 ? (int)preI : (int)preJ;
+          for (int k = lane; k < plen; k += WAVE) sup2[k] = f0 ? sup[k] : rd[k];
+          const int bp = nops / 2;
+          int ib = (int)preI, jb = (int)preJ, ob = plen;
+          for (int base = 0; base < nops; base += WAVE) {
+            const int q = base + lane;
+            const int op = (q < nops) ? (int)ops[q] : ED_MATCH;
+            const bool first = (q < bp) ? f0 : !f0;
+            const bool isI = (q < nops) && (op != ED_DELETE);   // consumes seqI
+            const bool isJ = (q < nops) && (op != ED_INSERT);   // consumes seqJ
+            const bool emit = (q < nops) && ((op == ED_DELETE) ? !first : (op == ED_INSERT) ? first : true);
+            const unsigned long long mi = __ballot(isI), mj = __ballot(isJ), me = __ballot(emit);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int ii = ib + __popcll(mi & below), jj = jb + __popcll(mj & below), oo = ob + __popcll(me & below);
+            if (emit) sup2[oo] = (op == ED_DELETE) ? rd[jj] : (op == ED_INSERT) ? sup[ii] : (first ? sup[ii] : rd[jj]);
+            ib += __popcll(mi);
+            jb += __popcll(mj);
+            ob += __popcll(me);
+          }
+          const bool tailI = postI > postJ;
+          const int tlen = tailI ? (int)postI : (int)postJ;
+          if (ob + tlen > acap - 2) { status = DELLYHIP_E_LIMIT; break; }
+          for (int k = lane; k < tlen; k += WAVE) sup2[ob + k] = tailI ? sup[ib + k] : rd[jb + k];
+          sl = ob + tlen;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          uint8_t* sw = sup; sup = sup2; sup2 = sw;
+        }
+      }
+      // ---- progressive HW alignment of every selected read (:662-686)
+      uint8_t* cur = alnA;
+      uint8_t* nxt = alnB;
+      int arows = 1, acols = sl;
+      if (!status) {
+        for (int k = lane; k < acols; k += WAVE) cur[k] = sup[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      for (int step = 0; step < nsel && !status; ++step) {
+        // consensusWfa (:262-336): only rows spanning the column vote
+        for (int r = 0; r < arows; ++r) {
+          int first = acols, last = 0;
+          bool any = false;
+          for (int base = 0; base < acols; base += WAVE) {
+            const int c = base + lane;
+            const unsigned long long bm = __ballot(c < acols && cur[(size_t)r * acap + c] != '-');
+            if (bm) {
+              if (!any) first = base + __builtin_ctzll(bm);
+              last = base + 63 - __builtin_clzll(bm);
+              any = true;
+            }
+          }
+          if (lane == 0) { L.first[r] = first; L.last[r] = last; }   // readStart = cols, readEnd = 0 when the row is all gaps
+        }
+        __syncthreads();
+        for (int col = lane; col < acols; col += WAVE) {
+          int count[5] = {0, 0, 0, 0, 0};
+          for (int r = 0; r < arows; ++r) {
+            if (col >= L.first[r] && col <= L.last[r]) {
+              const uint8_t ch = cur[(size_t)r * acap + col];
+              if (ch == 'A' || ch == 'a') ++count[0];
+              else if (ch == 'C' || ch == 'c') ++count[1];
+              else if (ch == 'G' || ch == 'g') ++count[2];
+              else if (ch == 'T' || ch == 't') ++count[3];
+              else ++count[4];
+            }
+          }
+          int maxIdx = 0, sndIdx = 1;
+          if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
+#pragma unroll
+          for (int i = 2; i < 5; ++i) {
+            if (count[i] > count[maxIdx]) { sndIdx = maxIdx; maxIdx = i; }
+            else if (count[i] > count[sndIdx]) sndIdx = i;
+          }
+          uint8_t letter;
+          if (2 * count[sndIdx] < count[maxIdx]) letter = (maxIdx < 4) ? (uint8_t)("ACGT"[maxIdx]) : (uint8_t)'-';
+          else {
+            const int k1 = min(maxIdx, sndIdx), k2 = max(maxIdx, sndIdx);
+            const int code = k1 * 5 + k2;
+            letter = code == 1 ? 'M' : code == 2 ? 'R' : code == 3 ? 'W' : code == 4 ? 'B' : code == 7 ? 'S' : code == 8 ? 'Y'
+                   : code == 9 ? 'D' : code == 13 ? 'K' : code == 14 ? 'E' : code == 19 ? 'F' : '-';
+          }
+          astr[col] = letter;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int rd = L.sel[step];
+        const uint8_t* qy = blob + L.roff[rd];
+        const int qn = L.rlen[rd];
+        const LmRes h = lm_hw(astr, acols, qy, qn, LM_EQ, true, true, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+        if (h.nops < 0) { status = DELLYHIP_E_LIMIT; break; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // convertAlignment(query, align, HW, cigar) (:24-88)
+        const int nops = h.nops;
+        const int missingStart = h.startLoc;                       // tIdx = end - #nonINSERT = start - 1
+        const int missingEnd = (h.endLoc < acols) ? acols - h.endLoc - 1 : 0;
+        const int ncols = missingStart + nops + missingEnd;
+        if (ncols > acap - 2) { status = DELLYHIP_E_LIMIT; break; }
+        for (int c = lane; c < missingStart; c += WAVE) {
+          for (int r = 0; r < arows; ++r) nxt[(size_t)r * acap + c] = cur[(size_t)r * acap + c];
+          nxt[(size_t)arows * acap + c] = '-';
+        }
+        int tbase = (h.endLoc == -1) ? 0 : missingStart, qbase = 0;
+        for (int base = 0; base < nops; base += WAVE) {
+          const int jc = base + lane;
+          const int op = (jc < nops) ? (int)ops[jc] : ED_MATCH;
+          const unsigned long long mt = __ballot(jc < nops && op != ED_INSERT);
+          const unsigned long long mq = __ballot(jc < nops && op != ED_DELETE);
+          const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+          const int ti = tbase + __popcll(mt & below), qi = qbase + __popcll(mq & below);
+          if (jc < nops) {
+            const int oc = missingStart + jc;
+            for (int r = 0; r < arows; ++r) nxt[(size_t)r * acap + oc] = (op != ED_INSERT) ? cur[(size_t)r * acap + ti] : (uint8_t)'-';
+            nxt[(size_t)arows * acap + oc] = (op != ED_DELETE) ? qy[qi] : (uint8_t)'-';
+          }
+          tbase += __popcll(mt);
+          qbase += __popcll(mq);
+        }
+        for (int c = lane; c < missingEnd; c += WAVE) {
+          const int oc = missingStart + nops + c;
+          for (int r = 0; r < arows; ++r) nxt[(size_t)r * acap + oc] = cur[(size_t)r * acap + tbase + c];
+          nxt[(size_t)arows * acap + oc] = '-';
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        uint8_t* sw = cur; cur = nxt; nxt = sw;
+        arows += 1;
+        acols = ncols;
+      }
+      if (!status) {
+        Node nd{cur, arows, acols, acap};
+        int Lc = consensus_node(nd, A.p, cbuf, acap, L, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int o = 0;
+        if (pn > 0 && sn > 0) {
+          // _trimConsensus (:338-365)
+          if (Lc < 1 || Lc > acap - 2) { Lc = max(Lc, 0); }
+          if (Lc >= 1) {
+            uint8_t* prev = sup2;   // reverse complement of the prefix (the superstring buffers are free by now)
+            for (int k = lane; k < pn; k += WAVE) prev[k] = rc_at(pre, pn, k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const LmRes f = lm_hw(cbuf, Lc, pre, pn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const LmRes r = lm_hw(cbuf, Lc, prev, pn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            if (f.ed > r.ed) {   // reverseComplement(cs), util.h:549-563 semantics
+              for (int k = lane; k < Lc; k += WAVE) astr[k] = rc_at(cbuf, Lc, k);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+              for (int k = lane; k < Lc; k += WAVE) cbuf[k] = astr[k];
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+            }
+            const LmRes cp = lm_hw(cbuf, Lc, pre, pn, 0, true, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const LmRes cs2 = lm_hw(cbuf, Lc, suf, sn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const uint32_t csStart = (uint32_t)cp.startLoc, csEnd = (uint32_t)cs2.endLoc;
+            if (csStart < csEnd && csEnd < (uint32_t)Lc) { o = (int)csStart; Lc = (int)(csEnd - csStart); }
+          }
+        } else {
+          int trim = (int)(0.05 * Lc);
+          if (trim > 50) trim = 50;
+          const int len = Lc - 2 * trim;
+          if (len > 100) { o = trim; Lc = len; }
+        }
+        if (Lc > A.out_cons_cap) status = DELLYHIP_E_LIMIT;
+        else {
+          for (int k = lane; k < Lc; k += WAVE) cons_out[k] = cbuf[o + k];
+          cons_len = Lc;
+          rows = nsel;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    out->sr_support = rows;
+    out->status = status;
+    A.cons_len[j] = status ? 0 : cons_len;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(WAVE) void lrwfa_kernel(LrWfaArgs A) {
+  __shared__ LrMsaLds L;
+  const int lane = threadIdx.x;
+  uint8_t* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
+    const int j = A.work_list ? A.work_list[w] : w;
+    if (j < 0) continue;
+    lrwfa_junction(A, j, L, ws, lane);
+  }
+}
+
+}  // namespace dh

@@ -26,7 +26,7 @@ EXPORTS = [
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
     "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
-    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib",
+    "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib", "dellyhip_msa_wfa",
 ]
 
 
@@ -199,6 +199,19 @@ class Context:
         cs = np.zeros(cap, dtype=np.uint8)
         ln, rows = C.c_int32(0), C.c_int32(0)
         self._check(fn(self._ctx, len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)), _p(cs), cap, C.byref(ln), C.byref(rows)))
+        return rows.value, cs[:ln.value].tobytes()
+
+    def msa_wfa(self, reads, prefix=b"", suffix=b""):
+        """msaWfa(c, sps, cs, prefix, suffix) -> (rows, consensus)"""
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        blob = _u8(b"".join(reads))
+        cap = 2 * int(off[-1]) + 8
+        cs = np.zeros(cap, dtype=np.uint8)
+        ln, rows = C.c_int32(0), C.c_int32(0)
+        pre, suf = _u8(prefix), _u8(suffix)
+        self._check(self.lib.dellyhip_msa_wfa(self._ctx, len(reads), _p(blob), _p(off, C.POINTER(C.c_uint64)), _p(pre), pre.size,
+                                              _p(suf), suf.size, _p(cs), cap, C.byref(ln), C.byref(rows)))
         return rows.value, cs[:ln.value].tobytes()
 
     def msa_edlib(self, reads):

@@ -190,7 +190,9 @@ int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms
  * followed by alignConsensus(c, hdr, seq, NULL, sv, realign) with the `delly lr` parameters
  * (dellyhip_default_params_lr; realign = bit 0 of params.reserved).  Reads: at most 16 per
  * junction, each <= 24000 bytes and -- for the all-pairs distances -- at least one of every
- * two <= 6144 bytes.  svt 4 junctions (msaWfa) are flagged DELLYHIP_E_LIMIT. */
+ * two <= 6144 bytes.  svt 4 junctions take the insertion branch of the loop (:855-860):
+ * msaWfa with the reference anchors around svStart, then alignConsensus with realign = false
+ * (reads 8 .. 6144 bytes, superstring / alignment <= 8190 columns). */
 int dellyhip_refine_batch_lr(dellyhip_ctx* ctx, int32_t n_junctions, const dellyhip_junction* junctions,
                              const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq,
                              dellyhip_result* results, char* out_blob, uint64_t out_blob_cap,
@@ -233,6 +235,11 @@ int dellyhip_gotoh(dellyhip_ctx* ctx, const char* a1, int32_t r1, int32_t m, con
 /* int msa(c, sps, cs)  src/msa.h:185-239: returns rows in *rows, consensus in cs. */
 int dellyhip_msa(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,
                  char* cs, int32_t cs_cap, int32_t* cs_len, int32_t* rows);
+
+/* int msaWfa(c, sps, cs, prefix, suffix)  src/assemble.h:547-726 (prefix / suffix may be empty). */
+int dellyhip_msa_wfa(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,
+                     const char* prefix, int32_t prefix_len, const char* suffix, int32_t suffix_len,
+                     char* cs, int32_t cs_cap, int32_t* cs_len, int32_t* rows);
 
 /* int msaEdlib(c, sps, cs)  src/assemble.h:383-473: returns rows in *rows, consensus in cs. */
 int dellyhip_msa_edlib(dellyhip_ctx* ctx, int32_t n_reads, const char* seq_blob, const uint64_t* seq_off,

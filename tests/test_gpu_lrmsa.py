@@ -77,3 +77,75 @@ def test_refine_batch_lr_vs_port(lr_ctx, port):
     gr, gb = lr_ctx.refine(b, want_alignment=False)
     pr, pb = port.refine_batch(b, params=abi.params_lr(realign=True), want_alignment=False)
     compare(gr, gb, pr, pb, fields=CORE + INTERNAL, blobs=("cons", "allele"), label="hip-vs-port")
+
+
+def test_msa_wfa_reproduces_reference_golden_vectors(lr_ctx):
+    """msaWfa (src/assemble.h:547-726) vs vectors produced by the reference (with and without anchors)"""
+    g = np.load(os.path.join(GOLD, "longread.npz"), allow_pickle=True)
+    n = 0
+    for reads, pre, suf, rows, cs in zip(g["wfa_sets"], g["wfa_pre"], g["wfa_suf"], g["wfa_rows"], g["wfa_cs"]):
+        r, c = lr_ctx.msa_wfa(list(reads), pre, suf)
+        assert r == int(rows), n
+        assert c == cs, (n, len(c), len(cs))
+        n += 1
+    assert n >= 5
+
+
+def test_msa_wfa_vs_port(lr_ctx, port):
+    rng = np.random.default_rng(41)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    old = port.params
+    port.params = abi.params_lr()
+    try:
+        for it in range(6):
+            F = int(rng.integers(200, 900))
+            left = bytes(rng.choice(list(b"ACGT"), F + 400).astype(np.uint8))
+            right = bytes(rng.choice(list(b"ACGT"), F + 400).astype(np.uint8))
+            hap = left + bytes(rng.choice(list(b"ACGT"), int(rng.integers(60, 500))).astype(np.uint8)) + right
+            n = [2, 3, 5, 8, 12, 16][it]
+            reads = []
+            for k in range(n):
+                a = 400 - int(rng.integers(0, min(F, 350)))
+                b = len(hap) - 400 + int(rng.integers(0, min(F, 350)))
+                r = _ont(rng, hap[a:b], 0.07 if it % 2 else 0.02)
+                if it == 3 and k % 4 == 1:
+                    r = bytes(comp[c] for c in reversed(r))
+                reads.append(r)
+            pre, suf = (left[-250:], right[:250]) if it % 2 == 0 else (b"", b"")
+            assert lr_ctx.msa_wfa(reads, pre, suf) == port.msa_wfa(reads, pre, suf), (it, n)
+    finally:
+        port.params = old
+
+
+def _lr_insertion_reads(n, n_reads=6, seed=5, err=0.04):
+    rng = np.random.default_rng(seed)
+    W = synth.WINDOW_LR
+    chrom = synth.ACGT[rng.integers(0, 4, n * W)]
+    junc = np.zeros(n, dtype=abi.junction_dtype())
+    seqs = []
+    for k in range(n):
+        s0 = k * W + 6000
+        il = int(rng.integers(300, 800))
+        hap = np.concatenate([chrom[s0 - 1300:s0], synth.ACGT[rng.integers(0, 4, il)], chrom[s0:s0 + 1300]])
+        junc[k]["svid"] = k
+        junc[k]["svt"] = 4
+        junc[k]["sv_start"] = s0
+        junc[k]["sv_end"] = s0 + 1
+        junc[k]["ins_len"] = il
+        junc[k]["seq_first"] = len(seqs)
+        junc[k]["n_seq"] = n_reads
+        for _ in range(n_reads):
+            seqs.append(synth._ont(rng, hap[int(rng.integers(0, 100)):hap.size - int(rng.integers(0, 100))], err))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs])
+    return synth.Batch([chrom], junc, np.concatenate(seqs), off, 2, None)
+
+
+def test_refine_batch_lr_insertions_vs_port(lr_ctx, port):
+    """long-read insertion branch of the loop body: msaWfa with reference anchors + alignConsensus(realign=false)"""
+    b = _lr_insertion_reads(4)
+    lr_ctx.set_chromosomes(b.chroms)
+    gr, gb = lr_ctx.refine(b, want_alignment=True)
+    pr, pb = port.refine_batch(b, params=abi.params_lr(realign=True))
+    compare(gr, gb, pr, pb, fields=CORE + INTERNAL, label="hip-vs-port LR INS loop")
+    assert int(gr["ok"].sum()) >= 3
