@@ -81,6 +81,8 @@ struct dellyhip_ctx {
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
 };
 
+struct SmallInv { int32_t j, full_len, offset; };   // long-read loop, small inversions (src/assemble.h:840-853)
+
 struct dellyhip_batch {
   int32_t n = 0;
   uint64_t n_seq = 0;
@@ -114,6 +116,8 @@ struct dellyhip_batch {
   DevBuf<uint8_t> wfa_ws;
   dh::LrWfaArgs wfa{};
   int wfa_count = 0, wfa_blocks = 0;
+  DevBuf<SmallInv> small_inv;
+  int small_inv_n = 0;
   // long-read MSA (with_msa == 2: msaEdlib)
   DevBuf<int32_t> lm_edit, lm_pair_first;
   DevBuf<uint8_t> lm_ws;
@@ -439,6 +443,15 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
 
 }  // namespace
 
+// long-read loop, small inversions (src/assemble.h:850-853): the consensus is restored, consBp shifted
+__global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SmallInv x = list[i];
+  res[x.j].cons_len = x.full_len;
+  if (res[x.j].ok) res[x.j].cons_bp += x.offset;
+}
+
 // ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
 // off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
 __global__ void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
@@ -559,7 +572,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->small_inv.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -762,6 +775,31 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     }
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    // "take care of small inversions" (src/assemble.h:840-848): align only the middle svSize letters
+    {
+      std::vector<SmallInv> si;
+      std::vector<uint64_t> coff;
+      for (int i = 0; i < b->n; ++i) {
+        const dellyhip_junction& J = b->h_junc[i];
+        const int32_t svSize = J.sv_end - J.sv_start, m = b->h_cons_len[i];
+        if ((J.svt == 0 || J.svt == 1) && svSize < m && m > 0) {
+          const int32_t off = (int32_t)(((size_t)m - (size_t)svSize) / 2);
+          if (off < 0 || off > m) continue;
+          const int32_t take = std::min<int32_t>(std::max(svSize, 0), m - off);
+          si.push_back(SmallInv{i, m, off});
+          b->h_cons_len[i] = take;
+          const uint64_t co = (uint64_t)i * b->out_stride + (uint64_t)off;
+          HIPCHK(hipMemcpyAsync(b->cons_off.p + i, &co, sizeof co, hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(b->cons_len.p + i, &take, sizeof take, hipMemcpyHostToDevice, s));
+        }
+      }
+      HIPCHK(hipStreamSynchronize(s));   // (the pageable sources above go out of scope)
+      b->small_inv_n = (int)si.size();
+      if (b->small_inv_n) {
+        if ((rc = b->small_inv.reserve(si.size()))) return rc;
+        HIPCHK(hipMemcpy(b->small_inv.p, si.data(), si.size() * sizeof(SmallInv), hipMemcpyHostToDevice));
+      }
+    }
     // consensus lengths known: window lengths, routing, strip-kernel workspace
     int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
     b->h_win_len.resize(b->n);
@@ -807,6 +845,10 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   }
   HIPCHK(hipEventRecord(e3[1], s));
   if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
+  if (b->with_msa == 2 && b->small_inv_n > 0) {
+    hipLaunchKernelGGL(small_inv_fix_kernel, dim3((b->small_inv_n + 63) / 64), dim3(64), 0, s, b->res.p, b->small_inv.p, b->small_inv_n);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(e3[2], s));
   b->last = e3[2];
   b->pending = true;

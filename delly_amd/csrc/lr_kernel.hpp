@@ -473,6 +473,7 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
   uint32_t* stack = reinterpret_cast<uint32_t*>(ws + R.off_stack);
   const int m = X.m;
   const uint8_t* cons_g = A.cons_base + A.cons_off[j];
+  const bool own_cons = (A.cons_base != A.out_blob) || (cons_g == X.ob);
   const int prior = X.out->status, support = X.out->sr_support;
   int status = 0;
   bool go = true, mlimit = false;
@@ -482,7 +483,7 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
     for (int i = lane; i < m; i += WAVE) {
       const uint8_t ch = cons_g[i];
       S.cons[i] = ch;
-      if (cons_g != X.ob) X.ob[i] = ch;
+      if (A.cons_base != A.out_blob) X.ob[i] = ch;   // (MSA modes: the consensus already lives in the slot)
     }
   }
   if (go && J.svt == 4) { status = DELLYHIP_E_LIMIT; go = false; }   // long-read splitAlign: edlib's Hirschberg regime
@@ -537,7 +538,7 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];
         S.cons[i] = ch;
-        X.ob[i] = ch;
+        if (own_cons) X.ob[i] = ch;   // (a trimmed small-inversion consensus is restored by the caller: assemble.h:850-853)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

@@ -86,6 +86,7 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
   const int ops_cap = R.mcap + R.ncap + 32;
   const int m = X.m;
   const uint8_t* cons_g = A.cons_base + A.cons_off[j];
+  const bool own_cons = (A.cons_base != A.out_blob) || (cons_g == X.ob);
   const int prior = X.out->status, support = X.out->sr_support;
   int status = 0;
   bool go = true, mlimit = false;
@@ -95,7 +96,7 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
     for (int i = lane; i < m; i += WAVE) {
       const uint8_t ch = cons_g[i];
       S.cons[i] = ch;
-      if (cons_g != X.ob) X.ob[i] = ch;
+      if (A.cons_base != A.out_blob) X.ob[i] = ch;   // (MSA modes: the consensus already lives in the slot)
     }
   }
   if (go && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
@@ -142,7 +143,7 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];
         S.cons[i] = ch;
-        X.ob[i] = ch;
+        if (own_cons) X.ob[i] = ch;   // (a trimmed small-inversion consensus is restored by the caller: assemble.h:850-853)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

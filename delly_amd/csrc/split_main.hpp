@@ -180,7 +180,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     for (int i = lane; i < m; i += WAVE) {
       uint8_t ch = cons_g[i];
       S.cons[i] = ch;
-      if (WRITE_DEFAULTS && cons_g != X.ob) X.ob[i] = ch;
+      if (WRITE_DEFAULTS && A.cons_base != A.out_blob) X.ob[i] = ch;   // (MSA modes: the consensus already lives in the slot)
     }
   }
   if (go && !X.direct && (J.svt == 4) != INS) {  // splitAlign/edlib path <-> insertion kernel only

@@ -1804,10 +1804,28 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   }
   R->cons_len = m;
   R->cons_off = blob_put(b, cons, (uint64_t)m);
+  /* src/assemble.h:840-853: small inversions in the long-read loop -- only the middle svSize letters are
+   * aligned; the consensus is restored afterwards and consBp shifted */
+  char* cons_full = NULL;
+  int32_t off_small = 0;
+  if (b->with_msa == 2 && J->svt != 4) {
+    int32_t svSize = J->sv_end - J->sv_start;
+    if ((J->svt == 0 || J->svt == 1) && svSize < m) {
+      off_small = (int32_t)(((size_t)m - (size_t)svSize) / 2);
+      cons_full = cons;
+      size_t take = (svSize > 0) ? (size_t)svSize : 0;
+      if ((size_t)off_small > (size_t)m) off_small = m;           /* std::string::substr semantics */
+      if (take > (size_t)m - (size_t)off_small) take = (size_t)m - (size_t)off_small;
+      cons = (char*)malloc(take + 1);
+      memcpy(cons, cons_full + off_small, take);
+      m = (int)take;
+    }
+  }
 
   /* alignConsensus  split.h:644-666 */
   if (m < (2 * c->minimum_flank_size + J->ins_len)) {
     free(cons);
+    free(cons_full);
     return;
   }
   bpoint bp;
@@ -1839,7 +1857,7 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
     ed_align(ref.d, n, revc, m, ED_NW, 0, &r);
     if (r.ed < f.ed) {
       memcpy(cons, revc, (size_t)m);
-      if (b->out_blob && R->cons_off != UINT64_MAX) memcpy(b->out_blob + R->cons_off, cons, (size_t)m); /* sv.consensus = revc */
+      if (!cons_full && b->out_blob && R->cons_off != UINT64_MAX) memcpy(b->out_blob + R->cons_off, cons, (size_t)m); /* sv.consensus = revc */
     }
     free(revc);
   }
@@ -1903,7 +1921,7 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
         R->sv_end = (int32_t)ge;
         R->sr_align_quality = ad.percId;
         R->ins_len = ad.cEnd - ad.cStart - 1;
-        R->cons_bp = ad.cStart;
+        R->cons_bp = ad.cStart + off_small; /* (+ offsetTmpCons, src/assemble.h:852) */
         R->hom_len = imax(0, ad.homLeft + ad.homRight - 2);
         R->ci_wiggle = imax(ad.homLeft, ad.homRight);
       }
@@ -1913,6 +1931,7 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
   free(part1.d);
   free(ref.d);
   free(cons);
+  free(cons_full);
 }
 
 static void* worker(void* arg) {

@@ -152,6 +152,18 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
   std::string consIn = sv.consensus;
   R.cons_len = (int32_t)consIn.size();
   R.cons_off = bw.put(consIn.data(), consIn.size());
+  // src/assemble.h:840-848: "take care of small inversions" -- the long-read loop aligns only the
+  // middle svSize letters of the consensus and restores it afterwards (:850-853)
+  std::string tmpCons;
+  int32_t offsetTmpCons = 0;
+  if (with_msa == 2 && sv.svt != 4) {
+    int32_t svSize = sv.svEnd - sv.svStart;
+    if (((sv.svt == 0) || (sv.svt == 1)) && (svSize < (int32_t)sv.consensus.size())) {
+      offsetTmpCons = (sv.consensus.size() - svSize) / 2;
+      tmpCons = sv.consensus;
+      sv.consensus = sv.consensus.substr(offsetTmpCons, svSize);
+    }
+  }
 
   // Diagnostics: replay the inner calls of alignConsensus (src/split.h:646-666,
   // :582,:596) with the reference's own functions to expose the alignment rows
@@ -199,6 +211,10 @@ void refine_one(RefConfig const& c, bam_hdr_t const* hdr, const char* const* chr
 
   // The authoritative call: src/shortpe.h:186 / src/split.h:668-672
   bool ok = alignConsensus(c, const_cast<bam_hdr_t const*>(hdr), seq, sndSeq, sv, realign);
+  if (!tmpCons.empty()) {  // src/assemble.h:850-853
+    sv.consensus = tmpCons;
+    sv.consBp += offsetTmpCons;
+  }
   if (realign && sv.consensus != consIn && sv.consensus.size() == consIn.size() && R.cons_off != UINT64_MAX)
     std::memcpy(bw.base + R.cons_off, sv.consensus.data(), sv.consensus.size());  // the orientation test replaced sv.consensus
   R.ok = ok ? 1 : 0;

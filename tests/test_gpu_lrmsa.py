@@ -149,3 +149,34 @@ def test_refine_batch_lr_insertions_vs_port(lr_ctx, port):
     pr, pb = port.refine_batch(b, params=abi.params_lr(realign=True))
     compare(gr, gb, pr, pb, fields=CORE + INTERNAL, label="hip-vs-port LR INS loop")
     assert int(gr["ok"].sum()) >= 3
+
+
+def test_refine_batch_lr_small_inversions(lr_ctx, port):
+    """src/assemble.h:840-853: for INV junctions smaller than the consensus only the middle svSize letters
+    are aligned, the consensus is restored afterwards and consBp shifted"""
+    rng = np.random.default_rng(12)
+    n = 4
+    W = synth.WINDOW_LR
+    chrom = synth.ACGT[rng.integers(0, 4, n * W)]
+    junc = np.zeros(n, dtype=abi.junction_dtype())
+    seqs = []
+    for k in range(n):
+        s0 = k * W + 6000
+        L = int(rng.integers(900, 1500))
+        hap = np.concatenate([chrom[s0 - 1300:s0], synth.revcomp(chrom[s0:s0 + L]), chrom[s0 + L:s0 + L + 1300]])
+        junc[k]["svid"] = k
+        junc[k]["svt"] = k % 2
+        junc[k]["sv_start"] = s0
+        junc[k]["sv_end"] = s0 + L
+        junc[k]["seq_first"] = len(seqs)
+        junc[k]["n_seq"] = 5
+        for _ in range(5):
+            seqs.append(synth._ont(rng, hap[int(rng.integers(0, 100)):hap.size - int(rng.integers(0, 100))], 0.04))
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs])
+    b = synth.Batch([chrom], junc, np.concatenate(seqs), off, 2, None)
+    lr_ctx.set_chromosomes(b.chroms)
+    gr, gb = lr_ctx.refine(b, want_alignment=False)
+    pr, pb = port.refine_batch(b, params=abi.params_lr(realign=True), want_alignment=False)
+    compare(gr, gb, pr, pb, fields=CORE + INTERNAL, blobs=("cons", "allele"), label="small inversions")
+    assert np.all(gr["cons_len"] > 3000)   # the restored, untrimmed consensus is reported
