@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdellyhip.so")
 SOURCES = ["dellyhip.hip"]
-HEADERS = ["split_kernel.hpp", "split_main.hpp", "msa_kernel.hpp", "../../include/dellyhip.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + ["../../include/dellyhip.h"]
 
 
 def _stale():
@@ -17,17 +17,18 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not _stale():
+def build_lib(force=False, verbose=False, out=None, extra_flags=()):
+    """out / extra_flags: tuning experiments only (e.g. -DDH_QUAD_WAVES=3 into a side file)"""
+    if out is None and not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-Wno-unused-value",  # profile-Gotoh scores must round like the reference (SURVEY.md H3)
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@
 #include "msa_kernel.hpp"
 #include "split_main.hpp"
 #include "split_pk.hpp"
+#include "split_quad.hpp"
 #include "ins_kernel.hpp"
 #include "lr_kernel.hpp"
 #include "lrmsa_kernel.hpp"
@@ -79,6 +80,8 @@ struct dellyhip_ctx {
   int scratch_blocks = 0;
   DevBuf<int32_t> counters;  // work counters (one per K bin + MSA)
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
+  int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
 struct SmallInv { int32_t j, full_len, offset; };   // long-read loop, small inversions (src/assemble.h:840-853)
@@ -102,6 +105,10 @@ struct dellyhip_batch {
   DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
+  // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
+  std::vector<int32_t> qbin_first, qbin_count, qbin_pairs;   // per KQ: offset, quad items, pair items behind them
+  int use_quad = 1, quad_mix = 0;
+  int n_simd = 1024;
   // long-read shapes (|consensus| > 319 or |svRefStr| > 2048): strip kernel, per-block workspace
   std::vector<int32_t> h_win_len;    // |svRefStr| per junction, computed on the host (U path)
   int lr_first = 0, lr_count = 0, lr_blocks = 0;
@@ -187,6 +194,24 @@ void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters,
   hipLaunchKernelGGL(dh::split_post_kernel<K>, dim3(balanced(2 * pairs)), dim3(dh::WAVE), 0, s, a);
 }
 
+// quad bins: packed DP over four junctions per wavefront (rows per lane KQ in a 32-lane half), then the
+// 32-bit kernel for deferred junctions and the post kernel with the matching 64-lane rows-per-lane KP
+template <int KQ, int KP>
+void launch_quad(dh::SplitArgs a, int n_quads, int n_pairs, int max_blocks, int32_t* counters, hipStream_t s, hipEvent_t mid) {
+  auto balanced = [&](int n) {
+    int rounds = (n + max_blocks - 1) / max_blocks;
+    return (n + rounds - 1) / rounds;
+  };
+  const int items = n_quads + n_pairs, seats = 4 * n_quads + 2 * n_pairs;
+  a.n_work = items;
+  a.work_counter = counters + 5 + KQ;   // (slots 6..10; the deferred count lives 16 further)
+  hipLaunchKernelGGL((dh::split_quad_kernel<KQ, KP>), dim3(balanced(items)), dim3(dh::WAVE), 0, s, a, n_quads);
+  a.n_work = seats;   // the list is a flat array of junction indices (-1 = empty seat) for the next two kernels
+  hipLaunchKernelGGL(dh::split_align_kernel<KP>, dim3(std::min(seats, 1024)), dim3(dh::WAVE), 0, s, a);
+  if (mid) (void)hipEventRecord(mid, s);
+  hipLaunchKernelGGL(dh::split_post_kernel<KP>, dim3(balanced(seats)), dim3(dh::WAVE), 0, s, a);
+}
+
 // Launches the split-alignment kernels for every K bin of the batch.
 int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   int rc;
@@ -228,6 +253,20 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
       case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
       case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
       default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  for (int KQ = 1; KQ <= 5 && !b->qbin_count.empty(); ++KQ) {
+    const int cnt = b->qbin_count[KQ], np = b->qbin_pairs[KQ];
+    if (cnt + np == 0) continue;
+    any_bin = true;
+    a.work_list = b->work.p + b->qbin_first[KQ];
+    switch (KQ) {
+      case 1: launch_quad<1, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 2: launch_quad<2, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 3: launch_quad<3, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 4: launch_quad<4, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      default: launch_quad<5, 3>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
     }
     HIPCHK(hipGetLastError());
   }
@@ -391,6 +430,10 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
   std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
+  std::vector<std::vector<std::pair<int, int>>> qbins(7);
+  b->qbin_first.assign(7, 0);
+  b->qbin_count.assign(7, 0);
+  b->qbin_pairs.assign(7, 0);
   std::vector<int32_t> ins, lrv, lriv;
   const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
@@ -412,7 +455,11 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     }
     long span = (long)J.sv_end - (long)J.sv_start;
     int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
-    bins[kk].push_back(std::make_pair(approx, i));
+    if (!b->h_win_len.empty()) approx = b->h_win_len[i];
+    if (b->use_quad && !direct && m + 1 <= dh::HALF * 5 && approx <= dh::QNMAX) {
+      const int kq = std::max(1, (m + 1 + dh::HALF - 1) / dh::HALF);
+      qbins[kq].push_back(std::make_pair(approx, i));
+    } else bins[kk].push_back(std::make_pair(approx, i));
   }
   std::vector<int32_t> work;
   work.reserve(b->n + 2 * dh::KMAX);
@@ -426,6 +473,39 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     }
     b->bin_count[K] = (int)work.size() / 2 - b->bin_first[K];
   }
+  for (int KQ = 1; KQ <= 5; ++KQ) {
+    auto& v = qbins[KQ];
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+    b->qbin_first[KQ] = (int)work.size();
+    // All junctions of the bin are seated four per wavefront.  (Topping whole rounds of quad wavefronts up
+    // with pair items -- which the kernel supports -- was measured on MI355X: 6 % faster at 40 000 junctions,
+    // 9 % slower at 10 000, where neither variant fills the SIMDs; DELLYHIP_QUAD_MIX=1 enables it.)
+    const int N = (int)v.size(), S = std::max(1, b->n_simd);
+    int best_q = (N + 3) / 4;
+    if (b->quad_mix) {
+      long best_cost = -1;
+      const int qmax = (N + 3) / 4;
+      for (int q = (qmax / S) * S; q >= 0 && q >= qmax - 2 * S; q -= S) {   // whole rounds below qmax, and qmax itself
+        for (int cand : {q, qmax}) {
+          if (cand < 0 || cand > qmax) continue;
+          const int rest = std::max(0, N - 4 * cand), pairs = (rest + 1) / 2;
+          const long cost = 3L * ((cand + S - 1) / S) + 2L * ((pairs + S - 1) / S);   // instructions per wavefront ~ 3 : 2
+          if (best_cost < 0 || cost < best_cost || (cost == best_cost && cand > best_q)) { best_cost = cost; best_q = cand; }
+        }
+        if (q == 0) break;
+      }
+    }
+    size_t pos = 0;
+    for (int q = 0; q < best_q; ++q)
+      for (int t = 0; t < 4; ++t, ++pos) work.push_back(pos < v.size() ? v[pos].second : -1);
+    b->qbin_count[KQ] = best_q;
+    int np = 0;
+    for (; pos < v.size(); pos += 2, ++np) {
+      work.push_back(v[pos].second);
+      work.push_back(pos + 1 < v.size() ? v[pos + 1].second : -1);
+    }
+    b->qbin_pairs[KQ] = np;
+  }
   b->ins_first = (int)work.size();
   b->ins_count = (int)ins.size();
   work.insert(work.end(), ins.begin(), ins.end());
@@ -435,7 +515,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->lri_first = (int)work.size();
   b->lri_count = (int)lriv.size();
   work.insert(work.end(), lriv.begin(), lriv.end());
-  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 2));
+  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 32));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
@@ -525,6 +605,8 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   c->device = device;
   c->params = *params;
   c->n_cu = prop.multiProcessorCount;
+  if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
+  if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -595,6 +677,9 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->n_seq = n_seq;
   b->with_msa = with_msa;
   b->want_alignment = want_alignment;
+  b->use_quad = c->use_quad;
+  b->quad_mix = c->quad_mix;
+  b->n_simd = c->n_cu * 4;
   b->h_junc.assign(junc, junc + n);
   int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
   if (!with_msa) {  // |svRefStr| per junction; long-read shapes get larger output slots and a workspace

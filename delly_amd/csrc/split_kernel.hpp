@@ -108,12 +108,16 @@ __device__ __forceinline__ uint8_t outmap(uint8_t ch) {
 // forward strings only (packed DP kernel: reverse complements are derived on the fly)
 struct __attribute__((aligned(16))) StrLdsFwd {
   static constexpr bool has_rc = false;
+  static constexpr int ref_cap = NMAX;
+  static constexpr int cons_cap = MMAX + 1;
   uint8_t cons[MMAX + 1];   // s1
   uint8_t ref[NMAX];        // s2 = svRefStr
 };
 // strings of one junction (LDS)
 struct __attribute__((aligned(16))) StrLds {
   static constexpr bool has_rc = true;
+  static constexpr int ref_cap = NMAX;
+  static constexpr int cons_cap = MMAX + 1;
   uint8_t cons[MMAX + 1];   // s1
   uint8_t rcons[MMAX + 1];  // reverseComplement(s1), util.h:549-563 semantics
   uint8_t ref[NMAX];        // s2 = svRefStr

@@ -171,7 +171,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     status = prior;
     mlimit = true;
     go = false;
-  } else if (m < 0 || m > MMAX || m + 1 > WAVE * K) {
+  } else if (m < 0 || m > MMAX || m + 1 > WAVE * K || m + 1 > STR::cons_cap) {
     status = DELLYHIP_E_LIMIT;
     mlimit = true;
     go = false;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
   int nseg = 0, n = 0;
   if (go && X.direct) {
     n = A.ref_len[j];
-    if (n > NMAX || n < 0) { status = DELLYHIP_E_LIMIT; go = false; }
+    if (n > STR::ref_cap || n < 0) { status = DELLYHIP_E_LIMIT; go = false; }
     else {
       const uint8_t* rg = A.ref_base + A.ref_off[j];
       for (int i = lane; i < n; i += WAVE) S.ref[i] = rg[i];
@@ -204,7 +204,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     for (int q = 0; q < nseg; ++q) n += seg[q].len;
-    if (go && (n > NMAX || (INS && n < 3))) {  // (splitAlign indexes distRev[n-2]: n < 3 is outside its domain)
+    if (go && (n > STR::ref_cap || (INS && n < 3))) {  // (splitAlign indexes distRev[n-2]: n < 3 is outside its domain)
       status = DELLYHIP_E_LIMIT;
       go = false;
     }

@@ -42,9 +42,10 @@ _lib = None
 def load_library():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("DELLYHIP_LIB", LIB_PATH)   # (override: A/B runs of tuning builds)
+        if not os.path.exists(path):
             raise DellyHipError(abi.E_NODEVICE, "libdellyhip.so is not built (run __graft_entry__.build())")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         lib.dellyhip_last_error.restype = C.c_char_p
         lib.dellyhip_batch_free.restype = None
         lib.dellyhip_destroy.restype = None
