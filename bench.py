@@ -215,7 +215,7 @@ def main():
                        "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "split_pair_kernel<3> (packed longNeedle DP, 2 junctions per wavefront)",
+                         "kernel": "split_quad_kernel<5,3> (packed int16 longNeedle DP, 4 junctions per wavefront)",
                          "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
                          "gcups": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
