@@ -95,7 +95,7 @@ def side_measurements(ctx, synth, device=0, steps=3):
     resident batch, whole-step wall clock."""
     out = {}
     from delly_amd import abi, refine
-    for name, n, kw in (("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
+    for name, n, kw in (("u_c2_40k_junctions", 40000, dict(mode="c2")), ("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
                         ("ins_svt4", 5000, dict(mode="ins")), ("lr_c4_align_consensus", 2048, dict(mode="lr", sub_rate=0.01)),
                         ("lr_c4_msaedlib_n15", 768, dict(mode="lr", n_reads=15, sub_rate=0.06))):
         b = synth.make_batch(n, **kw)
