@@ -463,6 +463,16 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   }
   std::vector<int32_t> work;
   work.reserve(b->n + 2 * dh::KMAX);
+  // A quad bin KQ and the pair bin KP = (KQ + 1) / 2 run in ONE launch of split_quad_kernel<KQ, KP> (quad items
+  // first, pair items behind them): independent bins launched one after the other would each pay the
+  // ~1 ms a single DP wavefront takes, whatever their size.
+  std::vector<std::vector<std::pair<int, int>>> qextra(7);
+  for (int KQ = 5; KQ >= 1; --KQ) {
+    const int KP = (KQ + 1) / 2;
+    if (!qbins[KQ].empty() && !bins[KP].empty()) {
+      qextra[KQ].swap(bins[KP]);
+    }
+  }
   for (int K = 1; K <= dh::KMAX; ++K) {
     auto& v = bins[K];
     std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
@@ -504,6 +514,12 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
       work.push_back(v[pos].second);
       work.push_back(pos + 1 < v.size() ? v[pos + 1].second : -1);
     }
+    auto& x = qextra[KQ];   // the merged pair bin
+    std::stable_sort(x.begin(), x.end(), [](const std::pair<int, int>& p1, const std::pair<int, int>& p2) { return p1.first > p2.first; });
+    for (size_t q = 0; q < x.size(); q += 2, ++np) {
+      work.push_back(x[q].second);
+      work.push_back(q + 1 < x.size() ? x[q + 1].second : -1);
+    }
     b->qbin_pairs[KQ] = np;
   }
   b->ins_first = (int)work.size();
@@ -515,7 +531,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->lri_first = (int)work.size();
   b->lri_count = (int)lriv.size();
   work.insert(work.end(), lriv.begin(), lriv.end());
-  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 32));
+  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 64));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
