@@ -879,7 +879,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     // "take care of small inversions" (src/assemble.h:840-848): align only the middle svSize letters
     {
       std::vector<SmallInv> si;
-      std::vector<uint64_t> coff;
+      std::vector<uint64_t> coffs;
+      std::vector<int32_t> takes;
       for (int i = 0; i < b->n; ++i) {
         const dellyhip_junction& J = b->h_junc[i];
         const int32_t svSize = J.sv_end - J.sv_start, m = b->h_cons_len[i];
@@ -889,12 +890,14 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
           const int32_t take = std::min<int32_t>(std::max(svSize, 0), m - off);
           si.push_back(SmallInv{i, m, off});
           b->h_cons_len[i] = take;
-          const uint64_t co = (uint64_t)i * b->out_stride + (uint64_t)off;
-          HIPCHK(hipMemcpyAsync(b->cons_off.p + i, &co, sizeof co, hipMemcpyHostToDevice, s));
-          HIPCHK(hipMemcpyAsync(b->cons_len.p + i, &take, sizeof take, hipMemcpyHostToDevice, s));
+          coffs.push_back((uint64_t)i * b->out_stride + (uint64_t)off);
+          takes.push_back(take);
         }
       }
-      HIPCHK(hipStreamSynchronize(s));   // (the pageable sources above go out of scope)
+      for (size_t k = 0; k < si.size(); ++k) {   // (sources stay alive until the synchronous copies return)
+        HIPCHK(hipMemcpy(b->cons_off.p + si[k].j, &coffs[k], sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->cons_len.p + si[k].j, &takes[k], sizeof(int32_t), hipMemcpyHostToDevice));
+      }
       b->small_inv_n = (int)si.size();
       if (b->small_inv_n) {
         if ((rc = b->small_inv.reserve(si.size()))) return rc;

@@ -98,13 +98,14 @@ struct LmKeys {
 constexpr int LM_HW = 1;    // E[r][0] = 0 (edlib HW: the query may start anywhere in the target)
 constexpr int LM_EQ = 2;    // extended-IUPAC additional equalities
 
-template <bool DIRS, bool LOC>
-__device__ __noinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
-                                       int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
-                                       int lane) {
+template <bool DIRS, bool LOC, bool EQ>
+__device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
+                                         int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
+                                         int lane) {
   constexpr int K = LRK;
   constexpr int POS = 1 << 28;
-  const bool hw = (mode & LM_HW) != 0, useeq = (mode & LM_EQ) != 0;
+  const bool hw = (mode & LM_HW) != 0;
+  constexpr bool useeq = EQ;
   int a[K], h[K], colq[K];
   uint32_t part[K], acc[K];
 #pragma unroll
@@ -126,7 +127,13 @@ __device__ __noinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, c
   int c = -lane;
   int outv = 0;
   // block blk+1's letters / boundary values are loaded while block blk computes
-  auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < qlen) ? (int)qp[ci * qstep] : NOMATCH; };
+  // (EQ: the letter travels with its equality-class index in bits 16.., decoded once per 16 steps here
+  // instead of once per step in the loop)
+  auto ld_chunk = [&](int blk) {
+    const int ci = blk * 16 + (lane & 15);
+    const int ch = (ci < qlen) ? (int)qp[ci * qstep] : NOMATCH;
+    return EQ ? (ch | ((iupac_index(ch) + 1) << 16)) : ch;
+  };
   auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= qlen) ? bin[ci + 1] : POS; };
   int chunk = ld_chunk(0), bchunk = ld_bnd(0);
   for (int blk = 0; blk < nblk; ++blk) {
@@ -139,12 +146,12 @@ __device__ __noinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, c
       const int recv = dpp_from_prev(h[K - 1], bnd);
       c += 1;
       if ((unsigned)(c - 1) < (unsigned)qlen) {
-        const int iy = useeq ? iupac_index(b) : -1;
-        const uint32_t ybit = (iy >= 0) ? (1u << iy) : 0u;
+        const uint32_t ybit = EQ ? ((1u << ((uint32_t)b >> 16)) >> 1) : 0u;   // class index + 1 in bits 16.. (0: none)
+        const int bl = EQ ? (b & 0xffff) : b;
         int diag = upPrev, up = recv;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-          const bool eq = (a[i] == b) || ((part[i] & ybit) != 0u);
+          const bool eq = EQ ? ((a[i] == bl) || ((part[i] & ybit) != 0u)) : (a[i] == bl);
           const int x = diag + (eq ? 0 : 1);
           const int y = up + 1;     // consumes a target letter only : DELETE
           const int z = h[i] + 1;   // consumes a query letter only  : INSERT
@@ -202,6 +209,16 @@ __device__ __noinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, c
     k.kl = (unsigned)rfl((int)kl);
   }
   return k;
+}
+
+// the extended-IUPAC equality logic is compiled only into the instances that need it (msaEdlib / msaWfa
+// progressive alignments); splitAlign and the superstring use plain byte equality
+template <bool DIRS, bool LOC>
+__device__ __forceinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
+                                          int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
+                                          int lane) {
+  if (mode & LM_EQ) return lm_pass_t<DIRS, LOC, true>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
+  return lm_pass_t<DIRS, LOC, false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
 }
 
 // row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
