@@ -98,14 +98,17 @@ struct LmKeys {
 constexpr int LM_HW = 1;    // E[r][0] = 0 (edlib HW: the query may start anywhere in the target)
 constexpr int LM_EQ = 2;    // extended-IUPAC additional equalities
 
-template <bool DIRS, bool LOC, bool EQ>
+// EQ: 0 plain byte equality; 1 equality classes, every letter of both strings is one of the 15 class
+// letters (then "same letter" is "shares a class bit": no byte compare); 2 equality classes + byte compare
+// (a string holds a letter outside the 15, e.g. N)
+template <bool DIRS, bool LOC, int EQ>
 __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
                                          int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
                                          int lane) {
   constexpr int K = LRK;
   constexpr int POS = 1 << 28;
   const bool hw = (mode & LM_HW) != 0;
-  constexpr bool useeq = EQ;
+  constexpr bool useeq = EQ != 0;
   int a[K], h[K], colq[K];
   uint32_t part[K], acc[K];
 #pragma unroll
@@ -115,7 +118,7 @@ __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen,
     h[i] = (r >= 0) ? (hw ? 0 : r) : POS;
     colq[i] = h[i];
     const int ix = useeq ? iupac_index(a[i]) : -1;
-    part[i] = iupac_partners(ix);
+    part[i] = iupac_partners(ix) | ((EQ == 1 && ix >= 0) ? (1u << ix) : 0u);   // (EQ 1: the letter's own bit too)
     acc[i] = 0;
   }
   const int lastrow = min(LRS - 1, tlen + pad - q * LRS);   // local slot of the last real row in this strip
@@ -151,7 +154,8 @@ __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen,
         int diag = upPrev, up = recv;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-          const bool eq = EQ ? ((a[i] == bl) || ((part[i] & ybit) != 0u)) : (a[i] == bl);
+          const bool eq = (EQ == 1) ? ((part[i] & ybit) != 0u)
+                                    : (EQ == 2) ? ((a[i] == bl) || ((part[i] & ybit) != 0u)) : (a[i] == bl);
           const int x = diag + (eq ? 0 : 1);
           const int y = up + 1;     // consumes a target letter only : DELETE
           const int z = h[i] + 1;   // consumes a query letter only  : INSERT
@@ -213,12 +217,25 @@ __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen,
 
 // the extended-IUPAC equality logic is compiled only into the instances that need it (msaEdlib / msaWfa
 // progressive alignments); splitAlign and the superstring use plain byte equality
+// true when every letter of s[0..n) (stride `step`) is one of the 15 equality-class letters
+__device__ __forceinline__ bool lm_in_classes(const uint8_t* sp, int step, int n, int lane) {
+  int bad = 0;
+  for (int i = lane; i < n; i += WAVE) bad |= (iupac_index((int)sp[i * step]) < 0) ? 1 : 0;
+  return __ballot(bad) == 0ull;
+}
+
+// the equality logic is compiled only into the instances that need it (msaEdlib / msaWfa progressive
+// alignments); splitAlign and the superstring use plain byte equality.  mode bit LM_EQFAST (set by the
+// caller after lm_in_classes) selects the compare-free variant.
+constexpr int LM_EQFAST = 4;
 template <bool DIRS, bool LOC>
 __device__ __forceinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
                                           int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
                                           int lane) {
-  if (mode & LM_EQ) return lm_pass_t<DIRS, LOC, true>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
-  return lm_pass_t<DIRS, LOC, false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
+  if ((mode & LM_EQ) && (mode & LM_EQFAST))
+    return lm_pass_t<DIRS, LOC, 1>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
+  if (mode & LM_EQ) return lm_pass_t<DIRS, LOC, 2>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
+  return lm_pass_t<DIRS, LOC, 0>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
 }
 
 // row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
@@ -230,7 +247,7 @@ __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tl
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : row_out;
-    (void)lm_pass<false, false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode & LM_EQ, 0, bin, bout, nullptr, lane);
+    (void)lm_pass<false, false>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode & (LM_EQ | LM_EQFAST), 0, bin, bout, nullptr, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -248,7 +265,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
-    (void)lm_pass<true, false>(t, 1, tlen, qy, 1, qlen, q, 0, mode & LM_EQ, 0, bin, bout, dirs + (size_t)q * strip_words, lane);
+    (void)lm_pass<true, false>(t, 1, tlen, qy, 1, qlen, q, 0, mode & (LM_EQ | LM_EQFAST), 0, bin, bout, dirs + (size_t)q * strip_words, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -367,7 +384,7 @@ __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* 
                                        uint8_t* ops, int ops_cap, int lane) {
   LmRes o;
   int first, last;
-  lm_locate(T, 1, tn, Qy, 1, qn, (mode & LM_EQ) | LM_HW, bnd, bnd + bnd_stride, lane, o.ed, first, last);
+  lm_locate(T, 1, tn, Qy, 1, qn, (mode & (LM_EQ | LM_EQFAST)) | LM_HW, bnd, bnd + bnd_stride, lane, o.ed, first, last);
   o.endLoc = first - 1;
   o.startLoc = 0;
   o.nops = 0;
@@ -377,7 +394,7 @@ __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* 
     return o;
   }
   int ed2, f2, l2;
-  lm_locate(T + o.endLoc, -1, o.endLoc + 1, Qy + (qn - 1), -1, qn, mode & LM_EQ, bnd, bnd + bnd_stride, lane, ed2, f2, l2);
+  lm_locate(T + o.endLoc, -1, o.endLoc + 1, Qy + (qn - 1), -1, qn, mode & (LM_EQ | LM_EQFAST), bnd, bnd + bnd_stride, lane, ed2, f2, l2);
   o.startLoc = o.endLoc - (l2 - 1);
   if (!path) return o;
   const int tl2 = o.endLoc - o.startLoc + 1;
@@ -385,7 +402,7 @@ __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* 
     o.nops = lm_fill_inserts(ops, qn, lane);
     return o;
   }
-  o.nops = lm_nw_path(T + o.startLoc, tl2, Qy, qn, mode & LM_EQ, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
+  o.nops = lm_nw_path(T + o.startLoc, tl2, Qy, qn, mode & (LM_EQ | LM_EQFAST), bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
   return o;
 }
 
@@ -395,11 +412,11 @@ __device__ __forceinline__ LmRes lm_shw(const uint8_t* T, int tn, const uint8_t*
                                         int ops_cap, int lane) {
   LmRes o;
   int first, last;
-  lm_locate(T, 1, tn, Qy, 1, qn, mode & LM_EQ, bnd, bnd + bnd_stride, lane, o.ed, first, last);
+  lm_locate(T, 1, tn, Qy, 1, qn, mode & (LM_EQ | LM_EQFAST), bnd, bnd + bnd_stride, lane, o.ed, first, last);
   o.endLoc = first - 1;
   o.startLoc = 0;
   if (o.endLoc == -1) o.nops = lm_fill_inserts(ops, qn, lane);
-  else o.nops = lm_nw_path(T, o.endLoc + 1, Qy, qn, mode & LM_EQ, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
+  else o.nops = lm_nw_path(T, o.endLoc + 1, Qy, qn, mode & (LM_EQ | LM_EQFAST), bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, lane);
   return o;
 }
 
@@ -522,7 +539,8 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int rd = L.sel[step];
         const uint8_t* qy = blob + L.roff[rd];
         const int qn = L.rlen[rd];
-        const int nops = lm_nw_path(astr, acols, qy, qn, LM_EQ, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
+        const int eqmode = LM_EQ | ((lm_in_classes(astr, 1, acols, lane) && lm_in_classes(qy, 1, qn, lane)) ? LM_EQFAST : 0);
+        const int nops = lm_nw_path(astr, acols, qy, qn, eqmode, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
         if (nops < 0 || nops > acap - 1) { status = DELLYHIP_E_LIMIT; break; }   // (the next target must fit the strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

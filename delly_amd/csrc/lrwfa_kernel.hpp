@@ -368,7 +368,8 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int rd = L.sel[step];
         const uint8_t* qy = blob + L.roff[rd];
         const int qn = L.rlen[rd];
-        const LmRes h = lm_hw(astr, acols, qy, qn, LM_EQ, true, true, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+        const int eqmode = LM_EQ | ((lm_in_classes(astr, 1, acols, lane) && lm_in_classes(qy, 1, qn, lane)) ? LM_EQFAST : 0);
+        const LmRes h = lm_hw(astr, acols, qy, qn, eqmode, true, true, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
         if (h.nops < 0) { status = DELLYHIP_E_LIMIT; break; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
