@@ -89,18 +89,33 @@ def _subbatch(batch, n):
                        batch.with_msa, batch.truth[:n])
 
 
-def side_measurements(ctx, synth, device=0, steps=3):
-    """Not the headline: what `delly sr` pays per junction (U_full = msa of N reads +
-    alignConsensus) and the insertion path (splitAlign/edlib), each over a
-    resident batch, whole-step wall clock."""
-    out = {}
+def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
+    """Not the headline: what `delly sr` / `delly lr` pay per junction beyond unit U -- msa of N reads +
+    alignConsensus (U_full), the insertion path (splitAlign/edlib) and the long-read shapes
+    of BASELINE config C4 -- each over a resident batch, whole-step wall clock.  with_cpu: the same
+    workloads through the CPU checker (oracle/_ref = the reference's own code, else the C port) on a small
+    bounded sample with all host threads; this is part of bench.py's cpu_baseline leg."""
     from delly_amd import abi, refine
-    for name, n, kw in (("u_c2_40k_junctions", 40000, dict(mode="c2")), ("u_full_n20", 2000, dict(mode="c2", n_reads=20)), ("u_full_n5", 2000, dict(mode="c2", n_reads=5)),
-                        ("ins_svt4", 5000, dict(mode="ins")), ("lr_c4_align_consensus", 2048, dict(mode="lr", sub_rate=0.01)),
-                        ("lr_c4_msaedlib_n15", 768, dict(mode="lr", n_reads=15, sub_rate=0.06))):
+    orc = None
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        orc = pyoracle.Oracle("reference" if pyoracle.have_reference() else "port")
+    cores = os.cpu_count() or 1
+    out = {}
+    #        name                       n      cpu sample   batch kwargs
+    plan = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
+            ("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
+            ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
+            ("ins_svt4", 5000, 5000, dict(mode="ins")),
+            ("lr_c4_align_consensus", 2048, 96, dict(mode="lr", sub_rate=0.01)),
+            ("lr_c4_msaedlib_n15", 768, 48, dict(mode="lr", n_reads=15, sub_rate=0.06)))
+    for name, n, ncpu, kw in plan:
         b = synth.make_batch(n, **kw)
-        if name == "lr_c4_align_consensus":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
-            ctx = refine.Context(params=abi.params_lr(realign=True), device=device)
+        lr = kw["mode"] == "lr"
+        params = abi.params_lr(realign=True) if lr else abi.params_sr()
+        if lr and name == "lr_c4_align_consensus":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
+            ctx = refine.Context(params=params, device=device)
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()
@@ -114,6 +129,18 @@ def side_measurements(ctx, synth, device=0, steps=3):
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
                      "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
         rb.free()
+        if orc is not None and ncpu > 0:
+            sub = b if ncpu >= n else synth.make_batch(ncpu, **kw)
+            t0 = time.perf_counter()
+            orc.refine_batch(sub, want_alignment=False, n_threads=cores, params=params)
+            first = time.perf_counter() - t0
+            reps = int(max(1, min(40, 1.5 / max(first, 1e-3))))   # ~1.5 s of CPU work per workload
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                orc.refine_batch(sub, want_alignment=False, n_threads=cores, params=params)
+            dtc = (time.perf_counter() - t0) / reps
+            out[name]["cpu_" + orc.kind] = {"junctions_per_s": sub.n / dtc, "cores": cores,
+                                            "sample": "%d x %d junctions, %.2f s each" % (reps, sub.n, dtc)}
     return out
 
 
@@ -229,7 +256,7 @@ def main():
         if world == 1 and not args.no_extras:
             rb.free()
             rb = None
-            out["extras"] = side_measurements(ctx, synth, device=local)
+            out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if rb is not None:
         rb.free()

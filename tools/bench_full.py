@@ -1,4 +1,6 @@
-"""U_full micro-benchmark: msa() + alignConsensus() per junction (what `delly sr` pays), resident batch."""
+"""Side benchmarks on a resident batch: mode c2/mixed/ins/lr, n_reads 0 = given consensus (unit U),
+>0 = msa stage + alignConsensus (U_full; lr: msaEdlib).  GPU only; the CPU reference numbers quoted in
+DESIGN.md come from bench.py (cpu_baseline and the reference legs of its extras)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,18 +26,3 @@ ms_split, ms_msa, _ = rb.kernel_ms()
 res, _ = rb.fetch()
 print(mode + " n=%d reads=%d: %.2f ms/step -> %.0f junctions/s | msa kernel %.2f ms, split %.2f ms | ok %d mean cons %.0f" % (
     n, nreads, dt * 1e3, n / dt, ms_msa, ms_split, int(res["ok"].sum()), res["cons_len"].mean()), flush=True)
-
-if len(sys.argv) > 5:  # CPU reference beside it (oracle/_ref, all host threads) -- test infrastructure, not the product
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    import pyoracle
-    kind = "reference" if pyoracle.have_reference() else "port"
-    O = pyoracle.Oracle(kind)
-    if params is not None:
-        O.params = params
-    for th in (1, os.cpu_count()):
-        k = min(n, 2048 if mode != "lr" else 256) if th > 1 else min(n, 128 if mode != "lr" else 4)
-        s1 = synth.make_batch(k, mode=mode, n_reads=nreads, **kw)
-        t = time.perf_counter()
-        O.refine_batch(s1, want_alignment=False, n_threads=th)
-        dt = time.perf_counter() - t
-        print("cpu %s threads=%d: %d junctions in %.2f s -> %.0f junctions/s" % (kind, th, k, dt, k / dt), flush=True)
