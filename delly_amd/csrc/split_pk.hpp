@@ -136,7 +136,7 @@ __device__ __forceinline__ void pass_R2(const StrLdsFwd& SA, const StrLdsFwd& SB
           pk sc = pk_shr(b, rsh[i]) & two2;
           pk x = pk_add(diag, sc);
           pk z = pk_add(h[i], hg[i]);
-          pk nv = pk_max(pk_max(x, up), z);
+          pk nv = pk_max(pk_max(x, z), up);   // (x, z do not depend on the row above: one dependent op per row)
           diag = h[i];
           up = nv;
           h[i] = nv;
@@ -237,7 +237,7 @@ __device__ __forceinline__ void pass_M2(const StrLdsFwd& SA, const StrLdsFwd& SB
           pk sc = pk_shr(b, rsh[i]) & two2;
           pk x = pk_add(diag, sc);
           pk z = pk_add(h[i], hg[i]);
-          pk nv = pk_max(pk_max(x, up), z);
+          pk nv = pk_max(pk_max(x, z), up);   // (x, z do not depend on the row above: one dependent op per row)
           diag = h[i];
           up = nv;
           h[i] = nv;

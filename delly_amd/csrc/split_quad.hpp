@@ -81,7 +81,7 @@ __device__ __forceinline__ void pass_R4(const StrLdsQ* SLo, const StrLdsQ* SHi, 
           const pk sc = pk_shr(b, rsh[i]) & two2;
           const pk x = pk_add(diag, sc);
           const pk z = pk_add(h[i], hg[i]);
-          const pk nv = pk_max(pk_max(x, up), z);
+          const pk nv = pk_max(pk_max(x, z), up);   // (x, z do not depend on the row above: one dependent op per row)
           diag = h[i];
           up = nv;
           h[i] = nv;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void pass_M4(const StrLdsQ* SLo, const StrLdsQ* SHi, 
           const pk sc = pk_shr(b, rsh[i]) & two2;
           const pk x = pk_add(diag, sc);
           const pk z = pk_add(h[i], hg[i]);
-          const pk nv = pk_max(pk_max(x, up), z);
+          const pk nv = pk_max(pk_max(x, z), up);   // (x, z do not depend on the row above: one dependent op per row)
           diag = h[i];
           up = nv;
           h[i] = nv;
