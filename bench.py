@@ -110,6 +110,38 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
             ("ins_svt4", 5000, 5000, dict(mode="ins")),
             ("lr_c4_align_consensus", 2048, 96, dict(mode="lr", sub_rate=0.01)),
             ("lr_c4_msaedlib_n15", 768, 48, dict(mode="lr", n_reads=15, sub_rate=0.06)))
+    # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
+    # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
+    try:
+        import torch
+        ctx2 = refine.Context(device=device)
+        pairs = []
+        for cx, first in ((ctx, 0), (ctx2, 10000)):
+            bb = synth.make_batch(10000, mode="c2", first=first)
+            cx.set_chromosomes(bb.chroms)
+            pairs.append((cx.upload(bb), torch.cuda.Stream(device=device)))
+        for _ in range(2):
+            for rb, st in pairs:
+                rb.run(st.cuda_stream)
+        for rb, _ in pairs:
+            rb.sync()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for rb, st in pairs:
+                rb.run(st.cuda_stream)
+        for rb, _ in pairs:
+            rb.sync()
+        dt = (time.perf_counter() - t0) / (2 * reps)
+        ok = sum(int(rb.fetch()[0]["ok"].sum()) for rb, _ in pairs)
+        out["u_c2_two_batches_in_flight"] = {"junctions": 10000, "junctions_per_s": 10000 / dt, "ms_per_step": dt * 1e3,
+                                             "refined_ok": ok,
+                                             "note": "two contexts, each with a resident 10 000-junction batch, alternating on two HIP streams"}
+        for rb, _ in pairs:
+            rb.free()
+        ctx2.close()
+    except Exception as e:  # side figure only
+        out["u_c2_two_batches_in_flight"] = {"error": repr(e)}
     for name, n, ncpu, kw in plan:
         b = synth.make_batch(n, **kw)
         lr = kw["mode"] == "lr"

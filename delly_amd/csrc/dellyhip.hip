@@ -79,6 +79,9 @@ struct dellyhip_ctx {
   uint64_t scratch_words = 0;
   int scratch_blocks = 0;
   DevBuf<int32_t> counters;  // work counters (one per K bin + MSA)
+  hipEvent_t serial_ev = nullptr;  // end of the last batch_run: runs of one context share its scratch area, so a run on
+                                   // another stream first waits for it (overlap batches with one context per stream)
+  bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
@@ -642,6 +645,7 @@ void dellyhip_destroy(dellyhip_ctx* c) {
   c->d_chr_len.release();
   c->scratch.release();
   c->counters.release();
+  if (c->serial_ev) (void)hipEventDestroy(c->serial_ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -841,6 +845,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreate(&e3[q]));
   for (int q = 0; q < 4; ++q) b->ev.push_back(e3[q]);
   b->mid = e3[3];
+  if (!c->serial_ev) HIPCHK(hipEventCreateWithFlags(&c->serial_ev, hipEventDisableTiming));
+  if (c->serial_valid) HIPCHK(hipStreamWaitEvent(s, c->serial_ev, 0));
   HIPCHK(hipEventRecord(e3[0], s));
   if (b->with_msa == 2) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
@@ -954,6 +960,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(e3[2], s));
+  HIPCHK(hipEventRecord(c->serial_ev, s));
+  c->serial_valid = true;
   b->last = e3[2];
   b->pending = true;
   b->launches++;

@@ -160,7 +160,11 @@ int dellyhip_align_consensus_batch(dellyhip_ctx* ctx, int32_t n_junctions,
 /* Uploads a batch once; run_resident() then executes the same work as
  * dellyhip_align_consensus_batch / dellyhip_refine_batch with inputs already in
  * HBM and results left in HBM; fetch_results() copies them back. `stream` is a
- * hipStream_t passed as void* (0 = the context's own stream). */
+ * hipStream_t passed as void* (0 = the context's own stream).  with_msa: 0 = the
+ * consensus is given (unit U), 1 = msa() first (short reads), 2 = the long-read
+ * loop body (msaEdlib / msaWfa, see dellyhip_refine_batch_lr).  Runs of ONE context
+ * share its scratch area and are ordered after each other even across streams;
+ * to overlap batches use one context per stream. */
 typedef struct dellyhip_batch dellyhip_batch;
 int dellyhip_batch_upload(dellyhip_ctx* ctx, int32_t n_junctions,
                           const dellyhip_junction* junctions, const char* seq_blob,
