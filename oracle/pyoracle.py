@@ -212,7 +212,7 @@ class Oracle:
         chr_ptrs = (C.c_char_p * nchr)(*[C.cast(c.ctypes.data, C.c_char_p) for c in batch.chroms])
         chr_len = np.array([c.size for c in batch.chroms], dtype=np.int64)
         res = np.zeros(n, dtype=abi.result_dtype())
-        cap = int(batch.seq_blob.size) + n * 4096 + (int(batch.seq_blob.size) * 2 + n * 8192 if want_alignment else 0)
+        cap = int(batch.seq_blob.size) * 3 + n * 16384 + (int(batch.seq_blob.size) * 16 + n * 65536 if want_alignment else 0)
         out = np.zeros(cap, dtype=np.uint8)
         used = C.c_uint64(0)
         junc = np.ascontiguousarray(batch.junctions)
