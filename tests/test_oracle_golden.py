@@ -108,6 +108,23 @@ def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
     compare(pr, pb, rr, rb, label="port-vs-reference")
 
 
+@pytest.mark.parametrize("mode", ["c2", "mixed", "ins"])
+def test_fuzz_port_vs_reference(port, reference, mode):
+    """perturbed breakpoint estimates / consensus sequences under unusual parameter sets, and reference windows
+    clipped at the chromosome ends (tests/fuzz.py); the same inputs go through the HIP path in tests/test_gpu_fuzz.py"""
+    import fuzz
+    for pi in range(4):
+        p = fuzz.params_of(pi)
+        b = fuzz.perturbed(240, 5 + pi, mode)
+        rr, rb = reference.refine_batch(b, params=p)
+        pr, pb = port.refine_batch(b, params=p)
+        compare(pr, pb, rr, rb, label="fuzz %s/%d" % (mode, pi))
+    for b in fuzz.clipped(60, 3, mode):
+        rr, rb = reference.refine_batch(b)
+        pr, pb = port.refine_batch(b)
+        compare(pr, pb, rr, rb, label="clipped " + mode)
+
+
 def test_port_multithreaded_matches_single(port):
     b = synth.make_batch(64, mode="mixed", seed=5)
     r1, b1 = port.refine_batch(b, n_threads=1, want_alignment=False)
