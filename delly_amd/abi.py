@@ -95,11 +95,42 @@ class Result(C.Structure):
     ]
 
 
+class AlignJob(C.Structure):
+    """dellyhip_align_job: AlignJob of src/coverage.h:87-96 with the strings as blob ranges."""
+    _fields_ = [
+        ("cons_off", C.c_uint64),
+        ("ref_off", C.c_uint64),
+        ("seq_off", C.c_uint64),
+        ("cons_len", C.c_uint32),
+        ("ref_len", C.c_uint32),
+        ("seq_len", C.c_uint32),
+        ("file_index", C.c_uint32),
+        ("sv_id", C.c_uint32),
+        ("qual", C.c_uint8),
+        ("pad0", C.c_uint8),
+        ("pad1", C.c_uint8),
+        ("pad2", C.c_uint8),
+    ]
+
+
+class AlignResult(C.Structure):
+    """dellyhip_align_result: AlignResult of src/coverage.h:98-105 plus the two edlib distances."""
+    _fields_ = [
+        ("file_index", C.c_uint32),
+        ("sv_id", C.c_uint32),
+        ("dist_alt", C.c_int32),
+        ("dist_ref", C.c_int32),
+        ("type", C.c_uint8),
+        ("qual", C.c_uint8),
+        ("status", C.c_int16),
+    ]
+
+
 # numpy structured dtypes with the same layout (for vectorised comparisons)
 def _np_dtype(struct):
     import numpy as np
 
-    m = {C.c_int32: "<i4", C.c_uint64: "<u8", C.c_float: "<f4"}
+    m = {C.c_int32: "<i4", C.c_uint64: "<u8", C.c_float: "<f4", C.c_uint32: "<u4", C.c_uint8: "u1", C.c_int16: "<i2"}
     names, formats, offsets = [], [], []
     for name, typ in struct._fields_:
         names.append(name)
@@ -115,3 +146,11 @@ def junction_dtype():
 
 def result_dtype():
     return _np_dtype(Result)
+
+
+def align_job_dtype():
+    return _np_dtype(AlignJob)
+
+
+def align_result_dtype():
+    return _np_dtype(AlignResult)

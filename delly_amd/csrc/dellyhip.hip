@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,7 @@
 #include "lrmsa_kernel.hpp"
 #include "lrins_kernel.hpp"
 #include "lrwfa_kernel.hpp"
+#include "classify_kernel.hpp"
 
 namespace {
 
@@ -1331,6 +1333,123 @@ int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const c
   }
   return 0;
 }
+
+// ---- split-read genotyping classifier (src/coverage.h:412-434), SURVEY.md 8f N1 ----------------------
+static_assert(sizeof(dellyhip_align_job) == 48 && sizeof(dellyhip_align_result) == 20, "C-ABI record layout");
+struct dellyhip_jobs {
+  uint64_t n = 0;
+  DevBuf<dellyhip_align_job> jobs;
+  DevBuf<uint8_t> blob;
+  DevBuf<dellyhip_align_result> res;
+  DevBuf<int32_t> wide;      // [0] = count, [1..] = job indices with a probe > 64 bytes
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms_sum = 0;
+  int launches = 0;
+  ~dellyhip_jobs() {
+    for (auto& e : pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  }
+};
+
+int dellyhip_jobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
+                         uint64_t blob_len, dellyhip_jobs** out) {
+  if (!c || !out || (n_jobs && !jobs) || (blob_len && !blob) || n_jobs >= (1ull << 31))
+    return fail(DELLYHIP_E_ARG, "bad argument");
+  for (uint64_t i = 0; i < n_jobs; ++i) {
+    const dellyhip_align_job& j = jobs[i];
+    if (j.cons_off + j.cons_len > blob_len || j.ref_off + j.ref_len > blob_len || j.seq_off + j.seq_len > blob_len ||
+        j.seq_len > 0x7fffffffu)
+      return fail(DELLYHIP_E_ARG, "align job points outside the blob");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<dellyhip_jobs> b(new dellyhip_jobs);
+  b->n = n_jobs;
+  int rc;
+  if ((rc = b->jobs.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->blob.alloc(blob_len + 2 * dh::CLS_PAD)) ||
+      (rc = b->res.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->wide.alloc(n_jobs + 1)))
+    return rc;
+  if (n_jobs) HIPCHK(hipMemcpyAsync(b->jobs.p, jobs, n_jobs * sizeof(dellyhip_align_job), hipMemcpyHostToDevice, c->stream));
+  if (blob_len) HIPCHK(hipMemcpyAsync(b->blob.p, blob, blob_len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(b->blob.p + blob_len, 0, 2 * dh::CLS_PAD, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = b.release();
+  return 0;
+}
+
+int dellyhip_jobs_run(dellyhip_ctx* c, dellyhip_jobs* b, void* stream_) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+  b->last_stream = st;
+  if (b->n == 0) return 0;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemsetAsync(b->wide.p, 0, sizeof(int32_t), st));
+  dh::ClsArgs a{b->jobs.p, b->blob.p, b->res.p, b->n, c->params.flank_quality, b->wide.p + 1, b->wide.p};
+  const uint64_t groups = (b->n + dh::WAVE - 1) / dh::WAVE;
+  const int grid = (int)std::min<uint64_t>(groups, (uint64_t)std::max(1, c->n_cu) * 64);
+  HIPCHK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(dh::classify_kernel<1>, dim3(grid), dim3(dh::WAVE), 0, st, a);
+  HIPCHK(hipEventRecord(e1, st));
+  // probes of 65 .. 256 bytes (the list is usually empty: the launch then costs a few microseconds)
+  hipLaunchKernelGGL(dh::classify_kernel<dh::CLS_MAXW>, dim3(std::max(1, c->n_cu)), dim3(dh::WAVE), 0, st, a);
+  HIPCHK(hipGetLastError());
+  b->pending.emplace_back(e0, e1);
+  return 0;
+}
+
+int dellyhip_jobs_sync(dellyhip_ctx* c, dellyhip_jobs* b) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : c->stream));
+  return 0;
+}
+
+int dellyhip_jobs_kernel_ms(dellyhip_ctx* c, dellyhip_jobs* b, double* ms, int32_t* launches) {
+  if (!c || !b || !ms || !launches) return fail(DELLYHIP_E_ARG, "bad argument");
+  int rc = dellyhip_jobs_sync(c, b);
+  if (rc) return rc;
+  double sum = 0;
+  for (auto& e : b->pending) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
+    sum += t;
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  *launches = (int32_t)b->pending.size();
+  *ms = b->pending.empty() ? 0.0 : sum / (double)b->pending.size();
+  b->pending.clear();
+  return 0;
+}
+
+int dellyhip_jobs_fetch(dellyhip_ctx* c, dellyhip_jobs* b, dellyhip_align_result* results) {
+  if (!c || !b || (b->n && !results)) return fail(DELLYHIP_E_ARG, "bad argument");
+  int rc = dellyhip_jobs_sync(c, b);
+  if (rc) return rc;
+  if (b->n) HIPCHK(hipMemcpy(results, b->res.p, b->n * sizeof(dellyhip_align_result), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void dellyhip_jobs_free(dellyhip_ctx* c, dellyhip_jobs* b) {
+  if (!b) return;
+  if (c) hipSetDevice(c->device);
+  delete b;
+}
+
+int dellyhip_classify_reads(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
+                            uint64_t blob_len, dellyhip_align_result* results) {
+  dellyhip_jobs* b = nullptr;
+  int rc = dellyhip_jobs_upload(c, n_jobs, jobs, blob, blob_len, &b);
+  if (rc) return rc;
+  rc = dellyhip_jobs_run(c, b, nullptr);
+  if (!rc) rc = dellyhip_jobs_fetch(c, b, results);
+  dellyhip_jobs_free(c, b);
+  return rc;
+}
+
 
 int dellyhip_lcs(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, int32_t* out) {
   if (!c || !out) return fail(DELLYHIP_E_ARG, "bad argument");

@@ -27,6 +27,8 @@ EXPORTS = [
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
     "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
     "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib", "dellyhip_msa_wfa",
+    "dellyhip_classify_reads", "dellyhip_jobs_upload", "dellyhip_jobs_run", "dellyhip_jobs_sync", "dellyhip_jobs_fetch",
+    "dellyhip_jobs_free", "dellyhip_jobs_kernel_ms",
 ]
 
 
@@ -49,6 +51,7 @@ def load_library():
         lib.dellyhip_last_error.restype = C.c_char_p
         lib.dellyhip_batch_free.restype = None
         lib.dellyhip_destroy.restype = None
+        lib.dellyhip_jobs_free.restype = None
         _lib = lib
     return _lib
 
@@ -126,6 +129,15 @@ class Context:
     def refine_batch_lr(self, junctions, seq_blob, seq_off, want_alignment=False):
         """msaEdlib() + alignConsensus(..., realign): loop body of src/assemble.h:833-872 (non-insertion junctions)."""
         return self._run_host(self.lib.dellyhip_refine_batch_lr, junctions, seq_blob, seq_off, want_alignment)
+
+    def classify_reads(self, jobs, blob):
+        """The worker body of process_batch (src/coverage.h:418-434) for every AlignJob -> AlignResult records."""
+        jobs = np.ascontiguousarray(jobs, dtype=abi.align_job_dtype())
+        blob = _u8(blob)
+        res = np.zeros(jobs.shape[0], dtype=abi.align_result_dtype())
+        self._check(self.lib.dellyhip_classify_reads(self._ctx, C.c_uint64(jobs.shape[0]), _p(jobs, C.c_void_p), _p(blob),
+                                                     C.c_uint64(blob.size), _p(res, C.c_void_p)))
+        return res
 
     def refine(self, batch, want_alignment=False):
         """Convenience for a synth.Batch."""
@@ -271,6 +283,46 @@ class ResidentBatch:
     def free(self):
         if self._b:
             self.ctx.lib.dellyhip_batch_free(self.ctx._ctx, self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResidentJobs:
+    """AlignJob batch kept in HBM (one process_batch of src/coverage.h:412-450)."""
+
+    def __init__(self, ctx, jobs, blob):
+        self.ctx = ctx
+        jobs = np.ascontiguousarray(jobs, dtype=abi.align_job_dtype())
+        blob = _u8(blob)
+        self.n = int(jobs.shape[0])
+        self._b = C.c_void_p()
+        ctx._check(ctx.lib.dellyhip_jobs_upload(ctx._ctx, C.c_uint64(self.n), _p(jobs, C.c_void_p), _p(blob),
+                                                C.c_uint64(blob.size), C.byref(self._b)))
+
+    def run(self, stream=None):
+        self.ctx._check(self.ctx.lib.dellyhip_jobs_run(self.ctx._ctx, self._b, C.c_void_p(stream or 0)))
+
+    def sync(self):
+        self.ctx._check(self.ctx.lib.dellyhip_jobs_sync(self.ctx._ctx, self._b))
+
+    def kernel_ms(self):
+        a, l = C.c_double(0), C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_jobs_kernel_ms(self.ctx._ctx, self._b, C.byref(a), C.byref(l)))
+        return a.value, l.value
+
+    def fetch(self):
+        res = np.zeros(self.n, dtype=abi.align_result_dtype())
+        self.ctx._check(self.ctx.lib.dellyhip_jobs_fetch(self.ctx._ctx, self._b, _p(res, C.c_void_p)))
+        return res
+
+    def free(self):
+        if self._b:
+            self.ctx.lib.dellyhip_jobs_free(self.ctx._ctx, self._b)
             self._b = C.c_void_p()
 
     def __del__(self):

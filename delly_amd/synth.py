@@ -272,3 +272,62 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
     blob = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
     chroms = [chrA, chrB] if two_chr else [chrA]
     return Batch(chroms, junc, blob, off, (2 if mode == "lr" else 1) if n_reads > 0 else 0, truth)
+
+
+def make_align_jobs(n_sv, reads_per_bp=40, *, seed=7, read_len=150, flank=13, sub_rate=0.005, weird=False):
+    """Synthetic AlignJob batch for the split-read genotyping classifier (src/coverage.h:412-434).
+
+    Per SV (a deletion) and breakpoint (bpPoint 0/1): consProbe / refProbe of length 2*flank + homLeft + homRight
+    (src/coverage.h:231-256) cut from the ALT / REF haplotype around the breakpoint, and `reads_per_bp` reads of
+    `read_len` bytes that span it -- half sampled from the ALT haplotype, half from the reference, with `sub_rate`
+    substitutions, 2 % of them unrelated sequence ('N' results), qualities 0..60.  weird: longer probes
+    (65 .. 256 bytes and beyond), ragged read lengths, lower-case / IUPAC bytes, empty strings.
+    -> (jobs structured array, blob np.uint8)"""
+    rng = np.random.default_rng(seed)
+    parts = []
+    pos = 0
+
+    def put(a):
+        nonlocal pos
+        parts.append(a)
+        o = pos
+        pos += a.size
+        return o
+
+    rows = []
+    for sv in range(n_sv):
+        G = ACGT[rng.integers(0, 4, 1400)]
+        s, e = 500, 900
+        alt = np.concatenate([G[:s], G[e:]])
+        for bp in (0, 1):
+            hom = int(rng.integers(0, 12)) if not weird else int(rng.integers(0, 140))
+            half = flank + hom // 2
+            if weird and sv % 9 == 0:
+                half = int(rng.integers(130, 170))      # beyond the 256-byte probe limit now and then
+            centre_ref = s if bp == 0 else e
+            consP = alt[s - half:s + half + (hom & 1)].copy()
+            refP = G[centre_ref - half:centre_ref + half + (hom & 1)].copy()
+            if weird and sv % 7 == 3:
+                consP[rng.integers(0, consP.size)] = ord("R")
+                refP[rng.integers(0, refP.size)] = ord("n")
+            if weird and sv % 31 == 5:
+                consP = consP[:0]
+            co, ro = put(consP), put(refP)
+            for r in range(reads_per_bp):
+                L = read_len if not weird else int(rng.integers(0 if r % 13 == 0 else 30, 260))
+                kind = r % 2
+                if rng.random() < 0.02:
+                    read = ACGT[rng.integers(0, 4, L)]
+                else:
+                    src, centre = (alt, s) if kind == 0 else (G, centre_ref)
+                    o = centre - int(rng.integers(flank + 8, max(flank + 9, L - flank - 8))) if L > 2 * flank + 20 else centre - L // 2
+                    o = max(0, o)
+                    read = _mutate(rng, src[o:o + L].copy(), sub_rate)
+                if weird and r % 11 == 4 and read.size:
+                    read[rng.integers(0, read.size)] = rng.choice(np.frombuffer(b"NRYacgtn=", dtype=np.uint8))
+                rows.append((co, ro, put(read), consP.size, refP.size, read.size, sv % 3, sv, int(rng.integers(0, 61))))
+    jobs = np.zeros(len(rows), dtype=abi.align_job_dtype())
+    for k, name in enumerate(("cons_off", "ref_off", "seq_off", "cons_len", "ref_len", "seq_len", "file_index", "sv_id", "qual")):
+        jobs[name] = [r[k] for r in rows]
+    blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    return jobs, blob

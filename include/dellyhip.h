@@ -202,6 +202,56 @@ int dellyhip_refine_batch_lr(dellyhip_ctx* ctx, int32_t n_junctions, const delly
                              dellyhip_result* results, char* out_blob, uint64_t out_blob_cap,
                              uint64_t* out_blob_len, int want_alignment);
 
+/* ---- split-read genotyping: the read classifier -------- */
+
+/* One AlignJob of src/coverage.h:87-96: a breakpoint-spanning read and the two probes of the
+ * SV it spans.  The three strings live in one byte blob (several jobs may share a probe or a
+ * read); file_index / sv_id / qual are carried through to the result as in :418-434. */
+typedef struct dellyhip_align_job {
+  uint64_t cons_off;   /* consProbe  (ALT probe, src/coverage.h:255) */
+  uint64_t ref_off;    /* refProbe   (:256)                          */
+  uint64_t seq_off;    /* read sequence, already orientation-adjusted (:518-522) */
+  uint32_t cons_len;
+  uint32_t ref_len;
+  uint32_t seq_len;
+  uint32_t file_index;
+  uint32_t sv_id;
+  uint8_t qual;        /* rec->core.qual */
+  uint8_t pad_[3];
+} dellyhip_align_job;
+
+/* AlignResult of src/coverage.h:98-105 plus the two edlib distances behind it. */
+typedef struct dellyhip_align_result {
+  uint32_t file_index;
+  uint32_t sv_id;
+  int32_t dist_alt;    /* edlibAlign(consProbe, read, k, HW, DISTANCE).editDistance, -1 beyond k */
+  int32_t dist_ref;    /* same for refProbe */
+  uint8_t type;        /* 'R', 'A' or 'N' */
+  uint8_t qual;
+  int16_t status;      /* 0, or DELLYHIP_E_LIMIT (probe > 256 bytes) */
+} dellyhip_align_result;
+
+/* The worker body of process_batch, src/coverage.h:418-434, for every job:
+ *   scoreAlt = _editDistanceHW(c, consProbe, sequence); scoreRef = _editDistanceHW(c, refProbe, sequence)
+ *   (src/coverage.h:107-115: edlib HW distance with k = (int)(2 * flankQuality * |probe|), score =
+ *   (1 - flankQuality) * |probe| / (distance + 1) in double, 0 beyond k), then type / qual as in :424-432.
+ * Uses params.flank_quality of the context.  Limits: probes <= 256 bytes (reads: any length).
+ * The merge into countMap (:438-449, order dependent) stays with the caller. */
+int dellyhip_classify_reads(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_align_job* jobs,
+                            const char* blob, uint64_t blob_len, dellyhip_align_result* results);
+
+/* Device-resident flavour (jobs of one BAM batch, src/coverage.h:271: 131072 x threads):
+ * upload once, run (stream = hipStream_t as void*, 0 = the context's stream), fetch. */
+typedef struct dellyhip_jobs dellyhip_jobs;
+int dellyhip_jobs_upload(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_align_job* jobs,
+                         const char* blob, uint64_t blob_len, dellyhip_jobs** out);
+int dellyhip_jobs_run(dellyhip_ctx* ctx, dellyhip_jobs* b, void* stream);
+int dellyhip_jobs_sync(dellyhip_ctx* ctx, dellyhip_jobs* b);
+int dellyhip_jobs_fetch(dellyhip_ctx* ctx, dellyhip_jobs* b, dellyhip_align_result* results);
+void dellyhip_jobs_free(dellyhip_ctx* ctx, dellyhip_jobs* b);
+/* Average duration (ms) of classify_kernel over the runs since the last call (HIP events on the launch stream). */
+int dellyhip_jobs_kernel_ms(dellyhip_ctx* ctx, dellyhip_jobs* b, double* ms, int32_t* launches);
+
 /* ---- single-item wrappers (parity tests, assemble.h / asmode.h call sites) */
 
 /* bool longNeedle(s1, s2, align, AlignConfig<true,false>, DnaScore(1,-1,-1,-1))

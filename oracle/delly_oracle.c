@@ -1966,3 +1966,90 @@ int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr
   if (out_used) *out_used = used;
   return (out_blob && used > out_cap) ? -1 : 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Split-read genotyping classifier: the worker body of process_batch,
+ * src/coverage.h:418-434, on top of _editDistanceHW (:107-115).
+ * edlib's HW distance with threshold k (src/edlib.cpp:157-170 empty operands; :545-700: the best
+ * last-row value over all target columns, k = min(queryLength, k), -1 when it exceeds k) is restated
+ * as the plain unit-cost DP with a free first row -- the distance is unique.
+ * ------------------------------------------------------------------------------------------------ */
+static int hw_distance_k(const char* q, int qn, const char* t, int tn, int k) {
+  if (qn == 0 || tn == 0) return qn;
+  int* col = (int*)malloc(sizeof(int) * (size_t)(qn + 1));
+  for (int i = 0; i <= qn; ++i) col[i] = i;
+  int best = qn;
+  for (int j = 1; j <= tn; ++j) {
+    int diag = col[0];   /* D[0][j-1] = 0 */
+    col[0] = 0;
+    for (int i = 1; i <= qn; ++i) {
+      const int up_left = diag + (q[i - 1] != t[j - 1]);
+      diag = col[i];
+      int v = up_left;
+      if (col[i] + 1 < v) v = col[i] + 1;         /* D[i][j-1] + 1 */
+      if (col[i - 1] + 1 < v) v = col[i - 1] + 1; /* D[i-1][j] + 1 */
+      col[i] = v;
+    }
+    if (col[qn] < best) best = col[qn];
+  }
+  free(col);
+  if (k < 0) return best;          /* edlib: k < 0 = search until found */
+  if (qn < k) k = qn;              /* src/edlib.cpp:563-565 */
+  return best <= k ? best : -1;
+}
+
+/* _editDistanceHW  src/coverage.h:107-115 */
+static double edit_distance_hw_score(float flank_quality, const char* q, int qn, const char* t, int tn, int* dist) {
+  double score = 0;
+  const int k = (int)(2 * flank_quality * (size_t)qn);   /* float product, truncated by edlibNewAlignConfig(int k, ...) */
+  const int d = hw_distance_k(q, qn, t, tn, k);
+  if (d != -1) score = ((1.0 - flank_quality) * (double)qn) / (double)(d + 1);
+  *dist = d;
+  return score;
+}
+
+typedef struct {
+  const dellyhip_params* p; const dellyhip_align_job* jobs; const char* blob; dellyhip_align_result* out;
+  uint64_t n; volatile uint64_t* next;
+} cls_work;
+
+static void* cls_worker(void* arg) {
+  cls_work* w = (cls_work*)arg;
+  for (;;) {
+    const uint64_t i = __sync_fetch_and_add(w->next, 1);
+    if (i >= w->n) break;
+    const dellyhip_align_job* J = &w->jobs[i];
+    dellyhip_align_result r;
+    memset(&r, 0, sizeof r);
+    r.type = 'N';
+    const char* seq = w->blob + J->seq_off;
+    const double scoreAlt = edit_distance_hw_score(w->p->flank_quality, w->blob + J->cons_off, (int)J->cons_len, seq, (int)J->seq_len, &r.dist_alt);
+    const double scoreRef = edit_distance_hw_score(w->p->flank_quality, w->blob + J->ref_off, (int)J->ref_len, seq, (int)J->seq_len, &r.dist_ref);
+    if ((scoreRef > 0.7) || (scoreAlt > 0.7)) {   /* src/coverage.h:424-433 */
+      r.sv_id = J->sv_id;
+      r.file_index = J->file_index;
+      if (scoreRef > scoreAlt) {
+        int qv = (int)(scoreRef * 35); if ((int)J->qual < qv) qv = (int)J->qual; if (qv > 255) qv = 255;
+        r.type = 'R'; r.qual = (uint8_t)qv;
+      } else {
+        int qv = (int)(scoreAlt * 35); if ((int)J->qual < qv) qv = (int)J->qual; if (qv > 255) qv = 255;
+        r.type = 'A'; r.qual = (uint8_t)qv;
+      }
+    }
+    w->out[i] = r;
+  }
+  return NULL;
+}
+
+int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
+                       dellyhip_align_result* out, int n_threads) {
+  volatile uint64_t next = 0;
+  cls_work w = {p, jobs, blob, out, n_jobs, &next};
+  if (n_threads <= 1) { cls_worker(&w); return 0; }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, cls_worker, &w);
+  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  free(th);
+  return 0;
+}

@@ -52,6 +52,9 @@ int dor_msa_edlib(const dellyhip_params* p, int n_reads, const char* blob, const
 /* msaWfa(c, sps, cs, prefix, suffix)  src/assemble.h:547-726 */
 int dor_msa_wfa(const dellyhip_params* p, int n_reads, const char* blob, const uint64_t* off, const char* prefix, int pn,
                 const char* suffix, int sn, char* cs, int cap, int* cs_len);
+/* worker body of process_batch, src/coverage.h:418-434 (split-read genotyping classifier) */
+int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
+                       dellyhip_align_result* out, int n_threads);
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

@@ -192,6 +192,18 @@ class Oracle:
                                   _p(pre), pre.size, _p(suf), suf.size, _p(cs), cap, C.byref(ln))
         return rows, cs[:ln.value].tobytes()
 
+    def classify_reads(self, jobs, blob, params=None, n_threads=1):
+        """worker body of process_batch (src/coverage.h:418-434) for every job -> structured result array"""
+        p = params if params is not None else self.params
+        blob = _u8(blob)
+        jobs = np.ascontiguousarray(jobs, dtype=abi.align_job_dtype())
+        res = np.zeros(jobs.shape[0], dtype=abi.align_result_dtype())
+        rc = self._f("classify_reads")(C.byref(p), C.c_uint64(jobs.shape[0]), C.c_void_p(jobs.ctypes.data), _p(blob),
+                                       C.c_void_p(res.ctypes.data), int(n_threads))
+        if rc:
+            raise RuntimeError("oracle classify_reads rc=%d" % rc)
+        return res
+
     def unordered_set_order(self, reads):
         assert self.kind == "reference"
         blob, off = self._pack(reads)

@@ -63,6 +63,7 @@ inline void reverseComplement(std::string& sequence) {
 #include "split.h"
 #include <numeric>          // std::iota (src/assemble.h:374 relies on a transitive include)
 #include "assemble_msa.h"   // src/assemble.h up to assemble(): derived into a temp dir at build time (oracle/Makefile)
+#include "coverage_jobs.h"  // src/coverage.h:87-162 (AlignJob, AlignResult, _editDistanceHW, _cutRef*): derived likewise
 
 #include "../include/dellyhip.h"
 
@@ -467,3 +468,58 @@ int dref_unordered_set_order(int n_reads, const char* blob, const uint64_t* off,
 }
 
 }  // extern "C"
+
+
+// ---- split-read genotyping classifier: the worker body of process_batch, src/coverage.h:418-434 ----
+// _editDistanceHW, AlignJob and AlignResult are the reference's (coverage_jobs.h); the ten lines of the
+// lambda body live inside genotype code that needs htslib, so they are replayed here statement by statement.
+extern "C" int dref_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs,
+                                   const char* blob, dellyhip_align_result* out, int n_threads) {
+  RefConfig c = make_config(p);
+  std::atomic<uint64_t> next(0);   // as process_batch: workers pull job indices from one atomic counter (:414-417)
+  auto worker = [&]() {
+  for (;;) {
+    const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+    if (i >= n_jobs) break;
+    const dellyhip_align_job& J = jobs[i];
+    torali::AlignJob job(std::string(blob + J.cons_off, J.cons_len), std::string(blob + J.ref_off, J.ref_len),
+                         std::string(blob + J.seq_off, J.seq_len), J.file_index, J.sv_id, J.qual);
+    torali::AlignResult r;
+    double scoreAlt = torali::_editDistanceHW(c, job.consProbe, job.sequence);
+    double scoreRef = torali::_editDistanceHW(c, job.refProbe, job.sequence);
+    if ((scoreRef > 0.7) || (scoreAlt > 0.7)) {
+      r.svId = job.svId;
+      r.fileIndex = job.fileIndex;
+      if (scoreRef > scoreAlt) {
+        r.type = 'R';
+        r.qual = (uint8_t) std::min(255, std::min((int) (scoreRef * 35), (int) job.qual));
+      } else {
+        r.type = 'A';
+        r.qual = (uint8_t) std::min(255, std::min((int) (scoreAlt * 35), (int) job.qual));
+      }
+    }
+    // the two distances behind the scores, from the reference's own edlib with the reference's k
+    auto dist = [&](std::string const& q) {
+      EdlibAlignResult a = edlibAlign(q.c_str(), q.size(), job.sequence.c_str(), job.sequence.size(),
+                                      edlibNewAlignConfig(2 * c.flankQuality * q.size(), EDLIB_MODE_HW, EDLIB_TASK_DISTANCE, NULL, 0));
+      int d = a.editDistance;
+      edlibFreeAlignResult(a);
+      return d;
+    };
+    out[i].file_index = r.fileIndex;
+    out[i].sv_id = r.svId;
+    out[i].dist_alt = dist(job.consProbe);
+    out[i].dist_ref = dist(job.refProbe);
+    out[i].type = (uint8_t)r.type;
+    out[i].qual = r.qual;
+    out[i].status = 0;
+  }
+  };
+  if (n_threads <= 1) worker();
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  return 0;
+}

@@ -162,6 +162,25 @@ def long_read_vectors(ref):
     print("longread ok: %d alignments, %d msaEdlib sets, %d msaWfa sets" % (len(q_l), len(sets), len(wsets)))
 
 
+# split-read genotyping classifier (src/coverage.h:412-434): (label, make_align_jobs kwargs, flank_quality)
+ALIGN_JOBS = [("plain", dict(n_sv=40, reads_per_bp=24, seed=11), 0.95),
+              ("weird", dict(n_sv=40, reads_per_bp=16, seed=12, weird=True), 0.95),
+              ("lowq", dict(n_sv=24, reads_per_bp=16, seed=13, weird=True), 0.4)]
+
+
+def align_job_vectors(ref):
+    d = {}
+    for label, kw, fq in ALIGN_JOBS:
+        jobs, blob = synth.make_align_jobs(**kw)
+        p = abi.params_sr()
+        p.flank_quality = fq
+        d[label + "_results"] = ref.classify_reads(jobs, blob, params=p)
+        d[label + "_jobs"] = jobs       # inputs are stored too, so the fixture does not depend on the generator
+        d[label + "_blob"] = blob
+    np.savez_compressed(os.path.join(HERE, "align_jobs.npz"), **d)
+    print("align_jobs ok:", {k: int(v.shape[0]) for k, v in d.items() if k.endswith("_results")})
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Oracle("reference")
@@ -170,6 +189,8 @@ def main():
         edlib_vectors(ref)
     if not only or "longread" in only:
         long_read_vectors(ref)
+    if not only or "align_jobs" in only:
+        align_job_vectors(ref)
     # --- batches ---------------------------------------------------------------
     for name, (n, kw) in BATCHES.items():
         if only and name not in only:

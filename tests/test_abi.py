@@ -42,6 +42,9 @@ def test_struct_layouts(lib):
     assert out[3] == C.sizeof(abi.Result)
     assert abi.result_dtype().itemsize == C.sizeof(abi.Result)
     assert abi.junction_dtype().itemsize == C.sizeof(abi.Junction)
+    # dellyhip_align_job / dellyhip_align_result (static_assert'ed to these sizes in csrc/dellyhip.hip)
+    assert C.sizeof(abi.AlignJob) == 48 and abi.align_job_dtype().itemsize == 48
+    assert C.sizeof(abi.AlignResult) == 20 and abi.align_result_dtype().itemsize == 20
 
 
 def test_no_cpu_fallback(lib):

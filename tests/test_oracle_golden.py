@@ -108,6 +108,26 @@ def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
     compare(pr, pb, rr, rb, label="port-vs-reference")
 
 
+def test_port_reproduces_golden_align_jobs(port):
+    """split-read genotyping classifier (src/coverage.h:412-434): reference-generated records"""
+    z = np.load(os.path.join(GOLD, "align_jobs.npz"))
+    for label, fq in (("plain", 0.95), ("weird", 0.95), ("lowq", 0.4)):
+        p = abi.params_sr()
+        p.flank_quality = fq
+        got = port.classify_reads(z[label + "_jobs"], z[label + "_blob"], params=p)
+        assert got.tobytes() == z[label + "_results"].tobytes(), label
+
+
+def test_port_classifier_vs_reference_fresh(port, reference):
+    for seed, weird, fq in ((21, False, 0.95), (22, True, 0.95), (23, True, 0.45), (24, True, 0.0)):
+        jobs, blob = synth.make_align_jobs(25, 12, seed=seed, weird=weird)
+        p = abi.params_sr()
+        p.flank_quality = fq
+        a = port.classify_reads(jobs, blob, params=p, n_threads=3)
+        b = reference.classify_reads(jobs, blob, params=p, n_threads=2)
+        assert a.tobytes() == b.tobytes(), (seed, fq)
+
+
 @pytest.mark.parametrize("mode", ["c2", "mixed", "ins"])
 def test_fuzz_port_vs_reference(port, reference, mode):
     """perturbed breakpoint estimates / consensus sequences under unusual parameter sets, and reference windows
