@@ -173,6 +173,48 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
             dtc = (time.perf_counter() - t0) / reps
             out[name]["cpu_" + orc.kind] = {"junctions_per_s": sub.n / dtc, "cores": cores,
                                             "sample": "%d x %d junctions, %.2f s each" % (reps, sub.n, dtc)}
+    # the split-read genotyping classifier (src/coverage.h:412-434), one process_batch of
+    # 131072 x 8 AlignJobs (:271) resident in HBM: 26..37-byte probes against 150-byte reads
+    try:
+        import numpy as np
+        base_jobs, base_blob = synth.make_align_jobs(160, 40, seed=9)
+        tiles = (131072 * 8 + base_jobs.shape[0] - 1) // base_jobs.shape[0]
+        jobs = np.tile(base_jobs, tiles)
+        shift = np.repeat(np.arange(tiles, dtype=np.uint64) * np.uint64(base_blob.size), base_jobs.shape[0])
+        for f in ("cons_off", "ref_off", "seq_off"):
+            jobs[f] += shift
+        blob = np.tile(base_blob, tiles)
+        cx = refine.Context(device=device)
+        rj = refine.ResidentJobs(cx, jobs, blob)
+        rj.run(); rj.sync(); rj.kernel_ms()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rj.run()
+        rj.sync()
+        dt = (time.perf_counter() - t0) / steps
+        kms, _ = rj.kernel_ms()
+        res = rj.fetch()
+        nj = int(jobs.shape[0])
+        cells = float((jobs["cons_len"].astype(np.int64) + jobs["ref_len"]).astype(np.float64) @ jobs["seq_len"].astype(np.float64))
+        alg_bytes = float(jobs["cons_len"].sum() + jobs["ref_len"].sum() + jobs["seq_len"].sum()) + nj * (48 + 20)
+        out["sr_genotype_classifier"] = {
+            "jobs": nj, "jobs_per_s": nj / dt, "ms_per_step": dt * 1e3, "classify_kernel_ms": kms,
+            "gcups": cells / (kms * 1e-3) / 1e9, "hbm_frac": alg_bytes / (kms * 1e-3) / 8e12,
+            "types": {t: int((res["type"] == ord(t)).sum()) for t in "RAN"},
+            "note": "two edlib HW distances per job (probe x read); one job per lane, 64-bit Myers"}
+        rj.free()
+        cx.close()
+        if orc is not None:
+            sub = slice(0, 40 * base_jobs.shape[0])
+            t0 = time.perf_counter()
+            ref = orc.classify_reads(jobs[sub], blob, n_threads=cores)
+            dtc = time.perf_counter() - t0
+            same = all((ref[f] == res[sub][f]).all() for f in ("type", "qual", "dist_alt", "dist_ref"))
+            out["sr_genotype_classifier"]["cpu_" + orc.kind] = {"jobs_per_s": ref.shape[0] / dtc, "cores": cores,
+                                                                "sample": "%d jobs, %.2f s" % (ref.shape[0], dtc),
+                                                                "identical_to_gpu": bool(same)}
+    except Exception as e:  # side figure only
+        out["sr_genotype_classifier"] = {"error": repr(e)}
     return out
 
 
