@@ -215,6 +215,47 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
                                                                 "identical_to_gpu": bool(same)}
     except Exception as e:  # side figure only
         out["sr_genotype_classifier"] = {"error": repr(e)}
+    # long-read genotyping, _editDistanceNW (src/genotype.h:21-30,276,284): read slice vs REF and
+    # ALT slices of 1000..2000 bytes, 6 % ONT-like error
+    try:
+        import numpy as np
+        base_jobs, base_blob = synth.make_nw_jobs(512, seed=19)
+        tiles = 16
+        jobs = np.tile(base_jobs, tiles)
+        shift = np.repeat(np.arange(tiles, dtype=np.uint64) * np.uint64(base_blob.size), base_jobs.shape[0])
+        for f in ("query_off", "target_off"):
+            jobs[f] += shift
+        blob = np.tile(base_blob, tiles)
+        cx = refine.Context(device=device)
+        rj = refine.ResidentNwJobs(cx, jobs, blob)
+        rj.run(); rj.fetch(); rj.kernel_ms()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rj.run()
+        dist = rj.fetch()
+        dt = (time.perf_counter() - t0) / steps
+        kms, _ = rj.kernel_ms()
+        nj = int(jobs.shape[0])
+        cells = float(jobs["query_len"].astype(np.float64) @ jobs["target_len"].astype(np.float64))
+        out["lr_genotype_edit_distance_nw"] = {"pairs": nj, "pairs_per_s": nj / dt, "ms_per_step": dt * 1e3,
+                                               "nw_jobs_kernel_ms": kms, "gcups": cells / (kms * 1e-3) / 1e9,
+                                               "mean_len": float(jobs["query_len"].mean())}
+        rj.free()
+        cx.close()
+        if orc is not None:
+            sub = slice(0, 4 * base_jobs.shape[0])
+            t0 = time.perf_counter()
+            ref = orc.edit_distance_nw_batch(jobs[sub], blob, n_threads=cores)
+            dtc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            orc.edit_distance_nw_batch(jobs[:256], blob, n_threads=1)
+            dt1 = time.perf_counter() - t0
+            out["lr_genotype_edit_distance_nw"]["cpu_" + orc.kind] = {
+                "pairs_per_s": ref.shape[0] / dtc, "cores": cores, "sample": "%d pairs, %.2f s" % (ref.shape[0], dtc),
+                "pairs_per_s_one_thread": 256 / dt1, "identical_to_gpu": bool((ref == dist[sub]).all()),
+                "note": "the reference calls _editDistanceNW serially per read (src/genotype.h:262-284)"}
+    except Exception as e:  # side figure only
+        out["lr_genotype_edit_distance_nw"] = {"error": repr(e)}
     return out
 
 

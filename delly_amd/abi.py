@@ -126,6 +126,16 @@ class AlignResult(C.Structure):
     ]
 
 
+class NwJob(C.Structure):
+    """dellyhip_nw_job: one _editDistanceNW(query, target) call (src/genotype.h:21-30)."""
+    _fields_ = [
+        ("query_off", C.c_uint64),
+        ("target_off", C.c_uint64),
+        ("query_len", C.c_uint32),
+        ("target_len", C.c_uint32),
+    ]
+
+
 # numpy structured dtypes with the same layout (for vectorised comparisons)
 def _np_dtype(struct):
     import numpy as np
@@ -154,3 +164,7 @@ def align_job_dtype():
 
 def align_result_dtype():
     return _np_dtype(AlignResult)
+
+
+def nw_job_dtype():
+    return _np_dtype(NwJob)

@@ -1451,6 +1451,104 @@ int dellyhip_classify_reads(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_ali
 }
 
 
+// ---- long-read genotyping: batched _editDistanceNW (src/genotype.h:21-30), SURVEY.md 8f N2 -----------------
+static_assert(sizeof(dellyhip_nw_job) == 24, "C-ABI record layout");
+struct dellyhip_nwjobs {
+  uint64_t n = 0;
+  DevBuf<dellyhip_nw_job> jobs;
+  DevBuf<uint8_t> blob;
+  DevBuf<int32_t> dist;
+  hipStream_t last_stream = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  ~dellyhip_nwjobs() {
+    for (auto& e : pending) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  }
+};
+
+int dellyhip_nwjobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob,
+                           uint64_t blob_len, dellyhip_nwjobs** out) {
+  if (!c || !out || (n_jobs && !jobs) || (blob_len && !blob)) return fail(DELLYHIP_E_ARG, "bad argument");
+  for (uint64_t i = 0; i < n_jobs; ++i)
+    if (jobs[i].query_off + jobs[i].query_len > blob_len || jobs[i].target_off + jobs[i].target_len > blob_len ||
+        jobs[i].query_len > 0x7fffffffu || jobs[i].target_len > 0x7fffffffu)
+      return fail(DELLYHIP_E_ARG, "nw job points outside the blob");
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<dellyhip_nwjobs> b(new dellyhip_nwjobs);
+  b->n = n_jobs;
+  int rc;
+  if ((rc = b->jobs.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->blob.alloc(blob_len + 16)) ||
+      (rc = b->dist.alloc(std::max<uint64_t>(n_jobs, 1))))
+    return rc;
+  if (n_jobs) HIPCHK(hipMemcpyAsync(b->jobs.p, jobs, n_jobs * sizeof(dellyhip_nw_job), hipMemcpyHostToDevice, c->stream));
+  if (blob_len) HIPCHK(hipMemcpyAsync(b->blob.p, blob, blob_len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = b.release();
+  return 0;
+}
+
+int dellyhip_nwjobs_run(dellyhip_ctx* c, dellyhip_nwjobs* b, void* stream_) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = stream_ ? (hipStream_t)stream_ : c->stream;
+  b->last_stream = st;
+  if (b->n == 0) return 0;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n};
+  const int grid = (int)std::min<uint64_t>(b->n, (uint64_t)std::max(1, c->n_cu) * 32);
+  HIPCHK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(dh::nw_jobs_kernel, dim3(grid), dim3(dh::WAVE), 0, st, a);
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipGetLastError());
+  b->pending.emplace_back(e0, e1);
+  return 0;
+}
+
+int dellyhip_nwjobs_kernel_ms(dellyhip_ctx* c, dellyhip_nwjobs* b, double* ms, int32_t* launches) {
+  if (!c || !b || !ms || !launches) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : c->stream));
+  double sum = 0;
+  for (auto& e : b->pending) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
+    sum += t;
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  *launches = (int32_t)b->pending.size();
+  *ms = b->pending.empty() ? 0.0 : sum / (double)b->pending.size();
+  b->pending.clear();
+  return 0;
+}
+
+int dellyhip_nwjobs_fetch(dellyhip_ctx* c, dellyhip_nwjobs* b, int32_t* distances) {
+  if (!c || !b || (b->n && !distances)) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(b->last_stream ? b->last_stream : c->stream));
+  if (b->n) HIPCHK(hipMemcpy(distances, b->dist.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void dellyhip_nwjobs_free(dellyhip_ctx* c, dellyhip_nwjobs* b) {
+  if (!b) return;
+  if (c) hipSetDevice(c->device);
+  delete b;
+}
+
+int dellyhip_edit_distance_nw_batch(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob,
+                                    uint64_t blob_len, int32_t* distances) {
+  dellyhip_nwjobs* b = nullptr;
+  int rc = dellyhip_nwjobs_upload(c, n_jobs, jobs, blob, blob_len, &b);
+  if (rc) return rc;
+  rc = dellyhip_nwjobs_run(c, b, nullptr);
+  if (!rc) rc = dellyhip_nwjobs_fetch(c, b, distances);
+  dellyhip_nwjobs_free(c, b);
+  return rc;
+}
+
+
 int dellyhip_lcs(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, int32_t* out) {
   if (!c || !out) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));

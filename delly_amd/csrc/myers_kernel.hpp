@@ -192,4 +192,28 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
   }
 }
 
+// ---- a batch of independent pairs: _editDistanceNW of the long-read genotyper (src/genotype.h:21-30,276,284) ----
+struct NwArgs {
+  const dellyhip_nw_job* jobs;
+  const uint8_t* blob;
+  int32_t* dist;
+  uint64_t n_jobs;
+};
+
+__global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
+  const int lane = threadIdx.x;
+  for (uint64_t item = blockIdx.x; item < A.n_jobs; item += gridDim.x) {
+    const dellyhip_nw_job J = A.jobs[item];
+    const int la = (int)J.query_len, lb = (int)J.target_len;
+    const uint8_t* a = A.blob + J.query_off;
+    const uint8_t* b = A.blob + J.target_off;
+    int d;
+    if (la == 0 || lb == 0) d = max(la, lb);                              // edlib.cpp:157-163
+    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = DELLYHIP_E_LIMIT;
+    else if (la <= lb) d = myers_nw(a, la, b, lb, lane);                   // pattern = the shorter string (symmetric)
+    else d = myers_nw(b, lb, a, la, lane);
+    if (lane == 0) A.dist[item] = d;
+  }
+}
+
 }  // namespace dh

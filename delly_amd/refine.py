@@ -29,6 +29,8 @@ EXPORTS = [
     "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib", "dellyhip_msa_wfa",
     "dellyhip_classify_reads", "dellyhip_jobs_upload", "dellyhip_jobs_run", "dellyhip_jobs_sync", "dellyhip_jobs_fetch",
     "dellyhip_jobs_free", "dellyhip_jobs_kernel_ms",
+    "dellyhip_edit_distance_nw_batch", "dellyhip_nwjobs_upload", "dellyhip_nwjobs_run", "dellyhip_nwjobs_fetch",
+    "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms",
 ]
 
 
@@ -52,6 +54,7 @@ def load_library():
         lib.dellyhip_batch_free.restype = None
         lib.dellyhip_destroy.restype = None
         lib.dellyhip_jobs_free.restype = None
+        lib.dellyhip_nwjobs_free.restype = None
         _lib = lib
     return _lib
 
@@ -138,6 +141,15 @@ class Context:
         self._check(self.lib.dellyhip_classify_reads(self._ctx, C.c_uint64(jobs.shape[0]), _p(jobs, C.c_void_p), _p(blob),
                                                      C.c_uint64(blob.size), _p(res, C.c_void_p)))
         return res
+
+    def edit_distance_nw_batch(self, jobs, blob):
+        """_editDistanceNW (src/genotype.h:21-30) for every (query, target) pair -> int32 distances."""
+        jobs = np.ascontiguousarray(jobs, dtype=abi.nw_job_dtype())
+        blob = _u8(blob)
+        out = np.zeros(jobs.shape[0], dtype=np.int32)
+        self._check(self.lib.dellyhip_edit_distance_nw_batch(self._ctx, C.c_uint64(jobs.shape[0]), _p(jobs, C.c_void_p),
+                                                             _p(blob), C.c_uint64(blob.size), _p(out, C.c_void_p)))
+        return out
 
     def refine(self, batch, want_alignment=False):
         """Convenience for a synth.Batch."""
@@ -323,6 +335,43 @@ class ResidentJobs:
     def free(self):
         if self._b:
             self.ctx.lib.dellyhip_jobs_free(self.ctx._ctx, self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResidentNwJobs:
+    """_editDistanceNW pairs kept in HBM."""
+
+    def __init__(self, ctx, jobs, blob):
+        self.ctx = ctx
+        jobs = np.ascontiguousarray(jobs, dtype=abi.nw_job_dtype())
+        blob = _u8(blob)
+        self.n = int(jobs.shape[0])
+        self._b = C.c_void_p()
+        ctx._check(ctx.lib.dellyhip_nwjobs_upload(ctx._ctx, C.c_uint64(self.n), _p(jobs, C.c_void_p), _p(blob),
+                                                  C.c_uint64(blob.size), C.byref(self._b)))
+
+    def run(self, stream=None):
+        self.ctx._check(self.ctx.lib.dellyhip_nwjobs_run(self.ctx._ctx, self._b, C.c_void_p(stream or 0)))
+
+    def kernel_ms(self):
+        a, l = C.c_double(0), C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_nwjobs_kernel_ms(self.ctx._ctx, self._b, C.byref(a), C.byref(l)))
+        return a.value, l.value
+
+    def fetch(self):
+        out = np.zeros(self.n, dtype=np.int32)
+        self.ctx._check(self.ctx.lib.dellyhip_nwjobs_fetch(self.ctx._ctx, self._b, _p(out, C.c_void_p)))
+        return out
+
+    def free(self):
+        if self._b:
+            self.ctx.lib.dellyhip_nwjobs_free(self.ctx._ctx, self._b)
             self._b = C.c_void_p()
 
     def __del__(self):

@@ -331,3 +331,50 @@ def make_align_jobs(n_sv, reads_per_bp=40, *, seed=7, read_len=150, flank=13, su
         jobs[name] = [r[k] for r in rows]
     blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
     return jobs, blob
+
+
+def make_nw_jobs(n_reads, *, seed=17, err=0.06, min_half=500, max_half=1000, weird=False):
+    """Synthetic _editDistanceNW pairs of the long-read genotyper (src/genotype.h:262-284): per read and
+    breakpoint the read slice `probe` (2*offset bytes, ONT-like errors) against the reference slice and against
+    the consensus (ALT) slice of the same length; one of the two alleles is the read's own haplotype, the other
+    differs by the SV (here a deletion next to the breakpoint), so one distance is small and one is large.
+    weird: empty strings, very unequal lengths, bytes outside ACGT, pairs beyond the 6144-byte pattern limit.
+    -> (jobs structured array, blob np.uint8)"""
+    rng = np.random.default_rng(seed)
+    parts, rows, pos = [], [], 0
+
+    def put(a):
+        nonlocal pos
+        parts.append(a)
+        o = pos
+        pos += a.size
+        return o
+
+    for r in range(n_reads):
+        half = int(rng.integers(min_half, max_half + 1))
+        G = ACGT[rng.integers(0, 4, 2 * half + 800)]
+        ref = G[:2 * half]
+        alt = np.concatenate([G[:half], G[half + 700:half + 700 + half]])   # deletion of 700 bp at the breakpoint
+        own = ref if r % 2 else alt
+        probe = _ont(rng, own, err)[:2 * half]
+        if weird:
+            k = r % 9
+            if k == 0:
+                probe = probe[:0]
+            elif k == 1:
+                probe = probe[:int(rng.integers(1, 40))]
+            elif k == 2 and probe.size:
+                probe = probe.copy()
+                probe[rng.integers(0, probe.size, 5)] = np.frombuffer(b"NRacg", dtype=np.uint8)
+            elif k == 3:
+                ref = np.concatenate([ref] * 4)[:6300 + int(rng.integers(0, 100))]       # pattern limit: the other string is shorter
+            elif k == 4:
+                ref = np.concatenate([ref] * 8)[:6200]
+                probe = np.concatenate([probe] * 8)[:6150]                               # both beyond 6144: E_LIMIT
+        po = put(np.ascontiguousarray(probe))
+        rows.append((put(np.ascontiguousarray(ref)), po, ref.size, probe.size))
+        rows.append((put(np.ascontiguousarray(alt)), po, alt.size, probe.size))
+    jobs = np.zeros(len(rows), dtype=abi.nw_job_dtype())
+    for k, name in enumerate(("query_off", "target_off", "query_len", "target_len")):
+        jobs[name] = [x[k] for x in rows]
+    return jobs, (np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8))

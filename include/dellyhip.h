@@ -252,6 +252,31 @@ void dellyhip_jobs_free(dellyhip_ctx* ctx, dellyhip_jobs* b);
 /* Average duration (ms) of classify_kernel over the runs since the last call (HIP events on the launch stream). */
 int dellyhip_jobs_kernel_ms(dellyhip_ctx* ctx, dellyhip_jobs* b, double* ms, int32_t* launches);
 
+/* ---- long-read genotyping: batched _editDistanceNW ------ */
+
+/* One _editDistanceNW(query, target) call of src/genotype.h:21-30 (edlibAlign(..., k = -1, EDLIB_MODE_NW,
+ * EDLIB_TASK_DISTANCE)) as made per read and breakpoint at src/genotype.h:276,284 (ref / alt allele slice vs
+ * read slice, each 2 * offset bytes).  Both strings are ranges of one byte blob. */
+typedef struct dellyhip_nw_job {
+  uint64_t query_off;
+  uint64_t target_off;
+  uint32_t query_len;
+  uint32_t target_len;
+} dellyhip_nw_job;
+
+/* distances[i] = editDistance of job i (max(len) if one string is empty, src/edlib.cpp:157-163), or
+ * DELLYHIP_E_LIMIT when BOTH strings exceed 6144 bytes.  One job per 64-lane wavefront, Myers bit-vectors. */
+int dellyhip_edit_distance_nw_batch(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_nw_job* jobs,
+                                    const char* blob, uint64_t blob_len, int32_t* distances);
+/* Device-resident flavour (bench / pipelined callers), as dellyhip_jobs_*. */
+typedef struct dellyhip_nwjobs dellyhip_nwjobs;
+int dellyhip_nwjobs_upload(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob,
+                           uint64_t blob_len, dellyhip_nwjobs** out);
+int dellyhip_nwjobs_run(dellyhip_ctx* ctx, dellyhip_nwjobs* b, void* stream);
+int dellyhip_nwjobs_fetch(dellyhip_ctx* ctx, dellyhip_nwjobs* b, int32_t* distances);
+void dellyhip_nwjobs_free(dellyhip_ctx* ctx, dellyhip_nwjobs* b);
+int dellyhip_nwjobs_kernel_ms(dellyhip_ctx* ctx, dellyhip_nwjobs* b, double* ms, int32_t* launches);
+
 /* ---- single-item wrappers (parity tests, assemble.h / asmode.h call sites) */
 
 /* bool longNeedle(s1, s2, align, AlignConfig<true,false>, DnaScore(1,-1,-1,-1))

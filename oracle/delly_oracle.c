@@ -2053,3 +2053,52 @@ int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip
   free(th);
   return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Long-read genotyping: _editDistanceNW, src/genotype.h:21-30 -- edlib's global
+ * edit distance with k = -1 (always found), restated as the two-row unit-cost DP.
+ * ------------------------------------------------------------------------------------------------ */
+static int nw_distance(const char* q, int qn, const char* t, int tn) {
+  if (qn == 0 || tn == 0) return imax(qn, tn);   /* src/edlib.cpp:157-163 */
+  int* col = (int*)malloc(sizeof(int) * (size_t)(qn + 1));
+  for (int i = 0; i <= qn; ++i) col[i] = i;
+  for (int j = 1; j <= tn; ++j) {
+    int diag = col[0];
+    col[0] = j;
+    for (int i = 1; i <= qn; ++i) {
+      int v = diag + (q[i - 1] != t[j - 1]);
+      diag = col[i];
+      if (col[i] + 1 < v) v = col[i] + 1;
+      if (col[i - 1] + 1 < v) v = col[i - 1] + 1;
+      col[i] = v;
+    }
+  }
+  const int d = col[qn];
+  free(col);
+  return d;
+}
+
+typedef struct { const dellyhip_nw_job* jobs; const char* blob; int32_t* out; uint64_t n; volatile uint64_t* next; } nw_work;
+
+static void* nw_worker(void* arg) {
+  nw_work* w = (nw_work*)arg;
+  for (;;) {
+    const uint64_t i = __sync_fetch_and_add(w->next, 1);
+    if (i >= w->n) break;
+    const dellyhip_nw_job* J = &w->jobs[i];
+    w->out[i] = nw_distance(w->blob + J->query_off, (int)J->query_len, w->blob + J->target_off, (int)J->target_len);
+  }
+  return NULL;
+}
+
+int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads) {
+  volatile uint64_t next = 0;
+  nw_work w = {jobs, blob, out, n_jobs, &next};
+  if (n_threads <= 1) { nw_worker(&w); return 0; }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, nw_worker, &w);
+  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  free(th);
+  return 0;
+}

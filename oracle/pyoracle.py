@@ -204,6 +204,17 @@ class Oracle:
             raise RuntimeError("oracle classify_reads rc=%d" % rc)
         return res
 
+    def edit_distance_nw_batch(self, jobs, blob, n_threads=1):
+        """_editDistanceNW (src/genotype.h:21-30) for every pair -> int32 distances"""
+        blob = _u8(blob)
+        jobs = np.ascontiguousarray(jobs, dtype=abi.nw_job_dtype())
+        out = np.zeros(jobs.shape[0], dtype=np.int32)
+        rc = self._f("edit_distance_nw_batch")(C.c_uint64(jobs.shape[0]), C.c_void_p(jobs.ctypes.data), _p(blob),
+                                               C.c_void_p(out.ctypes.data), int(n_threads))
+        if rc:
+            raise RuntimeError("oracle edit_distance_nw_batch rc=%d" % rc)
+        return out
+
     def unordered_set_order(self, reads):
         assert self.kind == "reference"
         blob, off = self._pack(reads)

@@ -523,3 +523,25 @@ extern "C" int dref_classify_reads(const dellyhip_params* p, uint64_t n_jobs, co
   }
   return 0;
 }
+
+
+// ---- long-read genotyping: the reference's _editDistanceNW (src/genotype.h:21-30, derived header) per pair ----
+extern "C" int dref_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out,
+                                           int n_threads) {
+  std::atomic<uint64_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_jobs) break;
+      const dellyhip_nw_job& J = jobs[i];
+      out[i] = torali::_editDistanceNW(std::string(blob + J.query_off, J.query_len), std::string(blob + J.target_off, J.target_len));
+    }
+  };
+  if (n_threads <= 1) worker();
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  return 0;
+}

@@ -181,6 +181,18 @@ def align_job_vectors(ref):
     print("align_jobs ok:", {k: int(v.shape[0]) for k, v in d.items() if k.endswith("_results")})
 
 
+def nw_job_vectors(ref):
+    """long-read genotyping pairs (src/genotype.h:21-30,276,284): the reference's _editDistanceNW per pair"""
+    d = {}
+    for label, kw in (("plain", dict(n_reads=48, seed=31)), ("weird", dict(n_reads=45, seed=32, weird=True))):
+        jobs, blob = synth.make_nw_jobs(**kw)
+        d[label + "_dist"] = ref.edit_distance_nw_batch(jobs, blob)
+        d[label + "_jobs"] = jobs
+        d[label + "_blob"] = blob
+    np.savez_compressed(os.path.join(HERE, "nw_jobs.npz"), **d)
+    print("nw_jobs ok:", {k: int(v.shape[0]) for k, v in d.items() if k.endswith("_dist")})
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Oracle("reference")
@@ -191,6 +203,8 @@ def main():
         long_read_vectors(ref)
     if not only or "align_jobs" in only:
         align_job_vectors(ref)
+    if not only or "nw_jobs" in only:
+        nw_job_vectors(ref)
     # --- batches ---------------------------------------------------------------
     for name, (n, kw) in BATCHES.items():
         if only and name not in only:

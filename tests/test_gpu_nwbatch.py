@@ -1,0 +1,53 @@
+"""-m gpu parity of the batched _editDistanceNW (src/genotype.h:21-30, call sites :276,:284): HIP vs the
+reference-generated golden distances and vs the C restatement, through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from delly_amd import abi, refine, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "nw_jobs.npz")
+
+
+def _check(got, want, jobs):
+    big = np.minimum(jobs["query_len"], jobs["target_len"]) > 6144
+    assert (got[big] == abi.E_LIMIT).all()
+    bad = np.nonzero(got[~big] != want[~big])[0]
+    assert bad.size == 0, (bad[:8], got[~big][bad[:8]], want[~big][bad[:8]])
+
+
+@pytest.mark.parametrize("label", ["plain", "weird"])
+def test_nw_batch_reproduces_reference_distances(gpu_ctx, label):
+    z = np.load(GOLD)
+    jobs, blob, want = z[label + "_jobs"], z[label + "_blob"], z[label + "_dist"]
+    got = gpu_ctx.edit_distance_nw_batch(jobs, blob)
+    _check(got, want, jobs)
+    if label == "weird":
+        assert (got == abi.E_LIMIT).sum() > 0
+
+
+def test_nw_batch_vs_port(gpu_ctx, port):
+    jobs, blob = synth.make_nw_jobs(60, seed=77, weird=True, min_half=300, max_half=1400)
+    want = port.edit_distance_nw_batch(jobs, blob, n_threads=8)
+    _check(gpu_ctx.edit_distance_nw_batch(jobs, blob), want, jobs)
+
+
+def test_nw_batch_edges_and_resident(gpu_ctx, port):
+    assert gpu_ctx.edit_distance_nw_batch(np.zeros(0, dtype=abi.nw_job_dtype()), np.zeros(0, dtype=np.uint8)).shape[0] == 0
+    jobs, blob = synth.make_nw_jobs(300, seed=5)
+    rj = refine.ResidentNwJobs(gpu_ctx, jobs, blob)
+    rj.run()
+    a = rj.fetch()
+    rj.run()
+    b = rj.fetch()
+    ms, launches = rj.kernel_ms()
+    rj.free()
+    assert launches == 2 and ms > 0 and (a == b).all()
+    sel = np.arange(0, jobs.shape[0], 11)
+    assert (a[sel] == port.edit_distance_nw_batch(jobs[sel], blob, n_threads=8)).all()
+    bad = jobs[:1].copy()
+    bad["target_len"] = blob.size + 1
+    with pytest.raises(refine.DellyHipError):
+        gpu_ctx.edit_distance_nw_batch(bad, blob)

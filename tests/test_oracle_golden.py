@@ -118,6 +118,14 @@ def test_port_reproduces_golden_align_jobs(port):
         assert got.tobytes() == z[label + "_results"].tobytes(), label
 
 
+def test_port_reproduces_golden_nw_jobs(port):
+    """long-read genotyping (src/genotype.h:21-30): reference-generated distances"""
+    z = np.load(os.path.join(GOLD, "nw_jobs.npz"))
+    for label in ("plain", "weird"):
+        got = port.edit_distance_nw_batch(z[label + "_jobs"], z[label + "_blob"], n_threads=4)
+        assert (got == z[label + "_dist"]).all(), label
+
+
 def test_port_classifier_vs_reference_fresh(port, reference):
     for seed, weird, fq in ((21, False, 0.95), (22, True, 0.95), (23, True, 0.45), (24, True, 0.0)):
         jobs, blob = synth.make_align_jobs(25, 12, seed=seed, weird=weird)
