@@ -89,7 +89,7 @@ def _subbatch(batch, n):
                        batch.with_msa, batch.truth[:n])
 
 
-def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
+def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     """Not the headline: what `delly sr` / `delly lr` pay per junction beyond unit U -- msa of N reads +
     alignConsensus (U_full), the insertion path (splitAlign/edlib) and the long-read shapes
     of BASELINE config C4 -- each over a resident batch, whole-step wall clock.  with_cpu: the same
@@ -110,9 +110,13 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
             ("ins_svt4", 5000, 5000, dict(mode="ins")),
             ("lr_c4_align_consensus", 2048, 96, dict(mode="lr", sub_rate=0.01)),
             ("lr_c4_msaedlib_n15", 768, 48, dict(mode="lr", n_reads=15, sub_rate=0.06)))
+    want = (lambda name: True) if not only else (lambda name: name in only)
+    plan = tuple(x for x in plan if want(x[0]))
     # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
     # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
     try:
+        if not want("u_c2_two_batches_in_flight"):
+            raise KeyError("skipped")
         import torch
         ctx2 = refine.Context(device=device)
         pairs = []
@@ -140,6 +144,8 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
         for rb, _ in pairs:
             rb.free()
         ctx2.close()
+    except KeyError:
+        pass
     except Exception as e:  # side figure only
         out["u_c2_two_batches_in_flight"] = {"error": repr(e)}
     for name, n, ncpu, kw in plan:
@@ -176,6 +182,8 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
     # the split-read genotyping classifier (src/coverage.h:412-434), one process_batch of
     # 131072 x 8 AlignJobs (:271) resident in HBM: 26..37-byte probes against 150-byte reads
     try:
+        if not want("sr_genotype_classifier"):
+            raise KeyError("skipped")
         import numpy as np
         base_jobs, base_blob = synth.make_align_jobs(160, 40, seed=9)
         tiles = (131072 * 8 + base_jobs.shape[0] - 1) // base_jobs.shape[0]
@@ -206,18 +214,21 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
         cx.close()
         if orc is not None:
             sub = slice(0, 40 * base_jobs.shape[0])
-            t0 = time.perf_counter()
-            ref = orc.classify_reads(jobs[sub], blob, n_threads=cores)
-            dtc = time.perf_counter() - t0
-            same = all((ref[f] == res[sub][f]).all() for f in ("type", "qual", "dist_alt", "dist_ref"))
+            ref = orc.classify_reads(jobs[sub], blob, n_threads=cores, with_dist=False)
+            dtc = orc.worker_seconds   # the thread-pool region of process_batch alone
+            same = all((ref[f] == res[sub][f]).all() for f in ("type", "qual", "sv_id", "file_index"))
             out["sr_genotype_classifier"]["cpu_" + orc.kind] = {"jobs_per_s": ref.shape[0] / dtc, "cores": cores,
                                                                 "sample": "%d jobs, %.2f s" % (ref.shape[0], dtc),
                                                                 "identical_to_gpu": bool(same)}
+    except KeyError:
+        pass
     except Exception as e:  # side figure only
         out["sr_genotype_classifier"] = {"error": repr(e)}
     # long-read genotyping, _editDistanceNW (src/genotype.h:21-30,276,284): read slice vs REF and
     # ALT slices of 1000..2000 bytes, 6 % ONT-like error
     try:
+        if not want("lr_genotype_edit_distance_nw"):
+            raise KeyError("skipped")
         import numpy as np
         base_jobs, base_blob = synth.make_nw_jobs(512, seed=19)
         tiles = 16
@@ -243,17 +254,17 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True):
         rj.free()
         cx.close()
         if orc is not None:
-            sub = slice(0, 4 * base_jobs.shape[0])
-            t0 = time.perf_counter()
+            sub = slice(0, nj)
             ref = orc.edit_distance_nw_batch(jobs[sub], blob, n_threads=cores)
-            dtc = time.perf_counter() - t0
-            t0 = time.perf_counter()
+            dtc = orc.worker_seconds
             orc.edit_distance_nw_batch(jobs[:256], blob, n_threads=1)
-            dt1 = time.perf_counter() - t0
+            dt1 = orc.worker_seconds
             out["lr_genotype_edit_distance_nw"]["cpu_" + orc.kind] = {
                 "pairs_per_s": ref.shape[0] / dtc, "cores": cores, "sample": "%d pairs, %.2f s" % (ref.shape[0], dtc),
                 "pairs_per_s_one_thread": 256 / dt1, "identical_to_gpu": bool((ref == dist[sub]).all()),
                 "note": "the reference calls _editDistanceNW serially per read (src/genotype.h:262-284)"}
+    except KeyError:
+        pass
     except Exception as e:  # side figure only
         out["lr_genotype_edit_distance_nw"] = {"error": repr(e)}
     return out
@@ -267,6 +278,7 @@ def main():
     ap.add_argument("--junctions", type=int, default=10000, help="junctions per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
+    ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
     args = ap.parse_args()
 
     import torch
@@ -371,7 +383,8 @@ def main():
         if world == 1 and not args.no_extras:
             rb.free()
             rb = None
-            out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline)
+            out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline,
+                                                only=set(filter(None, args.only_extras.split(','))) or None)
         print(json.dumps(out), flush=True)
     if rb is not None:
         rb.free()

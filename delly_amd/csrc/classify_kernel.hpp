@@ -9,7 +9,7 @@
 // the job in lock-step over the same read bytes.  The probes' equality masks sit in LDS, indexed
 // [probe][word][letter][lane] (bank-conflict free, one ds_read_b64 per probe and column); the read is
 // fetched 16 bytes per lane and load.  Probes of 65 .. 256 bytes (rare) go through the same code
-// with four words per probe in a second, small launch.
+// with four words per probe in a second, small launch; wavefronts whose probes all fit 32 rows use 32-bit words.
 #pragma once
 #include "split_kernel.hpp"
 
@@ -78,37 +78,41 @@ __device__ __forceinline__ double cls_score(int dist, int m, float fq) {
   return ((1.0 - (double)fq) * (double)m) / (double)(dist + 1);
 }
 
-// One text column for NP probes in lock-step (P/M/score/best: the per-probe Myers states).
-template <int NW, int NP, bool SLOW>
+// One text column for NP probes in lock-step (P/M/score/best: the per-probe Myers states).  WT = the word type:
+// uint64_t in general, uint32_t when every probe of the wavefront fits 32 rows (half the VALU work).
+template <typename WT, int NW, int NP, bool SLOW>
 __device__ __forceinline__ void cls_column(const ClsLds<NW>& L, int c, bool valid, int lane, int p0,
-                                           const uint8_t* const (&probe)[2], const int (&m)[2], uint64_t (&P)[NP][NW],
-                                           uint64_t (&M)[NP][NW], int (&score)[NP], int (&best)[NP]) {
+                                           const uint8_t* const (&probe)[2], const int (&m)[2], WT (&P)[NP][NW],
+                                           WT (&M)[NP][NW], int (&score)[NP], int (&best)[NP]) {
+  constexpr int WB = (int)sizeof(WT) * 8;
+  static_assert(WB == 64 || NW == 1, "32-bit words: one-word probes only");
   const int ci = (int)L.lut[c] + lane;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const int mm = m[p0 + p];
-    const int wl = (mm - 1) >> 6, bl = (mm - 1) & 63;
+    const int wl = (mm - 1) >> 6, bl = (mm - 1) & (WB - 1);
     int hin = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      uint64_t Eq = L.peq[((p0 + p) * NW + w) * CLS_NCODE * WAVE + ci];
+      const int slot = ((p0 + p) * NW + w) * CLS_NCODE * WAVE + ci;
+      WT Eq = (WB == 64) ? (WT)L.peq[slot] : (WT) reinterpret_cast<const uint32_t*>(L.peq)[2 * slot];
       if (SLOW) {
-        if (cls_code(c) == 5) Eq = cls_eq_slow(probe[p0 + p], mm, w, c);
+        if (cls_code(c) == 5) Eq = (WT)cls_eq_slow(probe[p0 + p], mm, w, c);
       }
-      const uint64_t Pv = P[p][w], Mv = M[p][w];
-      const uint64_t hinNeg = (NW > 1 && hin < 0) ? 1ull : 0ull;
-      const uint64_t Xv = Eq | Mv;
+      const WT Pv = P[p][w], Mv = M[p][w];
+      const WT hinNeg = (NW > 1 && hin < 0) ? 1 : 0;
+      const WT Xv = Eq | Mv;
       Eq |= hinNeg;
-      const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-      uint64_t Ph = Mv | ~(Xh | Pv);
-      uint64_t Mh = Pv & Xh;
+      const WT Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+      WT Ph = Mv | ~(Xh | Pv);
+      WT Mh = Pv & Xh;
       if (NW == 1 || w == wl) score[p] += (int)((Ph >> bl) & 1) - (int)((Mh >> bl) & 1);
-      const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+      const int hout = (int)(Ph >> (WB - 1)) - (int)(Mh >> (WB - 1));
       Ph <<= 1;
       Mh <<= 1;
       if (NW > 1) {
         Mh |= hinNeg;
-        Ph |= (hin > 0) ? 1ull : 0ull;
+        Ph |= (hin > 0) ? 1 : 0;
       }
       P[p][w] = Mh | ~(Xv | Ph);
       M[p][w] = Ph & Xv;
@@ -122,16 +126,16 @@ __device__ __forceinline__ void cls_column(const ClsLds<NW>& L, int c, bool vali
 // Scans the read.  Chunks of 16 columns that every lane of the wavefront owns run unrolled and unmasked
 // (one-word probes without foreign bytes); ragged ends, wide probes and probes with bytes outside ACGTN
 // take the rolled loop.
-template <int NW, int NP, bool SLOW>
+template <typename WT, int NW, int NP, bool SLOW>
 __device__ __forceinline__ void cls_scan(const ClsLds<NW>& L, const uint8_t* seq, int n, int nmin, int nmax, int lane, int p0,
                                          const uint8_t* const (&probe)[2], const int (&m)[2], int (&best)[NP]) {
-  uint64_t P[NP][NW], M[NP][NW];
+  WT P[NP][NW], M[NP][NW];
   int score[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      P[p][w] = ~0ull;
+      P[p][w] = ~(WT)0;
       M[p][w] = 0;
     }
     score[p] = m[p0 + p];
@@ -145,7 +149,7 @@ __device__ __forceinline__ void cls_scan(const ClsLds<NW>& L, const uint8_t* seq
       const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
       for (int f = 0; f < 16; ++f)
-        cls_column<NW, NP, false>(L, (int)((wd[f >> 2] >> ((f & 3) * 8)) & 0xff), true, lane, p0, probe, m, P, M, score, best);
+        cls_column<WT, NW, NP, false>(L, (int)((wd[f >> 2] >> ((f & 3) * 8)) & 0xff), true, lane, p0, probe, m, P, M, score, best);
       cur = nxt;
     }
   }
@@ -155,7 +159,7 @@ __device__ __forceinline__ void cls_scan(const ClsLds<NW>& L, const uint8_t* seq
     const int fend = min(16, nmax - base);
 #pragma unroll 1
     for (int f = 0; f < fend; ++f) {
-      cls_column<NW, NP, SLOW>(L, (int)(lo & 0xff), base + f < n, lane, p0, probe, m, P, M, score, best);
+      cls_column<WT, NW, NP, SLOW>(L, (int)(lo & 0xff), base + f < n, lane, p0, probe, m, P, M, score, best);
       lo = (lo >> 8) | (hi << 56);
       hi >>= 8;
     }
@@ -225,13 +229,15 @@ __global__ __launch_bounds__(WAVE) void classify_kernel(ClsArgs A) {
     const bool any_other = __ballot(other) != 0;
     int best[2] = {0, 0};
     if (NW == 1) {
-      if (!any_other) cls_scan<NW, 2, false>(L, seq, n, nmin, nmax, lane, 0, probe, m, best);
-      else cls_scan<NW, 2, true>(L, seq, n, nmin, nmax, lane, 0, probe, m, best);
+      const int mmax = cls_wave_max(max(m[0], m[1]));
+      if (any_other) cls_scan<uint64_t, NW, 2, true>(L, seq, n, nmin, nmax, lane, 0, probe, m, best);
+      else if (mmax <= 32) cls_scan<uint32_t, 1, 2, false>(reinterpret_cast<const ClsLds<1>&>(L), seq, n, nmin, nmax, lane, 0, probe, m, best);
+      else cls_scan<uint64_t, NW, 2, false>(L, seq, n, nmin, nmax, lane, 0, probe, m, best);
     } else {
       int b1[1];
-      cls_scan<NW, 1, true>(L, seq, n, nmin, nmax, lane, 0, probe, m, b1);
+      cls_scan<uint64_t, NW, 1, true>(L, seq, n, nmin, nmax, lane, 0, probe, m, b1);
       best[0] = b1[0];
-      cls_scan<NW, 1, true>(L, seq, n, nmin, nmax, lane, 1, probe, m, b1);
+      cls_scan<uint64_t, NW, 1, true>(L, seq, n, nmin, nmax, lane, 1, probe, m, b1);
       best[1] = b1[0];
     }
     if (active || limit) {

@@ -12,6 +12,7 @@
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------ */
 /* small helpers                                                             */
@@ -2042,15 +2043,26 @@ static void* cls_worker(void* arg) {
   return NULL;
 }
 
+static double now_seconds(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
-                       dellyhip_align_result* out, int n_threads) {
+                       dellyhip_align_result* out, int n_threads, int with_dist, double* worker_seconds) {
+  (void)with_dist;   /* the restatement computes each distance once and always reports it */
   volatile uint64_t next = 0;
   cls_work w = {p, jobs, blob, out, n_jobs, &next};
-  if (n_threads <= 1) { cls_worker(&w); return 0; }
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, cls_worker, &w);
-  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
-  free(th);
+  const double t0 = now_seconds();
+  if (n_threads <= 1) cls_worker(&w);
+  else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, cls_worker, &w);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+  }
+  if (worker_seconds) *worker_seconds = now_seconds() - t0;
   return 0;
 }
 
@@ -2092,13 +2104,18 @@ static void* nw_worker(void* arg) {
   return NULL;
 }
 
-int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads) {
+int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads,
+                               double* worker_seconds) {
   volatile uint64_t next = 0;
   nw_work w = {jobs, blob, out, n_jobs, &next};
-  if (n_threads <= 1) { nw_worker(&w); return 0; }
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-  for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, nw_worker, &w);
-  for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
-  free(th);
+  const double t0 = now_seconds();
+  if (n_threads <= 1) nw_worker(&w);
+  else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, nw_worker, &w);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+  }
+  if (worker_seconds) *worker_seconds = now_seconds() - t0;
   return 0;
 }

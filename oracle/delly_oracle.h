@@ -54,9 +54,10 @@ int dor_msa_wfa(const dellyhip_params* p, int n_reads, const char* blob, const u
                 const char* suffix, int sn, char* cs, int cap, int* cs_len);
 /* worker body of process_batch, src/coverage.h:418-434 (split-read genotyping classifier) */
 int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs, const char* blob,
-                       dellyhip_align_result* out, int n_threads);
+                       dellyhip_align_result* out, int n_threads, int with_dist, double* worker_seconds);
 /* _editDistanceNW src/genotype.h:21-30 for every pair (long-read genotyping) */
-int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads);
+int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads,
+                               double* worker_seconds);
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

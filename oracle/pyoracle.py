@@ -192,14 +192,16 @@ class Oracle:
                                   _p(pre), pre.size, _p(suf), suf.size, _p(cs), cap, C.byref(ln))
         return rows, cs[:ln.value].tobytes()
 
-    def classify_reads(self, jobs, blob, params=None, n_threads=1):
+    def classify_reads(self, jobs, blob, params=None, n_threads=1, with_dist=True):
         """worker body of process_batch (src/coverage.h:418-434) for every job -> structured result array"""
         p = params if params is not None else self.params
         blob = _u8(blob)
         jobs = np.ascontiguousarray(jobs, dtype=abi.align_job_dtype())
         res = np.zeros(jobs.shape[0], dtype=abi.align_result_dtype())
+        sec = C.c_double(0)
         rc = self._f("classify_reads")(C.byref(p), C.c_uint64(jobs.shape[0]), C.c_void_p(jobs.ctypes.data), _p(blob),
-                                       C.c_void_p(res.ctypes.data), int(n_threads))
+                                       C.c_void_p(res.ctypes.data), int(n_threads), int(bool(with_dist)), C.byref(sec))
+        self.worker_seconds = sec.value   # the parallel region alone (bench.py cpu_baseline leg)
         if rc:
             raise RuntimeError("oracle classify_reads rc=%d" % rc)
         return res
@@ -209,8 +211,10 @@ class Oracle:
         blob = _u8(blob)
         jobs = np.ascontiguousarray(jobs, dtype=abi.nw_job_dtype())
         out = np.zeros(jobs.shape[0], dtype=np.int32)
+        sec = C.c_double(0)
         rc = self._f("edit_distance_nw_batch")(C.c_uint64(jobs.shape[0]), C.c_void_p(jobs.ctypes.data), _p(blob),
-                                               C.c_void_p(out.ctypes.data), int(n_threads))
+                                               C.c_void_p(out.ctypes.data), int(n_threads), C.byref(sec))
+        self.worker_seconds = sec.value
         if rc:
             raise RuntimeError("oracle edit_distance_nw_batch rc=%d" % rc)
         return out

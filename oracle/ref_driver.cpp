@@ -18,6 +18,7 @@
 #include "ref_prelude.h"
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <unordered_set>
 
@@ -474,52 +475,65 @@ int dref_unordered_set_order(int n_reads, const char* blob, const uint64_t* off,
 // _editDistanceHW, AlignJob and AlignResult are the reference's (coverage_jobs.h); the ten lines of the
 // lambda body live inside genotype code that needs htslib, so they are replayed here statement by statement.
 extern "C" int dref_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip_align_job* jobs,
-                                   const char* blob, dellyhip_align_result* out, int n_threads) {
+                                   const char* blob, dellyhip_align_result* out, int n_threads, int with_dist,
+                                   double* worker_seconds) {
   RefConfig c = make_config(p);
+  // the job buffer of src/coverage.h:411,541 (strings are copied when the BAM loop pushes a job, not by the workers)
+  std::vector<torali::AlignJob> jobBuf;
+  jobBuf.reserve(n_jobs);
+  for (uint64_t i = 0; i < n_jobs; ++i) {
+    const dellyhip_align_job& J = jobs[i];
+    jobBuf.push_back(torali::AlignJob(std::string(blob + J.cons_off, J.cons_len), std::string(blob + J.ref_off, J.ref_len),
+                                      std::string(blob + J.seq_off, J.seq_len), J.file_index, J.sv_id, J.qual));
+  }
+  std::vector<torali::AlignResult> results(n_jobs, torali::AlignResult());
   std::atomic<uint64_t> next(0);   // as process_batch: workers pull job indices from one atomic counter (:414-417)
   auto worker = [&]() {
-  for (;;) {
-    const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
-    if (i >= n_jobs) break;
-    const dellyhip_align_job& J = jobs[i];
-    torali::AlignJob job(std::string(blob + J.cons_off, J.cons_len), std::string(blob + J.ref_off, J.ref_len),
-                         std::string(blob + J.seq_off, J.seq_len), J.file_index, J.sv_id, J.qual);
-    torali::AlignResult r;
-    double scoreAlt = torali::_editDistanceHW(c, job.consProbe, job.sequence);
-    double scoreRef = torali::_editDistanceHW(c, job.refProbe, job.sequence);
-    if ((scoreRef > 0.7) || (scoreAlt > 0.7)) {
-      r.svId = job.svId;
-      r.fileIndex = job.fileIndex;
-      if (scoreRef > scoreAlt) {
-        r.type = 'R';
-        r.qual = (uint8_t) std::min(255, std::min((int) (scoreRef * 35), (int) job.qual));
-      } else {
-        r.type = 'A';
-        r.qual = (uint8_t) std::min(255, std::min((int) (scoreAlt * 35), (int) job.qual));
+    for (;;) {
+      const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_jobs) break;
+      torali::AlignJob& job = jobBuf[i];
+      double scoreAlt = torali::_editDistanceHW(c, job.consProbe, job.sequence);
+      double scoreRef = torali::_editDistanceHW(c, job.refProbe, job.sequence);
+      if ((scoreRef > 0.7) || (scoreAlt > 0.7)) {
+        results[i].svId = job.svId;
+        results[i].fileIndex = job.fileIndex;
+        if (scoreRef > scoreAlt) {
+          results[i].type = 'R';
+          results[i].qual = (uint8_t) std::min(255, std::min((int) (scoreRef * 35), (int) job.qual));
+        } else {
+          results[i].type = 'A';
+          results[i].qual = (uint8_t) std::min(255, std::min((int) (scoreAlt * 35), (int) job.qual));
+        }
       }
     }
-    // the two distances behind the scores, from the reference's own edlib with the reference's k
-    auto dist = [&](std::string const& q) {
-      EdlibAlignResult a = edlibAlign(q.c_str(), q.size(), job.sequence.c_str(), job.sequence.size(),
-                                      edlibNewAlignConfig(2 * c.flankQuality * q.size(), EDLIB_MODE_HW, EDLIB_TASK_DISTANCE, NULL, 0));
-      int d = a.editDistance;
-      edlibFreeAlignResult(a);
-      return d;
-    };
-    out[i].file_index = r.fileIndex;
-    out[i].sv_id = r.svId;
-    out[i].dist_alt = dist(job.consProbe);
-    out[i].dist_ref = dist(job.refProbe);
-    out[i].type = (uint8_t)r.type;
-    out[i].qual = r.qual;
-    out[i].status = 0;
-  }
   };
+  const auto t0 = std::chrono::steady_clock::now();
   if (n_threads <= 1) worker();
   else {
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
     for (auto& t : th) t.join();
+  }
+  if (worker_seconds) *worker_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (uint64_t i = 0; i < n_jobs; ++i) {
+    out[i].file_index = results[i].fileIndex;
+    out[i].sv_id = results[i].svId;
+    out[i].type = (uint8_t)results[i].type;
+    out[i].qual = results[i].qual;
+    out[i].status = 0;
+    out[i].dist_alt = out[i].dist_ref = 0;
+    if (with_dist) {   // the two distances behind the scores, from the reference's own edlib with the reference's k
+      auto dist = [&](std::string const& q) {
+        EdlibAlignResult a = edlibAlign(q.c_str(), q.size(), jobBuf[i].sequence.c_str(), jobBuf[i].sequence.size(),
+                                        edlibNewAlignConfig(2 * c.flankQuality * q.size(), EDLIB_MODE_HW, EDLIB_TASK_DISTANCE, NULL, 0));
+        int d = a.editDistance;
+        edlibFreeAlignResult(a);
+        return d;
+      };
+      out[i].dist_alt = dist(jobBuf[i].consProbe);
+      out[i].dist_ref = dist(jobBuf[i].refProbe);
+    }
   }
   return 0;
 }
@@ -527,21 +541,27 @@ extern "C" int dref_classify_reads(const dellyhip_params* p, uint64_t n_jobs, co
 
 // ---- long-read genotyping: the reference's _editDistanceNW (src/genotype.h:21-30, derived header) per pair ----
 extern "C" int dref_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out,
-                                           int n_threads) {
+                                           int n_threads, double* worker_seconds) {
+  std::vector<std::string> q(n_jobs), t(n_jobs);   // the ref / alt / probe strings exist before the calls (src/genotype.h:270-272)
+  for (uint64_t i = 0; i < n_jobs; ++i) {
+    q[i].assign(blob + jobs[i].query_off, jobs[i].query_len);
+    t[i].assign(blob + jobs[i].target_off, jobs[i].target_len);
+  }
   std::atomic<uint64_t> next(0);
   auto worker = [&]() {
     for (;;) {
       const uint64_t i = next.fetch_add(1, std::memory_order_relaxed);
       if (i >= n_jobs) break;
-      const dellyhip_nw_job& J = jobs[i];
-      out[i] = torali::_editDistanceNW(std::string(blob + J.query_off, J.query_len), std::string(blob + J.target_off, J.target_len));
+      out[i] = torali::_editDistanceNW(q[i], t[i]);
     }
   };
+  const auto t0 = std::chrono::steady_clock::now();
   if (n_threads <= 1) worker();
   else {
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
     for (auto& t : th) t.join();
   }
+  if (worker_seconds) *worker_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
