@@ -136,6 +136,25 @@ class NwJob(C.Structure):
     ]
 
 
+class Probes(C.Structure):
+    """dellyhip_probes: consProbeArr / refProbeArr / BpRegion of _generateProbes (src/coverage.h:230-258)."""
+    _fields_ = [
+        ("svid", C.c_int32),
+        ("ok", C.c_int32),
+        ("hom_left", C.c_int32),
+        ("hom_right", C.c_int32),
+        ("region_start0", C.c_int32), ("region_start1", C.c_int32),
+        ("region_end0", C.c_int32), ("region_end1", C.c_int32),
+        ("bppos0", C.c_int32), ("bppos1", C.c_int32),
+        ("cons_len0", C.c_int32), ("cons_len1", C.c_int32),
+        ("ref_len0", C.c_int32), ("ref_len1", C.c_int32),
+        ("cons_off0", C.c_uint64), ("cons_off1", C.c_uint64),
+        ("ref_off0", C.c_uint64), ("ref_off1", C.c_uint64),
+        ("status", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
 # numpy structured dtypes with the same layout (for vectorised comparisons)
 def _np_dtype(struct):
     import numpy as np
@@ -168,3 +187,7 @@ def align_result_dtype():
 
 def nw_job_dtype():
     return _np_dtype(NwJob)
+
+
+def probes_dtype():
+    return _np_dtype(Probes)

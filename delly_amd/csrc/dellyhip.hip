@@ -23,6 +23,7 @@
 #include "lrins_kernel.hpp"
 #include "lrwfa_kernel.hpp"
 #include "classify_kernel.hpp"
+#include "probes_kernel.hpp"
 
 namespace {
 
@@ -92,6 +93,8 @@ struct dellyhip_ctx {
 struct SmallInv { int32_t j, full_len, offset; };   // long-read loop, small inversions (src/assemble.h:840-853)
 
 struct dellyhip_batch {
+  bool ever_run = false;
+  int probe_mode = 0;   // _generateProbes flavour: no early length test (src/split.h:647), bit 1 of params.reserved on the device
   int32_t n = 0;
   uint64_t n_seq = 0;
   int with_msa = 0;
@@ -232,6 +235,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   a.chr_len = c->d_chr_len.p;
   a.n_chr = (int)c->chr_dev.size();
   a.p = c->params;
+  if (b->probe_mode) a.p.reserved |= 2;
   a.res = b->res.p;
   a.out_blob = b->out_blob.p;
   a.out_stride = b->out_stride;
@@ -834,7 +838,10 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
 
 int dellyhip_batch_upload(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
                           const uint64_t* seq_off, uint64_t n_seq, int with_msa, dellyhip_batch** out) {
-  return batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, with_msa, 0, out);
+  if ((with_msa & ~16) < 0 || (with_msa & ~16) > 2) return fail(DELLYHIP_E_ARG, "with_msa");
+  int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, with_msa & ~16, 0, out);
+  if (!rc && (with_msa & 16)) (*out)->probe_mode = 1;
+  return rc;
 }
 
 int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
@@ -967,6 +974,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   b->last = e3[2];
   b->pending = true;
   b->launches++;
+  b->ever_run = true;
   return 0;
 }
 
@@ -1545,6 +1553,75 @@ int dellyhip_edit_distance_nw_batch(dellyhip_ctx* c, uint64_t n_jobs, const dell
   rc = dellyhip_nwjobs_run(c, b, nullptr);
   if (!rc) rc = dellyhip_nwjobs_fetch(c, b, distances);
   dellyhip_nwjobs_free(c, b);
+  return rc;
+}
+
+
+// ---- probe generation (src/coverage.h:164-263), SURVEY.md 8f N3 ------------------------------------------
+static_assert(sizeof(dellyhip_probes) == 96, "C-ABI record layout");
+
+int dellyhip_batch_probes(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_probes* probes, char* out_blob, uint64_t cap,
+                          uint64_t* used) {
+  if (!c || !b || (b->n && !probes) || !used) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (b->with_msa) return fail(DELLYHIP_E_ARG, "probes need a batch with the consensus given (with_msa = 0)");
+  if (!b->ever_run) return fail(DELLYHIP_E_ARG, "run the batch first");
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc) return rc;
+  *used = 0;
+  if (b->n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = ensure_chr_table(c))) return rc;
+  DevBuf<dellyhip_probes> d_rec;
+  DevBuf<uint8_t> d_blob;
+  const size_t slot = 4 * (size_t)dh::PROBE_CAP;
+  if ((rc = d_rec.alloc(b->n)) || (rc = d_blob.alloc(slot * b->n))) return rc;
+  dh::ProbeArgs A{};
+  A.a.junc = b->junc.p;
+  A.a.cons_base = b->seq_blob.p;
+  A.a.cons_off = b->cons_off.p;
+  A.a.cons_len = b->cons_len.p;
+  A.a.chr_seq = c->d_chr_ptr.p;
+  A.a.chr_len = c->d_chr_len.p;
+  A.a.n_chr = (int)c->chr_dev.size();
+  A.a.p = c->params;
+  A.a.res = b->res.p;
+  A.out = d_rec.p;
+  A.blob = d_blob.p;
+  A.n = b->n;
+  hipLaunchKernelGGL(dh::probes_kernel, dim3(std::min(b->n, std::max(1, c->n_cu) * 16)), dim3(dh::WAVE), 0, c->stream, A);
+  HIPCHK(hipGetLastError());
+  std::vector<uint8_t> h_blob(slot * b->n);
+  HIPCHK(hipMemcpyAsync(probes, d_rec.p, sizeof(dellyhip_probes) * b->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(h_blob.data(), d_blob.p, h_blob.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  uint64_t pos = 0;
+  for (int j = 0; j < b->n; ++j) {   // pack the fixed-stride slots
+    dellyhip_probes& P = probes[j];
+    if (!P.ok) continue;
+    for (int bp = 0; bp < 2; ++bp) {
+      for (int which = 0; which < 2; ++which) {
+        uint64_t& off = which ? P.ref_off[bp] : P.cons_off[bp];
+        const int32_t len = which ? P.ref_len[bp] : P.cons_len[bp];
+        if (pos + (uint64_t)len > cap || (len && !out_blob)) return fail(DELLYHIP_E_ARG, "out_blob too small for the probes");
+        if (len) memcpy(out_blob + pos, h_blob.data() + off, (size_t)len);
+        off = pos;
+        pos += (uint64_t)len;
+      }
+    }
+  }
+  *used = pos;
+  return 0;
+}
+
+int dellyhip_generate_probes_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
+                                   const uint64_t* seq_off, uint64_t n_seq, dellyhip_probes* probes, char* out_blob,
+                                   uint64_t cap, uint64_t* used) {
+  dellyhip_batch* b = nullptr;
+  int rc = dellyhip_batch_upload(c, n, junc, seq_blob, seq_off, n_seq, 16, &b);
+  if (rc) return rc;
+  rc = dellyhip_batch_run(c, b, nullptr);
+  if (!rc) rc = dellyhip_batch_probes(c, b, probes, out_blob, cap, used);
+  dellyhip_batch_free(c, b);
   return rc;
 }
 

@@ -487,7 +487,7 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
     }
   }
   if (go && J.svt == 4) { status = DELLYHIP_E_LIMIT; go = false; }   // long-read splitAlign: edlib's Hirschberg regime
-  if (go && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
+  if (go && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
   Seg seg[3];
   int nseg = 0, n = 0;
   if (go) {

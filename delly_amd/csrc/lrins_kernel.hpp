@@ -99,7 +99,7 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
       if (A.cons_base != A.out_blob) X.ob[i] = ch;   // (MSA modes: the consensus already lives in the slot)
     }
   }
-  if (go && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
+  if (go && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
   Seg seg[3];
   int nseg = 0, n = 0;
   if (go) {

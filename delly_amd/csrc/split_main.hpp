@@ -187,7 +187,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     status = DELLYHIP_E_LIMIT;
     go = false;
   }
-  if (go && !X.direct && m < 2 * P.minimum_flank_size + J.ins_len) go = false;  // split.h:647
+  if (go && !X.direct && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;  // split.h:647 (bit 1 of reserved: _generateProbes has no such test)
 
   // _initBreakpoint (tags.h:151-172) + _getSVRef segments (split.h:70-163)
   Seg seg[3];

@@ -30,7 +30,7 @@ EXPORTS = [
     "dellyhip_classify_reads", "dellyhip_jobs_upload", "dellyhip_jobs_run", "dellyhip_jobs_sync", "dellyhip_jobs_fetch",
     "dellyhip_jobs_free", "dellyhip_jobs_kernel_ms",
     "dellyhip_edit_distance_nw_batch", "dellyhip_nwjobs_upload", "dellyhip_nwjobs_run", "dellyhip_nwjobs_fetch",
-    "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms",
+    "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
 ]
 
 
@@ -150,6 +150,22 @@ class Context:
         self._check(self.lib.dellyhip_edit_distance_nw_batch(self._ctx, C.c_uint64(jobs.shape[0]), _p(jobs, C.c_void_p),
                                                              _p(blob), C.c_uint64(blob.size), _p(out, C.c_void_p)))
         return out
+
+    def generate_probes(self, batch):
+        """The per-SV body of _generateProbes (src/coverage.h:196-258) for a synth.Batch with the consensus given
+        -> (probes structured array, blob np.uint8)"""
+        n = batch.n
+        junc = np.ascontiguousarray(batch.junctions)
+        blob = _u8(batch.seq_blob)
+        off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
+        rec = np.zeros(n, dtype=abi.probes_dtype())
+        cap = n * 4 * 640 + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        self._check(self.lib.dellyhip_generate_probes_batch(self._ctx, n, _p(junc, C.c_void_p), _p(blob),
+                                                            _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1),
+                                                            _p(rec, C.c_void_p), _p(out), C.c_uint64(cap), C.byref(used)))
+        return rec, out[:used.value]
 
     def refine(self, batch, want_alignment=False):
         """Convenience for a synth.Batch."""

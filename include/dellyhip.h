@@ -252,6 +252,41 @@ void dellyhip_jobs_free(dellyhip_ctx* ctx, dellyhip_jobs* b);
 /* Average duration (ms) of classify_kernel over the runs since the last call (HIP events on the launch stream). */
 int dellyhip_jobs_kernel_ms(dellyhip_ctx* ctx, dellyhip_jobs* b, double* ms, int32_t* launches);
 
+/* ---- split-read genotyping: probe generation ----------- */
+
+/* What _generateProbes (src/coverage.h:164-263) derives per precise SV from _consRefAlignment + _findSplit
+ * (:214-217): consProbeArr[bpPoint][id], refProbeArr[bpPoint][id] (:255-256) and the BpRegion (:257), for
+ * bpPoint 0 (svStart side) and 1 (svEnd side).  The probe bytes are ranges of out_blob. */
+typedef struct dellyhip_probes {
+  int32_t svid;
+  int32_t ok;              /* _consRefAlignment && _findSplit (no probes otherwise, src/coverage.h:214-217) */
+  int32_t hom_left;        /* ad.homLeft / ad.homRight */
+  int32_t hom_right;
+  int32_t region_start[2]; /* BpRegion(regionStart, regionEnd, bppos, ...) src/coverage.h:236-253 */
+  int32_t region_end[2];
+  int32_t bppos[2];
+  int32_t cons_len[2];
+  int32_t ref_len[2];
+  uint64_t cons_off[2];
+  uint64_t ref_off[2];
+  int32_t status;          /* 0, or DELLYHIP_E_LIMIT (long-read shapes, probe > 640 bytes) */
+  int32_t reserved;
+} dellyhip_probes;
+
+/* _generateProbes' per-SV work for every junction (consensus given: n_seq == 1, as
+ * dellyhip_align_consensus_batch): the same window / alignment / split detection as alignConsensus, WITHOUT
+ * its early length test (src/split.h:647, which _generateProbes does not have), then the four substrings.
+ * Short-read shapes only (|consensus| <= 319, |svRefStr| <= 2048). */
+int dellyhip_generate_probes_batch(dellyhip_ctx* ctx, int32_t n_junctions, const dellyhip_junction* junctions,
+                                   const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq,
+                                   dellyhip_probes* probes, char* out_blob, uint64_t out_blob_cap,
+                                   uint64_t* out_blob_len);
+/* The same for a resident batch that has been run (dellyhip_batch_run): probes are cut from the descriptors
+ * the run left in HBM, nothing is re-aligned.  Upload the batch with (with_msa | 16) to drop the early
+ * length test of alignConsensus as _generateProbes does. */
+int dellyhip_batch_probes(dellyhip_ctx* ctx, dellyhip_batch* b, dellyhip_probes* probes, char* out_blob,
+                          uint64_t out_blob_cap, uint64_t* out_blob_len);
+
 /* ---- long-read genotyping: batched _editDistanceNW ------ */
 
 /* One _editDistanceNW(query, target) call of src/genotype.h:21-30 (edlibAlign(..., k = -1, EDLIB_MODE_NW,

@@ -1756,6 +1756,10 @@ typedef struct {
   _Atomic uint64_t used;
   _Atomic uint32_t next;
   int with_msa, want_alignment;
+  dellyhip_probes* probes;   /* non-NULL: _generateProbes flavour (dor_generate_probes) */
+  _Atomic uint64_t probe_used;
+  char* probe_blob;
+  uint64_t probe_cap;
 } batch_t;
 
 static uint64_t blob_put(batch_t* b, const char* p, uint64_t n) {
@@ -1763,6 +1767,45 @@ static uint64_t blob_put(batch_t* b, const char* p, uint64_t n) {
   if (b->out_blob == NULL || o + n > b->out_cap) return UINT64_MAX;
   if (n) memcpy(b->out_blob + o, p, n);
   return o;
+}
+
+/* _cutRefStart / _cutRefEnd  src/coverage.h:117-162 */
+static int cut_ref(int rStart, int rEnd, int offset, int bpPoint, int svt, int is_end) {
+  const int ct = is_tra(svt) ? svt - 5 : svt;   /* _getSpanOrientation src/tags.h:33-40; plain SVs test svt == 3 */
+  int anchor;
+  if (ct == 3) anchor = (!bpPoint) ? rEnd : rStart;
+  else anchor = bpPoint ? rEnd : rStart;
+  return is_end ? anchor + offset : anchor - offset;
+}
+
+static uint64_t probe_put(batch_t* b, const char* p, uint64_t n) {
+  uint64_t o = atomic_fetch_add(&b->probe_used, n);
+  if (b->probe_blob && o + n <= b->probe_cap) memcpy(b->probe_blob + o, p, (size_t)n);
+  return o;
+}
+
+/* the loop over bpPoint of _generateProbes, src/coverage.h:230-258 (substr semantics: the start lies inside the
+ * string whenever _findSplit succeeded, the length is clipped at its end) */
+static void probes_cut(batch_t* b, const dellyhip_junction* J, const adesc* ad, const char* cons, int m, const char* ref, int n,
+                       dellyhip_probes* O) {
+  const dellyhip_params* c = b->p;
+  const int mfs = c->minimum_flank_size;
+  O->ok = 1;
+  O->hom_left = ad->homLeft;
+  O->hom_right = ad->homRight;
+  for (int bp = 0; bp < 2; ++bp) {
+    const int anchor = bp ? ad->cEnd : ad->cStart;
+    const int cs = anchor - ad->homLeft - mfs, ce = anchor + ad->homRight + mfs;
+    const int rs = cut_ref(ad->rStart, ad->rEnd, ad->homLeft + mfs, bp, J->svt, 0);
+    const int re = cut_ref(ad->rStart, ad->rEnd, ad->homRight + mfs, bp, J->svt, 1);
+    int cl = ce - cs, rl = re - rs;
+    if (cl > m - cs) cl = m - cs;
+    if (rl > n - rs) rl = n - rs;
+    O->cons_len[bp] = cl;
+    O->ref_len[bp] = rl;
+    O->cons_off[bp] = probe_put(b, cons + cs, (uint64_t)cl);
+    O->ref_off[bp] = probe_put(b, ref + rs, (uint64_t)rl);
+  }
 }
 
 static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* R) {
@@ -1823,8 +1866,8 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
     }
   }
 
-  /* alignConsensus  split.h:644-666 */
-  if (m < (2 * c->minimum_flank_size + J->ins_len)) {
+  /* alignConsensus  split.h:644-666 (bit 1 of reserved: _generateProbes, src/coverage.h:196-217, has no length test) */
+  if (!(c->reserved & 2) && m < (2 * c->minimum_flank_size + J->ins_len)) {
     free(cons);
     free(cons_full);
     return;
@@ -1889,6 +1932,7 @@ static void refine_one(batch_t* b, const dellyhip_junction* J, dellyhip_result* 
       R->hom_left = ad.homLeft; R->hom_right = ad.homRight;
       R->matches = (int32_t)ad.ma;
       R->mismatches = (int32_t)ad.mm;
+      if (b->probes) probes_cut(b, J, &ad, cons, m, ref.d, n, &b->probes[J - b->junc]);
       uint32_t gs = 0, ge = 0;
       if (coord_transform(c, (uint64_t)n, &bp, &ad, &gs, &ge, J->svt) && (is_tra(J->svt) || gs < ge)) {
         /* exact alleles split.h:606-624 */
@@ -1954,6 +1998,8 @@ int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr
   b.p = p; b.n_chr = n_chr; b.chr_seq = chr_seq; b.chr_len = chr_len; b.n_junc = n_junc;
   b.junc = junc; b.blob = blob; b.off = off; b.results = results; b.out_blob = out_blob;
   b.out_cap = out_cap; b.with_msa = with_msa; b.want_alignment = want_alignment;
+  b.probes = NULL; b.probe_blob = NULL; b.probe_cap = 0;
+  atomic_init(&b.probe_used, 0);
   atomic_init(&b.used, 0);
   atomic_init(&b.next, 0);
   if (n_threads <= 1) worker(&b);
@@ -2118,4 +2164,44 @@ int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, con
   }
   if (worker_seconds) *worker_seconds = now_seconds() - t0;
   return 0;
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Probe generation: the per-SV body of _generateProbes, src/coverage.h:196-258 --
+ * window, _consRefAlignment, _findSplit (all shared with alignConsensus above, without its length
+ * test), then the probe substrings and the BpRegion fields.  Single-threaded: the reference loop is.
+ * ------------------------------------------------------------------------------------------------ */
+int dor_generate_probes(const dellyhip_params* p, int n_chr, const char* const* chr_seq, const int64_t* chr_len, int n_junc,
+                        const dellyhip_junction* junc, const char* blob, const uint64_t* off, dellyhip_probes* probes,
+                        char* out_blob, uint64_t out_cap, uint64_t* out_used) {
+  dellyhip_params pp = *p;
+  pp.reserved |= 2;
+  dellyhip_result* results = (dellyhip_result*)calloc((size_t)(n_junc > 0 ? n_junc : 1), sizeof(dellyhip_result));
+  batch_t b;
+  b.p = &pp; b.n_chr = n_chr; b.chr_seq = chr_seq; b.chr_len = chr_len; b.n_junc = n_junc;
+  b.junc = junc; b.blob = blob; b.off = off; b.results = results; b.out_blob = NULL;
+  b.out_cap = 0; b.with_msa = 0; b.want_alignment = 0;
+  b.probes = probes; b.probe_blob = out_blob; b.probe_cap = out_cap;
+  atomic_init(&b.probe_used, 0);
+  atomic_init(&b.used, 0);
+  atomic_init(&b.next, 0);
+  const int mfs = pp.minimum_flank_size;
+  for (int i = 0; i < n_junc; ++i) {
+    dellyhip_probes* O = &probes[i];
+    memset(O, 0, sizeof *O);
+    O->svid = junc[i].svid;
+    O->region_start[0] = imax(0, junc[i].sv_start - mfs);                          /* src/coverage.h:244-245 */
+    O->region_end[0] = (int32_t)(((uint32_t)(junc[i].sv_start + mfs) < (uint32_t)chr_len[junc[i].chr]) ? (uint32_t)(junc[i].sv_start + mfs) : (uint32_t)chr_len[junc[i].chr]);
+    O->bppos[0] = junc[i].sv_start;
+    O->region_start[1] = imax(0, junc[i].sv_end - mfs);                            /* :235-236 */
+    O->region_end[1] = (int32_t)(((uint32_t)(junc[i].sv_end + mfs) < (uint32_t)chr_len[junc[i].chr2]) ? (uint32_t)(junc[i].sv_end + mfs) : (uint32_t)chr_len[junc[i].chr2]);
+    O->bppos[1] = junc[i].sv_end;
+  }
+  worker(&b);
+  for (int i = 0; i < n_junc; ++i) probes[i].status = results[i].status;
+  free(results);
+  uint64_t used = atomic_load(&b.probe_used);
+  if (out_used) *out_used = used;
+  return (out_blob && used > out_cap) ? -1 : 0;
 }

@@ -58,6 +58,10 @@ int dor_classify_reads(const dellyhip_params* p, uint64_t n_jobs, const dellyhip
 /* _editDistanceNW src/genotype.h:21-30 for every pair (long-read genotyping) */
 int dor_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_job* jobs, const char* blob, int32_t* out, int n_threads,
                                double* worker_seconds);
+/* per-SV body of _generateProbes, src/coverage.h:196-258 */
+int dor_generate_probes(const dellyhip_params* p, int n_chr, const char* const* chr_seq, const int64_t* chr_len, int n_junc,
+                        const dellyhip_junction* junc, const char* blob, const uint64_t* off, dellyhip_probes* probes,
+                        char* out_blob, uint64_t out_cap, uint64_t* out_used);
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

@@ -219,6 +219,28 @@ class Oracle:
             raise RuntimeError("oracle edit_distance_nw_batch rc=%d" % rc)
         return out
 
+    def generate_probes(self, batch, params=None):
+        """per-SV body of _generateProbes (src/coverage.h:196-258) over a synth.Batch with given consensus
+        -> (probes structured array, blob np.uint8)"""
+        p = params if params is not None else self.params
+        n = batch.n
+        nchr = len(batch.chroms)
+        chr_ptrs = (C.c_char_p * nchr)(*[C.cast(c.ctypes.data, C.c_char_p) for c in batch.chroms])
+        chr_len = np.array([c.size for c in batch.chroms], dtype=np.int64)
+        rec = np.zeros(n, dtype=abi.probes_dtype())
+        cap = n * 4096 + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        used = C.c_uint64(0)
+        junc = np.ascontiguousarray(batch.junctions)
+        blob = _u8(batch.seq_blob)
+        off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
+        rc = self._f("generate_probes")(C.byref(p), nchr, chr_ptrs, _p(chr_len, C.POINTER(C.c_int64)), n,
+                                        C.c_void_p(junc.ctypes.data), _p(blob), _p(off, C.POINTER(C.c_uint64)),
+                                        C.c_void_p(rec.ctypes.data), _p(out), C.c_uint64(cap), C.byref(used))
+        if rc:
+            raise RuntimeError("oracle generate_probes rc=%d" % rc)
+        return rec, out[:used.value]
+
     def unordered_set_order(self, reads):
         assert self.kind == "reference"
         blob, off = self._pack(reads)

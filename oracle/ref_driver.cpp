@@ -565,3 +565,87 @@ extern "C" int dref_edit_distance_nw_batch(uint64_t n_jobs, const dellyhip_nw_jo
   if (worker_seconds) *worker_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
 }
+
+
+// ---- probe generation: the per-SV body of _generateProbes, src/coverage.h:196-258, replayed with the reference's
+// own _initBreakpoint / _getSVRef / _consRefAlignment / _findSplit / _cutRefStart / _cutRefEnd (the enclosing
+// function needs faidx / htslib, so its statements are repeated here in their order) ----
+extern "C" int dref_generate_probes(const dellyhip_params* p, int n_chr, const char* const* chr_seq, const int64_t* chr_len,
+                                    int n_junc, const dellyhip_junction* junc, const char* blob, const uint64_t* off,
+                                    dellyhip_probes* probes, char* out_blob, uint64_t out_cap, uint64_t* out_used) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  std::vector<uint32_t> tlen(n_chr);
+  for (int i = 0; i < n_chr; ++i) tlen[i] = (uint32_t)chr_len[i];
+  bam_hdr_t hdrv;
+  hdrv.n_targets = n_chr;
+  hdrv.target_len = tlen.data();
+  hdrv.target_name = NULL;
+  bam_hdr_t* hdr = &hdrv;
+  BlobWriter bw(out_blob, out_cap);
+  for (int i = 0; i < n_junc; ++i) {
+    const dellyhip_junction& J = junc[i];
+    dellyhip_probes& O = probes[i];
+    std::memset(&O, 0, sizeof(O));
+    O.svid = J.svid;
+    StructuralVariantRecord svr;
+    svr.chr = J.chr; svr.chr2 = J.chr2; svr.svStart = J.sv_start; svr.svEnd = J.sv_end; svr.svt = J.svt;
+    svr.insLen = J.ins_len; svr.id = J.svid;
+    svr.consensus = std::string(blob + off[J.seq_first], blob + off[J.seq_first + 1]);
+    StructuralVariantRecord* itSV = &svr;
+    // regions (:233-253) do not depend on the alignment
+    for (unsigned int bpPoint = 0; bpPoint < 2; ++bpPoint) {
+      if (bpPoint) {
+        O.region_start[1] = std::max(0, itSV->svEnd - c.minimumFlankSize);
+        O.region_end[1] = std::min((uint32_t) (itSV->svEnd + c.minimumFlankSize), hdr->target_len[itSV->chr2]);
+        O.bppos[1] = itSV->svEnd;
+      } else {
+        O.region_start[0] = std::max(0, itSV->svStart - c.minimumFlankSize);
+        O.region_end[0] = std::min((uint32_t) (itSV->svStart + c.minimumFlankSize), hdr->target_len[itSV->chr]);
+        O.bppos[0] = itSV->svStart;
+      }
+    }
+    // :196-217
+    std::string part1;
+    if (itSV->chr != itSV->chr2) {
+      Breakpoint bp(*itSV);
+      _initBreakpoint(hdr, bp, (int32_t) itSV->consensus.size(), itSV->svt);
+      part1 = _getSVRef(c, chr_seq[itSV->chr2], bp, itSV->chr2, itSV->svt);
+    }
+    Breakpoint bp(*itSV);
+    if (_translocation(itSV->svt)) bp.part1 = part1;
+    if (itSV->svt == 4) {
+      int32_t bufferSpace = std::max((int32_t) ((itSV->consensus.size() - itSV->insLen) / 3), c.minimumFlankSize);
+      _initBreakpoint(hdr, bp, bufferSpace, itSV->svt);
+    } else _initBreakpoint(hdr, bp, (int32_t) itSV->consensus.size(), itSV->svt);
+    std::string svRefStr = _getSVRef(c, chr_seq[itSV->chr], bp, itSV->chr, itSV->svt);
+    if (itSV->svt == 4 && svRefStr.size() < 3) { O.status = DELLYHIP_E_LIMIT; continue; }   // splitAlign indexes out of bounds there
+    TAlign align;
+    if (!_consRefAlignment(itSV->consensus, svRefStr, align, itSV->svt)) continue;
+    AlignDescriptor ad;
+    if (!_findSplit(c, itSV->consensus, svRefStr, align, ad, itSV->svt)) continue;
+    O.ok = 1;
+    O.hom_left = ad.homLeft;
+    O.hom_right = ad.homRight;
+    for (unsigned int bpPoint = 0; bpPoint < 2; ++bpPoint) {   // :230-256
+      int32_t cutConsStart, cutConsEnd, cutRefStart, cutRefEnd;
+      if (bpPoint) {
+        cutConsStart = ad.cEnd - ad.homLeft - c.minimumFlankSize;
+        cutConsEnd = ad.cEnd + ad.homRight + c.minimumFlankSize;
+      } else {
+        cutConsStart = ad.cStart - ad.homLeft - c.minimumFlankSize;
+        cutConsEnd = ad.cStart + ad.homRight + c.minimumFlankSize;
+      }
+      cutRefStart = _cutRefStart(ad.rStart, ad.rEnd, ad.homLeft + c.minimumFlankSize, bpPoint, itSV->svt);
+      cutRefEnd = _cutRefEnd(ad.rStart, ad.rEnd, ad.homRight + c.minimumFlankSize, bpPoint, itSV->svt);
+      std::string consProbe = itSV->consensus.substr(cutConsStart, (cutConsEnd - cutConsStart));
+      std::string refProbe = svRefStr.substr(cutRefStart, (cutRefEnd - cutRefStart));
+      O.cons_len[bpPoint] = (int32_t)consProbe.size();
+      O.ref_len[bpPoint] = (int32_t)refProbe.size();
+      O.cons_off[bpPoint] = bw.put(consProbe.data(), consProbe.size());
+      O.ref_off[bpPoint] = bw.put(refProbe.data(), refProbe.size());
+    }
+  }
+  if (out_used) *out_used = bw.used.load();
+  return (bw.used.load() > out_cap && out_blob) ? -1 : 0;
+}

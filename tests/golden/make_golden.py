@@ -193,6 +193,22 @@ def nw_job_vectors(ref):
     print("nw_jobs ok:", {k: int(v.shape[0]) for k, v in d.items() if k.endswith("_dist")})
 
 
+PROBE_BATCHES = [("c2", dict(mode="c2", seed=41), 96), ("mixed", dict(mode="mixed", seed=42), 96), ("ins", dict(mode="ins", seed=43), 96)]
+
+
+def probe_vectors(ref):
+    """per-SV body of _generateProbes (src/coverage.h:196-258) from the reference's own functions"""
+    d = {}
+    for label, kw, n in PROBE_BATCHES:
+        rec, blob = ref.generate_probes(synth.make_batch(n, **kw))
+        d[label + "_rec"] = rec
+        d[label + "_blob"] = blob
+        d[label + "_n"] = n
+        d[label + "_kwargs"] = repr(kw)
+    np.savez_compressed(os.path.join(HERE, "probes.npz"), **d)
+    print("probes ok:", {l: int(d[l + "_rec"]["ok"].sum()) for l, _, _ in PROBE_BATCHES})
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Oracle("reference")
@@ -205,6 +221,8 @@ def main():
         align_job_vectors(ref)
     if not only or "nw_jobs" in only:
         nw_job_vectors(ref)
+    if not only or "probes" in only:
+        probe_vectors(ref)
     # --- batches ---------------------------------------------------------------
     for name, (n, kw) in BATCHES.items():
         if only and name not in only:

@@ -10,7 +10,7 @@ import pytest
 
 import pyoracle
 from delly_amd import abi, synth
-from util import CORE, compare
+from util import CORE, compare, compare_probes
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -124,6 +124,30 @@ def test_port_reproduces_golden_nw_jobs(port):
     for label in ("plain", "weird"):
         got = port.edit_distance_nw_batch(z[label + "_jobs"], z[label + "_blob"], n_threads=4)
         assert (got == z[label + "_dist"]).all(), label
+
+
+def test_port_reproduces_golden_probes(port):
+    """per-SV body of _generateProbes (src/coverage.h:196-258): reference-generated probes"""
+    z = np.load(os.path.join(GOLD, "probes.npz"))
+    for label in ("c2", "mixed", "ins"):
+        b = synth.make_batch(int(z[label + "_n"]), **eval(str(z[label + "_kwargs"])))
+        rec, blob = port.generate_probes(b)
+        compare_probes(rec, blob, z[label + "_rec"], z[label + "_blob"], label)
+
+
+def test_port_probes_vs_reference_fuzz(port, reference):
+    import fuzz
+    for mode in ("c2", "mixed", "ins"):
+        for pi in (0, 1, 3):
+            b = fuzz.perturbed(120, 9 + pi, mode)
+            p = fuzz.params_of(pi)
+            a, ab = port.generate_probes(b, params=p)
+            r, rb = reference.generate_probes(b, params=p)
+            compare_probes(a, ab, r, rb, "%s/%d" % (mode, pi))
+        for b in fuzz.clipped(20, 5, mode):
+            a, ab = port.generate_probes(b)
+            r, rb = reference.generate_probes(b)
+            compare_probes(a, ab, r, rb, "clipped " + mode)
 
 
 def test_port_classifier_vs_reference_fresh(port, reference):

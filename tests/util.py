@@ -30,3 +30,20 @@ def compare(res_a, blob_a, res_b, blob_b, fields=CORE, blobs=("cons", "allele", 
                 if len(bad) > 20:
                     break
     assert not bad, "\n".join(bad[:20])
+
+
+def compare_probes(a, ab, b, bb, label=""):
+    """dellyhip_probes records + probe bytes (offsets are layout, not content)"""
+    import numpy as np
+    assert a.shape == b.shape, label
+    for f in a.dtype.names:
+        if "_off" in f or f == "reserved":
+            continue
+        bad = np.nonzero(a[f] != b[f])[0]
+        assert bad.size == 0, (label, f, bad[:5], a[f][bad[:5]], b[f][bad[:5]])
+    for k in np.nonzero(a["ok"])[0]:
+        for w in ("cons", "ref"):
+            for bp in "01":
+                n = int(a[w + "_len" + bp][k])
+                oa, ob = int(a[w + "_off" + bp][k]), int(b[w + "_off" + bp][k])
+                assert bytes(ab[oa:oa + n]) == bytes(bb[ob:ob + n]), (label, int(k), w, bp)
