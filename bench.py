@@ -255,12 +255,16 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         cx.close()
         if orc is not None:
             sub = slice(0, nj)
-            ref = orc.edit_distance_nw_batch(jobs[sub], blob, n_threads=cores)
-            dtc = orc.worker_seconds
-            orc.edit_distance_nw_batch(jobs[:256], blob, n_threads=1)
-            dt1 = orc.worker_seconds
+            dtc, ncpu = 0.0, 0
+            while dtc < 0.5 and ncpu < 64:   # >= 0.5 s of worker time: one pass is only tens of milliseconds
+                ref = orc.edit_distance_nw_batch(jobs[sub], blob, n_threads=cores)
+                dtc += orc.worker_seconds
+                ncpu += 1
+            dtc /= ncpu
+            orc.edit_distance_nw_batch(jobs[:2048], blob, n_threads=1)
+            dt1 = orc.worker_seconds * 256 / 2048
             out["lr_genotype_edit_distance_nw"]["cpu_" + orc.kind] = {
-                "pairs_per_s": ref.shape[0] / dtc, "cores": cores, "sample": "%d pairs, %.2f s" % (ref.shape[0], dtc),
+                "pairs_per_s": ref.shape[0] / dtc, "cores": cores, "sample": "%d x %d pairs, %.3f s each" % (ncpu, ref.shape[0], dtc),
                 "pairs_per_s_one_thread": 256 / dt1, "identical_to_gpu": bool((ref == dist[sub]).all()),
                 "note": "the reference calls _editDistanceNW serially per read (src/genotype.h:262-284)"}
     except KeyError:
