@@ -1466,6 +1466,7 @@ struct dellyhip_nwjobs {
   DevBuf<dellyhip_nw_job> jobs;
   DevBuf<uint8_t> blob;
   DevBuf<int32_t> dist;
+  DevBuf<uint32_t> next;
   hipStream_t last_stream = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   ~dellyhip_nwjobs() {
@@ -1484,9 +1485,10 @@ int dellyhip_nwjobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_nw_j
   std::unique_ptr<dellyhip_nwjobs> b(new dellyhip_nwjobs);
   b->n = n_jobs;
   int rc;
-  if ((rc = b->jobs.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->blob.alloc(blob_len + 16)) ||
-      (rc = b->dist.alloc(std::max<uint64_t>(n_jobs, 1))))
+  if ((rc = b->jobs.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->blob.alloc(blob_len + 64)) ||
+      (rc = b->dist.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->next.alloc(1)))
     return rc;
+  if (n_jobs >= (1ull << 31) - 65536) return fail(DELLYHIP_E_ARG, "too many nw jobs");
   if (n_jobs) HIPCHK(hipMemcpyAsync(b->jobs.p, jobs, n_jobs * sizeof(dellyhip_nw_job), hipMemcpyHostToDevice, c->stream));
   if (blob_len) HIPCHK(hipMemcpyAsync(b->blob.p, blob, blob_len, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1503,8 +1505,9 @@ int dellyhip_nwjobs_run(dellyhip_ctx* c, dellyhip_nwjobs* b, void* stream_) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n};
-  const int grid = (int)std::min<uint64_t>(b->n, (uint64_t)std::max(1, c->n_cu) * 32);
+  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n, b->next.p};
+  const int grid = (int)std::min<uint64_t>(b->n, (uint64_t)std::max(1, c->n_cu) * 28);   // 7 wavefronts per SIMD (71 VGPRs)
+  HIPCHK(hipMemsetAsync(b->next.p, 0, sizeof(uint32_t), st));
   HIPCHK(hipEventRecord(e0, st));
   hipLaunchKernelGGL(dh::nw_jobs_kernel, dim3(grid), dim3(dh::WAVE), 0, st, a);
   HIPCHK(hipEventRecord(e1, st));

@@ -192,17 +192,158 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
   }
 }
 
+// ---- branch-free variant for the batched long-read genotyping distances ---------------------------------
+// Same recurrence and layout as myers_nw_distance, but the column step has no divergent control flow: the
+// per-lane equality masks sit in LDS as [word][letter A,C,G,T,N,none][lane] behind a byte -> slot table, lanes
+// outside their column range keep their state through selects (so every lane ends frozen at column tn and the
+// bottom-right value is read off once after the loop).  A text byte outside ACGTN takes the all-zero mask, which
+// is exact as long as the pattern holds no such byte; otherwise the function declines (returns -1) and the
+// caller uses myers_nw_distance.
+template <int NWORDS>
+struct MyersLds {
+  uint16_t lut[256];                 // first: the same offset for every NWORDS (the kernel holds one MyersLds<MYERS_NW>)
+  uint32_t eq[NWORDS * 6 * WAVE];
+};
+
+__device__ __forceinline__ void myers_lut_init(uint16_t* lut, int lane) {
+  for (int i = lane; i < 256; i += WAVE) {
+    const int code = myers_code(i);
+    lut[i] = (uint16_t)((code < 0 ? 5 : code) * WAVE);
+  }
+}
+
+template <int NWORDS>
+__device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pattern, int pn, const uint8_t* text, int tn,
+                                             int lane) {
+  const int row0 = lane * 32 * NWORDS;
+  bool foreign = false;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    uint32_t* slot = &L.eq[w * 6 * WAVE + lane];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) slot[k * WAVE] = 0;
+    const int rbeg = row0 + w * 32;
+    if (rbeg < pn) {   // the word's 32 pattern bytes in two loads (the blob is padded: reading past pn is harmless)
+      uint4 v[2];
+      __builtin_memcpy(&v[0], pattern + rbeg, 16);
+      __builtin_memcpy(&v[1], pattern + rbeg + 16, 16);
+      const uint32_t wd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int code = (int)L.lut[(wd[q >> 2] >> ((q & 3) * 8)) & 0xff];
+        const bool in = rbeg + q < pn;
+        foreign |= in && code == 5 * WAVE;
+        if (in) slot[code] |= 1u << q;
+      }
+    }
+    slot[5 * WAVE] = 0;
+  }
+  if (__ballot(foreign)) return -1;
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = 0xffffffffu;
+    Mv[w] = 0;
+  }
+  int score = row0 + 32 * NWORDS;
+  const int lastlane = (pn - 1) / (32 * NWORDS);
+  const int T = tn + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 1;
+  int c = -lane;
+  // The text travels through the lanes as mask-slot offsets (byte -> slot translated once per 16-column chunk),
+  // and the masks of step t+1 are fetched while the arithmetic of step t runs.
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    return (int)L.lut[(ci < tn) ? (int)text[ci] : 0];
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));   // slot offset of this lane's next column
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = L.eq[w * 6 * WAVE + bs + lane];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+      // next column's slot and masks
+      const int newc = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      bs = dpp_from_prev(bs, newc);
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqN[w] = L.eq[w * 6 * WAVE + bs + lane];
+      int hin = dpp_from_prev(hcarry, 1);
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)tn;
+      uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        uint32_t Eq = EqC[w];
+        const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470 (Hyyro's block step), 32-bit words
+        const uint32_t Xv = Eq | Mv[w];
+        Eq |= hinNeg;
+        const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+        uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+        uint32_t Mh = Pv[w] & Xh;
+        const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Mh |= hinNeg;
+        Ph |= (hin > 0) ? 1u : 0u;
+        nP[w] = Mh | ~(Xv | Ph);
+        nM[w] = Ph & Xv;
+        hin = hout;
+      }
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        Pv[w] = valid ? nP[w] : Pv[w];
+        Mv[w] = valid ? nM[w] : Mv[w];
+      }
+      hcarry = valid ? hin : hcarry;
+      score += valid ? hin : 0;
+    }
+    chunk = chunk_next;
+  }
+  // every lane is frozen at column tn: D[pn][tn] = bottom score of lane `lastlane` minus the vertical deltas below row pn
+  int s = score;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, lo + 32 - pn));
+    if (nb > 0) {
+      const uint32_t mk = (nb >= 32) ? 0xffffffffu : (~0u << (32 - nb));
+      s -= __popc(Pv[w] & mk);
+      s += __popc(Mv[w] & mk);
+    }
+  }
+  return __shfl(s, lastlane);
+}
+
 // ---- a batch of independent pairs: _editDistanceNW of the long-read genotyper (src/genotype.h:21-30,276,284) ----
 struct NwArgs {
   const dellyhip_nw_job* jobs;
   const uint8_t* blob;
   int32_t* dist;
   uint64_t n_jobs;
+  uint32_t* next;   // work counter, zeroed before the launch: wavefronts pull job indices (pair lengths vary)
 };
 
 __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
+  __shared__ MyersLds<MYERS_NW> L;   // (the one- and two-word variants use a prefix of it)
   const int lane = threadIdx.x;
-  for (uint64_t item = blockIdx.x; item < A.n_jobs; item += gridDim.x) {
+  myers_lut_init(L.lut, lane);
+  __syncthreads();
+  // (the loop condition must be a scalar compare: hipcc's exec-mask structurisation of a `break` it cannot prove
+  //  uniform produced a non-terminating loop here, see split_main.hpp JCtx)
+  const int n_items = __builtin_amdgcn_readfirstlane((int)(uint32_t)A.n_jobs);
+  auto fetch = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = (int)atomicAdd(A.next, 1u);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  for (int item = fetch(); item < n_items; item = fetch()) {
     const dellyhip_nw_job J = A.jobs[item];
     const int la = (int)J.query_len, lb = (int)J.target_len;
     const uint8_t* a = A.blob + J.query_off;
@@ -210,8 +351,15 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
     int d;
     if (la == 0 || lb == 0) d = max(la, lb);                              // edlib.cpp:157-163
     else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = DELLYHIP_E_LIMIT;
-    else if (la <= lb) d = myers_nw(a, la, b, lb, lane);                   // pattern = the shorter string (symmetric)
-    else d = myers_nw(b, lb, a, la, lane);
+    else {
+      const uint8_t* pat = (la <= lb) ? a : b;                             // pattern = the shorter string (symmetric)
+      const uint8_t* txt = (la <= lb) ? b : a;
+      const int pn = min(la, lb), tn = max(la, lb);
+      if (pn <= WAVE * 32) d = myers_nw_fast<1>(reinterpret_cast<MyersLds<1>&>(L), pat, pn, txt, tn, lane);
+      else if (pn <= WAVE * 64) d = myers_nw_fast<2>(reinterpret_cast<MyersLds<2>&>(L), pat, pn, txt, tn, lane);
+      else d = myers_nw_fast<3>(L, pat, pn, txt, tn, lane);
+      if (d < 0) d = myers_nw(pat, pn, txt, tn, lane);                     // pattern with bytes outside ACGTN
+    }
     if (lane == 0) A.dist[item] = d;
   }
 }
