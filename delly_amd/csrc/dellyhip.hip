@@ -737,7 +737,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   int rc = 0;
   auto bail = [&](int r) { dellyhip_batch_free(c, b); return r; };
   if ((rc = b->junc.alloc(std::max(n, 1)))) return bail(rc);
-  if ((rc = b->seq_blob.alloc(std::max<uint64_t>(blob_bytes, 1)))) return bail(rc);
+  if ((rc = b->seq_blob.alloc(blob_bytes + 64))) return bail(rc);   // (+64: the bit-vector kernels fetch pattern bytes 32 at a time)
   if ((rc = b->seq_off.alloc(n_seq + 1))) return bail(rc);
   if ((rc = b->cons_off.alloc(std::max(n, 1)))) return bail(rc);
   if ((rc = b->cons_len.alloc(std::max(n, 1)))) return bail(rc);
@@ -1141,7 +1141,7 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   M.off_cons = take(M.acap);
   M.off_dirs = take((uint64_t)(M.acap / dh::LRS + 1) * M.strip_words * 4);
   M.ws_stride = o;
-  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(std::max<uint64_t>(blob_bytes, 1))) || (rc = doff.alloc(n_reads + 1)) ||
+  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(blob_bytes + 64)) || (rc = doff.alloc(n_reads + 1)) ||
       (rc = dpf.alloc(2)) || (rc = dedit.alloc(dh::LM_NR * dh::LM_NR)) || (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) ||
       (rc = dout.alloc(M.acap)) || (rc = dws.alloc(M.ws_stride)))
     return rc;
@@ -1202,7 +1202,7 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
   DevBuf<dellyhip_result> dres;
   dh::LrWfaArgs W{};
   wfa_layout(W, maxlen);
-  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(std::max<uint64_t>(blob_bytes, 1))) || (rc = doff.alloc(n_reads + 1)) ||
+  if ((rc = dj.alloc(1)) || (rc = dblob.alloc(blob_bytes + 64)) || (rc = doff.alloc(n_reads + 1)) ||
       (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) || (rc = dout.alloc(dh::WFA_ACAP)) || (rc = dws.alloc(W.ws_stride)) ||
       (rc = dpre.alloc(std::max(prefix_len, 1))) || (rc = dsuf.alloc(std::max(suffix_len, 1))))
     return rc;

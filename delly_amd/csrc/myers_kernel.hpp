@@ -138,60 +138,6 @@ __device__ __forceinline__ int myers_nw(const uint8_t* pattern, int pn, const ui
   return myers_nw_distance<3>(pattern, pn, text, tn, lane);
 }
 
-// ---- single call (dellyhip_edlib_align, NW + DISTANCE beyond the insertion-kernel shapes) ----
-__global__ __launch_bounds__(WAVE) void myers_single_kernel(const uint8_t* q, int qn, const uint8_t* t, int tn, int32_t* out) {
-  const int lane = threadIdx.x;
-  // rows = the shorter of the two strings would be cheaper; edlib's distance is symmetric
-  const int d = myers_nw(q, qn, t, tn, lane);
-  if (lane == 0) out[0] = d;
-}
-
-// ---- all pairs of a junction's reads: msaEdlib's distance matrix (src/assemble.h:386-395) ----
-struct PairArgs {
-  const dellyhip_junction* junc;
-  const uint8_t* seq_blob;
-  const uint64_t* seq_off;
-  const int32_t* pair_first;   // first work item of junction j (prefix sums of n(n-1)/2), n_junc + 1 entries
-  int32_t n_junc;
-  int32_t n_items;
-  int32_t nrmax;               // row stride of a junction's matrix
-  int32_t* edit;               // edit[j*nrmax*nrmax + a*nrmax + b]
-};
-
-__global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
-  const int lane = threadIdx.x;
-  for (int item = blockIdx.x; item < A.n_items; item += gridDim.x) {
-    // junction of this item: binary search in pair_first
-    int lo = 0, hi = A.n_junc;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (A.pair_first[mid] <= item) lo = mid;
-      else hi = mid;
-    }
-    const int j = lo;
-    const dellyhip_junction J = A.junc[j];
-    const int N = J.n_seq;
-    int rem = item - A.pair_first[j], a = 0;
-    while (rem >= N - 1 - a) {
-      rem -= N - 1 - a;
-      ++a;
-    }
-    const int bb = a + 1 + rem;
-    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + bb];
-    const int la = (int)(A.seq_off[J.seq_first + a + 1] - oa), lb = (int)(A.seq_off[J.seq_first + bb + 1] - ob);
-    int d;
-    if (la == 0 || lb == 0) d = max(la, lb);                 // edlib.cpp:160-166
-    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = -1;     // beyond the kernel limit (flagged by the consumer)
-    else if (la <= lb || lb > MYERS_ROWS) d = myers_nw(A.seq_blob + oa, la, A.seq_blob + ob, lb, lane);
-    else d = myers_nw(A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
-    if (lane == 0) {
-      int32_t* E = A.edit + (size_t)j * A.nrmax * A.nrmax;
-      E[a * A.nrmax + bb] = d;
-      E[bb * A.nrmax + a] = d;
-    }
-  }
-}
-
 // ---- branch-free variant for the batched long-read genotyping distances ---------------------------------
 // Same recurrence and layout as myers_nw_distance, but the column step has no divergent control flow: the
 // per-lane equality masks sit in LDS as [word][letter A,C,G,T,N,none][lane] behind a byte -> slot table, lanes
@@ -321,6 +267,74 @@ __device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pa
   return __shfl(s, lastlane);
 }
 
+// fast variant with the exact-compare fallback; L: one MyersLds<MYERS_NW> per wavefront, lut initialised
+__device__ __forceinline__ int myers_nw_auto(MyersLds<MYERS_NW>& L, const uint8_t* pattern, int pn, const uint8_t* text, int tn,
+                                             int lane) {
+  int d;
+  if (pn <= WAVE * 32) d = myers_nw_fast<1>(reinterpret_cast<MyersLds<1>&>(L), pattern, pn, text, tn, lane);
+  else if (pn <= WAVE * 64) d = myers_nw_fast<2>(reinterpret_cast<MyersLds<2>&>(L), pattern, pn, text, tn, lane);
+  else d = myers_nw_fast<3>(L, pattern, pn, text, tn, lane);
+  if (d < 0) d = myers_nw(pattern, pn, text, tn, lane);   // pattern with bytes outside ACGTN
+  return d;
+}
+
+// ---- single call (dellyhip_edlib_align, NW + DISTANCE beyond the insertion-kernel shapes) ----
+__global__ __launch_bounds__(WAVE) void myers_single_kernel(const uint8_t* q, int qn, const uint8_t* t, int tn, int32_t* out) {
+  const int lane = threadIdx.x;
+  // rows = the shorter of the two strings would be cheaper; edlib's distance is symmetric
+  const int d = myers_nw(q, qn, t, tn, lane);
+  if (lane == 0) out[0] = d;
+}
+
+// ---- all pairs of a junction's reads: msaEdlib's distance matrix (src/assemble.h:386-395) ----
+struct PairArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  const int32_t* pair_first;   // first work item of junction j (prefix sums of n(n-1)/2), n_junc + 1 entries
+  int32_t n_junc;
+  int32_t n_items;
+  int32_t nrmax;               // row stride of a junction's matrix
+  int32_t* edit;               // edit[j*nrmax*nrmax + a*nrmax + b]
+};
+
+__global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
+  __shared__ MyersLds<MYERS_NW> L;
+  const int lane = threadIdx.x;
+  myers_lut_init(L.lut, lane);
+  __syncthreads();
+  for (int item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+    // junction of this item: binary search in pair_first
+    int lo = 0, hi = A.n_junc;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (A.pair_first[mid] <= item) lo = mid;
+      else hi = mid;
+    }
+    const int j = lo;
+    const dellyhip_junction J = A.junc[j];
+    const int N = J.n_seq;
+    int rem = item - A.pair_first[j], a = 0;
+    while (rem >= N - 1 - a) {
+      rem -= N - 1 - a;
+      ++a;
+    }
+    const int bb = a + 1 + rem;
+    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + bb];
+    const int la = (int)(A.seq_off[J.seq_first + a + 1] - oa), lb = (int)(A.seq_off[J.seq_first + bb + 1] - ob);
+    int d;
+    if (la == 0 || lb == 0) d = max(la, lb);                 // edlib.cpp:160-166
+    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = -1;     // beyond the kernel limit (flagged by the consumer)
+    else if (la <= lb || lb > MYERS_ROWS) d = myers_nw_auto(L, A.seq_blob + oa, la, A.seq_blob + ob, lb, lane);   // (the blob is padded)
+    else d = myers_nw_auto(L, A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
+    if (lane == 0) {
+      int32_t* E = A.edit + (size_t)j * A.nrmax * A.nrmax;
+      E[a * A.nrmax + bb] = d;
+      E[bb * A.nrmax + a] = d;
+    }
+  }
+}
+
 // ---- a batch of independent pairs: _editDistanceNW of the long-read genotyper (src/genotype.h:21-30,276,284) ----
 struct NwArgs {
   const dellyhip_nw_job* jobs;
@@ -355,10 +369,7 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
       const uint8_t* pat = (la <= lb) ? a : b;                             // pattern = the shorter string (symmetric)
       const uint8_t* txt = (la <= lb) ? b : a;
       const int pn = min(la, lb), tn = max(la, lb);
-      if (pn <= WAVE * 32) d = myers_nw_fast<1>(reinterpret_cast<MyersLds<1>&>(L), pat, pn, txt, tn, lane);
-      else if (pn <= WAVE * 64) d = myers_nw_fast<2>(reinterpret_cast<MyersLds<2>&>(L), pat, pn, txt, tn, lane);
-      else d = myers_nw_fast<3>(L, pat, pn, txt, tn, lane);
-      if (d < 0) d = myers_nw(pat, pn, txt, tn, lane);                     // pattern with bytes outside ACGTN
+      d = myers_nw_auto(L, pat, pn, txt, tn, lane);
     }
     if (lane == 0) A.dist[item] = d;
   }
