@@ -58,7 +58,7 @@ __device__ __forceinline__ int lri_mask_append_run(PL& L, int pos, int cnt, unsi
   return pos;
 }
 
-__device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, PostLR& L, uint8_t* ws, int lane) {
+__device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, PostLR& L, MyersLds<MYERS_NW>& ML, uint8_t* ws, int lane) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
   JCtx X;
@@ -137,8 +137,8 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int dF = rfl(myers_nw(S.cons, m, S.ref, n, lane));
-    const int dR = rfl(myers_nw(S.rcons, m, S.ref, n, lane));
+    const int dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
+    const int dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
     if (dR < dF) {
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];
@@ -268,12 +268,15 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
 
 __global__ __launch_bounds__(WAVE) void lr_ins_kernel(SplitArgs A, LrInsArgs R) {
   __shared__ PostLR L;
+  __shared__ MyersLds<MYERS_NW> ML;
   const int lane = threadIdx.x;
+  myers_lut_init(ML.lut, lane);
+  __syncthreads();
   uint8_t* ws = R.ws + (size_t)blockIdx.x * R.ws_stride;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;
-    process_lr_ins(A, R, j, L, ws, lane);
+    process_lr_ins(A, R, j, L, ML, ws, lane);
   }
 }
 
