@@ -238,10 +238,134 @@ __device__ __forceinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen
   return lm_pass_t<DIRS, LOC, 0>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
 }
 
+// ---- bit-vector flavour of the last-row pass (Hirschberg halves of edlib's NW PATH, edlib.cpp:1163-1389) -------------
+// In the compare-free regime (every letter of both strings is one of the 15 classes) "equal" is a relation
+// between classes, so the pass is Myers' recurrence with one equality mask per QUERY class: mask[y] = rows whose
+// letter x has y in {x} + partners(x).  Layout and column step as myers_nw_fast (myers_kernel.hpp): 32 target rows
+// per lane-word, masks in LDS, the query travels through the lanes as mask offsets, no divergent control flow.
+// The value of row tlen is read off the owning lane after every column (bottom score of its words minus the
+// vertical deltas below row tlen) and leaves through the 16-column staging register of the strip passes.
+__device__ __forceinline__ uint32_t* lm_eq_lds() {
+  __shared__ uint32_t eqm[MYERS_NW * 16 * WAVE];   // [word][query class 0..14, 15 = none][lane]
+  return eqm;
+}
+
+template <int NWORDS>
+__device__ __noinline__ void lm_last_row_myers(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
+                                               int32_t* row_out, int lane) {
+  uint32_t* E = lm_eq_lds();
+  const int row0 = lane * 32 * NWORDS;
+  uint32_t mk[NWORDS];   // rows of this lane at or beyond tlen (their vertical deltas are taken off the bottom score)
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, lo + 32 - tlen));
+    mk[w] = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? (~0u << (32 - nb)) : 0u);
+    for (int q = 0; q < 32; ++q) {
+      const int r = lo + q;
+      if (r < tlen) {
+        const int x = iupac_index((int)tp[r * tstep]);
+        uint32_t pm = (1u << x) | iupac_partners(x);
+        while (pm) {
+          const int y = __builtin_ctz(pm);
+          pm &= pm - 1;
+          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
+        }
+      }
+    }
+  }
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = 0xffffffffu;
+    Mv[w] = 0;
+  }
+  int score = row0 + 32 * NWORDS;
+  const int lastlane = (tlen - 1) / (32 * NWORDS);
+  const int T = qlen + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 1;
+  int c = -lane;
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    const int y = (ci < qlen) ? iupac_index((int)qp[ci * qstep]) : -1;
+    return ((y < 0) ? 15 : y) * WAVE;
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+  int outv = 0;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+      const int newc = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      bs = dpp_from_prev(bs, newc);
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+      int hin = dpp_from_prev(hcarry, 1);
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)qlen;
+      uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        uint32_t Eq = EqC[w];
+        const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470
+        const uint32_t Xv = Eq | Mv[w];
+        Eq |= hinNeg;
+        const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+        uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+        uint32_t Mh = Pv[w] & Xh;
+        const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Mh |= hinNeg;
+        Ph |= (hin > 0) ? 1u : 0u;
+        nP[w] = Mh | ~(Xv | Ph);
+        nM[w] = Ph & Xv;
+        hin = hout;
+      }
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        Pv[w] = valid ? nP[w] : Pv[w];
+        Mv[w] = valid ? nM[w] : Mv[w];
+      }
+      hcarry = valid ? hin : hcarry;
+      score += valid ? hin : 0;
+      int s = score;   // E[tlen][c] in the lane that owns row tlen
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) s += __popc(Mv[w] & mk[w]) - __popc(Pv[w] & mk[w]);
+      const int sv = __builtin_amdgcn_readlane(s, lastlane);
+      outv = (lane == f) ? sv : outv;   // (v_writelane_b32 takes one scalar operand only: no scalar lane index next to a scalar value)
+    }
+    {   // lanes 0..15 hold the columns blk*16 + lane + 1 - lastlane of this block
+      const int col = blk * 16 + lane + 1 - lastlane;
+      if (lane < 16 && col >= 1 && col <= qlen) row_out[col] = outv;
+    }
+    chunk = chunk_next;
+  }
+  if (lane == 0) row_out[0] = tlen;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
 // (row_out[c] = distance(t, q[0..c))).  bndA / bndB: strip boundary scratch.
 __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
                                             int mode, int32_t* bndA, int32_t* bndB, int32_t* row_out, int lane) {
+  if ((mode & LM_EQ) && (mode & LM_EQFAST) && tlen >= 1 && qlen >= 1 && tlen <= MYERS_ROWS) {
+    if (tlen <= WAVE * 32) lm_last_row_myers<1>(tp, tstep, tlen, qp, qstep, qlen, row_out, lane);
+    else if (tlen <= WAVE * 64) lm_last_row_myers<2>(tp, tstep, tlen, qp, qstep, qlen, row_out, lane);
+    else lm_last_row_myers<3>(tp, tstep, tlen, qp, qstep, qlen, row_out, lane);
+    return;
+  }
   const int Q = (tlen + 1 + LRS - 1) / LRS;
   const int pad = Q * LRS - (tlen + 1);   // row tlen = last slot of the last strip
   for (int q = 0; q < Q; ++q) {
