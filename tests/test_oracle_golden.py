@@ -108,6 +108,18 @@ def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
     compare(pr, pb, rr, rb, label="port-vs-reference")
 
 
+@pytest.mark.parametrize("kw", [dict(mode="lr", n_reads=5, sub_rate=0.05, seed=91), dict(mode="lr", sub_rate=0.02, seed=92),
+                                dict(mode="lr", n_reads=4, sub_rate=0.03, seed=93, first=4)])
+def test_port_vs_reference_long_read_fresh(port, reference, kw):
+    """the long-read loop body (msaEdlib / given consensus + alignConsensus(realign)) on batches not in the fixtures"""
+    b = synth.make_batch(6, **kw)
+    p = abi.params_lr(realign=True)
+    pr, pb = port.refine_batch(b, params=p, n_threads=6)
+    rr, rb = reference.refine_batch(b, params=p, n_threads=6)
+    compare(pr, pb, rr, rb, label="lr fresh")
+    assert int(rr["ok"].sum()) >= 4
+
+
 def test_port_reproduces_golden_align_jobs(port):
     """split-read genotyping classifier (src/coverage.h:412-434): reference-generated records"""
     z = np.load(os.path.join(GOLD, "align_jobs.npz"))
