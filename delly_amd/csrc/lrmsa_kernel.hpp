@@ -356,6 +356,176 @@ __device__ __noinline__ void lm_last_row_myers(const uint8_t* tp, int tstep, int
   __syncthreads();
 }
 
+// ---- bit-vector flavour of the traceback-regime path (the base-case rectangles of the Hirschberg split) ----------------
+// edlib's direction rule (INSERT > DELETE > diagonal, edlib.cpp:1018-1125) needs per cell only two bits the Myers
+// step has in hand: INSERT (left: a query letter alone) <=> the horizontal delta D[r][c] - D[r][c-1] is +1 (Ph),
+// DELETE (up: a target letter alone) <=> the vertical delta D[r][c] - D[r-1][c] is +1 (the new Pv); otherwise the move
+// is diagonal and MATCH / MISMATCH is the class relation of the two letters.  So the fill stores the two planes
+// (2 bits per cell, as the code words do) 32 rows per ~40 instructions, and the windowed run-length traceback reads
+// them "transposed": a lane keeps a COLUMN and the 32-row word of its fetch row.
+// Layout: word of (step s, word w, owner lane lo) at ((s * NW + w) * (nl + 1) + lo); lanes beyond the last owner
+// lane share the dummy slot nl.  Cell (r, c) (1-based): lo = (r-1) / (32 NW), w = ((r-1) >> 5) - lo NW, s = c - 1 + lo.
+template <int NWORDS>
+__device__ __noinline__ void lm_dirs_myers(const uint8_t* tp, int tlen, const uint8_t* qp, int qlen, uint32_t* planeH,
+                                           uint32_t* planeV, int lane) {
+  uint32_t* E = lm_eq_lds();
+  const int row0 = lane * 32 * NWORDS;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
+    const int lo = row0 + w * 32;
+    for (int q = 0; q < 32; ++q) {
+      const int r = lo + q;
+      if (r < tlen) {
+        const int x = iupac_index((int)tp[r]);
+        uint32_t pm = (1u << x) | iupac_partners(x);
+        while (pm) {
+          const int y = __builtin_ctz(pm);
+          pm &= pm - 1;
+          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
+        }
+      }
+    }
+  }
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = 0xffffffffu;
+    Mv[w] = 0;
+  }
+  const int lastlane = (tlen - 1) / (32 * NWORDS);
+  const int nl1 = lastlane + 2;                       // owner lanes + the shared dummy slot
+  const int sl = (lane <= lastlane) ? lane : lastlane + 1;
+  const int T = qlen + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 1;
+  int c = -lane;
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    const int y = (ci < qlen) ? iupac_index((int)qp[ci]) : -1;
+    return ((y < 0) ? 15 : y) * WAVE;
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+      const int newc = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      bs = dpp_from_prev(bs, newc);
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+      int hin = dpp_from_prev(hcarry, 1);
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)qlen;
+      const size_t sbase = ((size_t)(blk * 16 + f) * NWORDS) * nl1 + sl;
+      uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        uint32_t Eq = EqC[w];
+        const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470
+        const uint32_t Xv = Eq | Mv[w];
+        Eq |= hinNeg;
+        const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+        uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+        uint32_t Mh = Pv[w] & Xh;
+        planeH[sbase + (size_t)w * nl1] = Ph;            // horizontal +1 deltas of this column's rows
+        const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Mh |= hinNeg;
+        Ph |= (hin > 0) ? 1u : 0u;
+        nP[w] = Mh | ~(Xv | Ph);
+        nM[w] = Ph & Xv;
+        planeV[sbase + (size_t)w * nl1] = nP[w];          // vertical +1 deltas within this column
+        hin = hout;
+      }
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        Pv[w] = valid ? nP[w] : Pv[w];
+        Mv[w] = valid ? nM[w] : Mv[w];
+      }
+      hcarry = valid ? hin : hcarry;
+    }
+    chunk = chunk_next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// windowed run-length traceback over the two planes (see traceback_runs, split_kernel.hpp, for the row-word
+// flavour): lane x keeps column cc - x and the planes' words of the 32-row word its fetch row lies in.
+// ops (edlib codes 0 match, 1 insert, 2 delete, 3 mismatch) to tr[] in push order; rr / cc end at the border.
+__device__ __noinline__ int lm_traceback_planes(const uint32_t* planeH, const uint32_t* planeV, int nw, int nl1, const uint8_t* t,
+                                                const uint8_t* qy, int& rr, int& cc, uint8_t* tr, int lane) {
+  int tl = 0;
+  rr = rfl(rr);
+  cc = rfl(cc);
+  while (rr > 0 && cc > 0) {
+    const int r = rr - lane, c = cc - lane;
+    uint32_t wh = 0, wv = 0;
+    int rwf = -1;
+    uint32_t tmask = 0;   // classes the query letter of this lane's column equals
+    if (r >= 1 && c >= 1) {
+      const int z = r - 1;
+      const int lo = z / (32 * nw);
+      const int w = (z >> 5) - lo * nw;
+      const size_t wi = ((size_t)(c - 1 + lo) * nw + w) * nl1 + lo;
+      rwf = z >> 5;
+      wh = ld_scratch(planeH + wi);
+      wv = ld_scratch(planeV + wi);
+      const int y = iupac_index((int)qy[c - 1]);
+      tmask = (1u << y) | iupac_partners(y);   // (the relation is symmetric)
+    }
+    int l = 0;   // columns consumed since the fetch: lane x stands for diagonal offset x - l
+    bool inwin = true;
+    while (inwin) {
+      const int d = lane - l;
+      const int rx = rr - d;
+      const bool valid = (d >= 0) && (rwf >= 0) && (rx >= 1) && (((rx - 1) >> 5) == rwf);
+      uint32_t code = 4u;
+      if (valid) {
+        const int q = (rx - 1) & 31;
+        if ((wh >> q) & 1u) code = (uint32_t)ED_INSERT;
+        else if ((wv >> q) & 1u) code = (uint32_t)ED_DELETE;
+        else code = ((tmask >> iupac_index((int)t[rx - 1])) & 1u) ? (uint32_t)ED_MATCH : (uint32_t)ED_MISMATCH;
+      }
+      const bool isd = (code == (uint32_t)ED_MATCH || code == (uint32_t)ED_MISMATCH);
+      const unsigned long long dm = __ballot(isd) >> l;
+      const int L = (~dm == 0ull) ? WAVE : __builtin_ctzll(~dm);
+      if (L > 0) {
+        if (d >= 0 && d < L) tr[tl + d] = (uint8_t)code;
+        tl += L;
+        rr -= L;
+        cc -= L;
+        l += L;
+      }
+      if (rr <= 0 || cc <= 0 || l >= WAVE) {
+        inwin = false;
+      } else {
+        const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane((int)code, l);
+        if (cl == 4u) {
+          inwin = false;   // the path left the fetched 32-row word of this column
+        } else {
+          if (lane == 0) tr[tl] = (uint8_t)cl;
+          ++tl;
+          if (cl == (uint32_t)ED_INSERT) { --cc; ++l; }   // the column is consumed: next lane
+          else --rr;                                        // same column, next row up
+          if (rr <= 0 || cc <= 0 || l >= WAVE) inwin = false;
+        }
+      }
+    }
+  }
+  return tl;
+}
+
 // row `tlen` of the NW matrix of t (tlen letters) vs q for every column, into row_out[0..qlen]
 // (row_out[c] = distance(t, q[0..c))).  bndA / bndB: strip boundary scratch.
 __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
@@ -386,16 +556,32 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
                                              int32_t* bndB, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                              uint8_t* ops, int pos, int lane) {
   const int Q = tlen / LRS + 1;
-  for (int q = 0; q < Q; ++q) {
-    const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
-    int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
-    (void)lm_pass<true, false>(t, 1, tlen, qy, 1, qlen, q, 0, mode & (LM_EQ | LM_EQFAST), 0, bin, bout, dirs + (size_t)q * strip_words, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  GeoLR G{dirs, strip_words};
   int rr = tlen, cc = qlen;
-  int tl = traceback_runs<true>(G, rr, cc, tmp, lane);
+  int tl;
+  // bit-plane flavour in the compare-free regime, when the two planes fit the room the code words of this
+  // rectangle would take (both are 2 bits per cell up to rounding)
+  const int bv_nw = (tlen <= WAVE * 32) ? 1 : ((tlen <= WAVE * 64) ? 2 : 3);
+  const int bv_nl1 = (tlen >= 1) ? (tlen - 1) / (32 * bv_nw) + 2 : 2;
+  const uint64_t bv_words = (uint64_t)(((qlen + bv_nl1 - 2 + 15) >> 4) * 16) * bv_nw * bv_nl1;
+  if ((mode & LM_EQ) && (mode & LM_EQFAST) && tlen >= 1 && qlen >= 1 && tlen <= MYERS_ROWS &&
+      2 * bv_words <= (uint64_t)Q * strip_words) {
+    uint32_t* planeH = dirs;
+    uint32_t* planeV = dirs + bv_words;
+    if (bv_nw == 1) lm_dirs_myers<1>(t, tlen, qy, qlen, planeH, planeV, lane);
+    else if (bv_nw == 2) lm_dirs_myers<2>(t, tlen, qy, qlen, planeH, planeV, lane);
+    else lm_dirs_myers<3>(t, tlen, qy, qlen, planeH, planeV, lane);
+    tl = lm_traceback_planes(planeH, planeV, bv_nw, bv_nl1, t, qy, rr, cc, tmp, lane);
+  } else {
+    for (int q = 0; q < Q; ++q) {
+      const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
+      int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
+      (void)lm_pass<true, false>(t, 1, tlen, qy, 1, qlen, q, 0, mode & (LM_EQ | LM_EQFAST), 0, bin, bout, dirs + (size_t)q * strip_words, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    GeoLR G{dirs, strip_words};
+    tl = traceback_runs<true>(G, rr, cc, tmp, lane);
+  }
   // border runs: target exhausted -> INSERTs, query exhausted -> DELETEs (edlib.cpp:1027-1091)
   const int tail = (rr > 0) ? rr : cc;
   const uint8_t op = (rr > 0) ? (uint8_t)ED_DELETE : (uint8_t)ED_INSERT;
