@@ -62,6 +62,38 @@ def test_msa_edlib_vs_port_small_and_edge(lr_ctx, port):
         port.params = old
 
 
+def _subs(rng, s, rate):
+    out = bytearray(s)
+    for k in range(len(out)):
+        if rng.random() < rate:
+            out[k] = rng.choice(list(b"ACGT"))
+    return bytes(out)
+
+
+def test_msa_edlib_wide_row_blocks(lr_ctx, port):
+    """shapes that take the two- and three-word variants of the bit-vector passes: a short read against a consensus of
+    > 2048 columns (traceback-regime rectangle with > 2048 rows), consensus of > 4096 columns (Hirschberg halves > 2048 rows)"""
+    rng = np.random.default_rng(77)
+    old = port.params
+    port.params = abi.params_lr()
+    try:
+        base = bytes(rng.choice(list(b"ACGT"), 4400).astype(np.uint8))
+        # (msaEdlib drops the worst 20 % of the reads: two short ones so that one of them stays)
+        sets = [[_ont(rng, base[:2180], 0.03), _ont(rng, base[10:2190], 0.03), _ont(rng, base[400:1800], 0.03), _ont(rng, base[:2170], 0.03),
+                 _ont(rng, base[300:1750], 0.03)],
+                # substitutions only: the alignment stays at 4100 columns (kernel limit 4160), halves of 2050 rows
+                [_subs(rng, base[:4100], 0.01), _subs(rng, base[:4100], 0.01), _subs(rng, base[1000:3300], 0.02), _subs(rng, base[:4100], 0.01),
+                 _subs(rng, base[900:3200], 0.02)],
+                # very short reads against 4100 columns: a traceback-regime rectangle with > 4096 rows (three words per lane)
+                [_subs(rng, base[:4100], 0.01), _subs(rng, base[:4100], 0.01), _subs(rng, base[2000:2300], 0.02), _subs(rng, base[:4100], 0.01),
+                 _subs(rng, base[1500:1810], 0.02)]]
+        for k, reads in enumerate(sets):
+            want = port.msa_edlib(reads)
+            assert lr_ctx.msa_edlib(reads) == want, k
+    finally:
+        port.params = old
+
+
 def test_refine_batch_lr_reproduces_reference_golden_vectors(lr_ctx):
     """msaEdlib + alignConsensus(realign) vs the committed outputs of the reference (batch_full_lr_n8.npz)"""
     g = np.load(os.path.join(GOLD, "batch_full_lr_n8.npz"), allow_pickle=True)
