@@ -34,6 +34,14 @@ def test_nw_batch_vs_port(gpu_ctx, port):
     _check(gpu_ctx.edit_distance_nw_batch(jobs, blob), want, jobs)
 
 
+def test_nw_batch_three_word_patterns(gpu_ctx, port):
+    """patterns of 4200 .. 6000 rows: three 32-row words per lane"""
+    jobs, blob = synth.make_nw_jobs(6, seed=78, min_half=2100, max_half=3000)
+    want = port.edit_distance_nw_batch(jobs, blob, n_threads=8)
+    _check(gpu_ctx.edit_distance_nw_batch(jobs, blob), want, jobs)
+    assert int(jobs["query_len"].min()) > 4096
+
+
 def test_nw_batch_edges_and_resident(gpu_ctx, port):
     assert gpu_ctx.edit_distance_nw_batch(np.zeros(0, dtype=abi.nw_job_dtype()), np.zeros(0, dtype=np.uint8)).shape[0] == 0
     jobs, blob = synth.make_nw_jobs(300, seed=5)
