@@ -18,13 +18,14 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-def gather_records(local, world, dist=None, max_count=None):
+def gather_records(local, world, dist=None, max_count=None, record_bytes=None):
     """All-gathers fixed-size result records (a uint8 torch tensor of
     count*sizeof(dellyhip_result) bytes, on the device of the backend).  Ranks
     may hold different counts: records are padded to max_count (RCCL has no
-    all-gatherv; payload is ~150 B per junction, latency-bound)."""
+    all-gatherv; payload is ~150 B per junction, latency-bound).  record_bytes: size of one record when it is not
+    a dellyhip_result (the genotyping rows shard the same way: 20-byte dellyhip_align_result, 4-byte distances)."""
     import torch
-    rec = abi.result_dtype().itemsize
+    rec = record_bytes or abi.result_dtype().itemsize
     count = local.numel() // rec
     if world == 1:
         return local, [count]
@@ -42,11 +43,14 @@ def gather_records(local, world, dist=None, max_count=None):
     return out, [int(x) for x in allc.cpu()], max_count
 
 
-def merge_records(gathered_bytes, counts, max_count):
+def merge_records(gathered_bytes, counts, max_count, dtype=None, sort_key="svid"):
     """Host side: strips the padding and orders by svid (the CPU result is
-    order-independent because every task writes its own slot)."""
-    dt = abi.result_dtype()
+    order-independent because every task writes its own slot).  sort_key=None keeps rank order
+    (block-partitioned job lists: rank order IS job order)."""
+    dt = dtype or abi.result_dtype()
     arr = np.frombuffer(np.ascontiguousarray(gathered_bytes), dtype=dt).reshape(len(counts), max_count)
     parts = [arr[r, :c] for r, c in enumerate(counts)]
     allr = np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
-    return allr[np.argsort(allr["svid"], kind="stable")]
+    if sort_key is None:
+        return allr
+    return allr[np.argsort(allr[sort_key], kind="stable")]

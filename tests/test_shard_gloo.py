@@ -57,6 +57,43 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     assert np.array_equal(merged["sv_end"] + first * synth.WINDOW, ref["sv_end"])
 
 
+def _job_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import abi, shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    jobs, blob = synth.make_align_jobs(9, 7, seed=4)          # every rank sees the job list, classifies its block
+    first, count = shard.shard_range(jobs.shape[0], rank, world)
+    res = pyoracle.Oracle("port").classify_reads(jobs[first:first + count], blob)
+    local = torch.from_numpy(np.frombuffer(res.tobytes(), dtype=np.uint8).copy())
+    rec = abi.align_result_dtype().itemsize
+    gathered, counts, mx = shard.gather_records(local, world, dist, record_bytes=rec)
+    if rank == 0:
+        merged = shard.merge_records(gathered.numpy(), counts, mx, dtype=abi.align_result_dtype(), sort_key=None)
+        np.save(os.path.join(out_dir, "jobs.npy"), merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_classifier_jobs_equal_single_process(tmp_path):
+    """the genotyping rows shard by job index exactly like junctions: block partition + padded all-gather"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_job_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    merged = np.load(os.path.join(str(tmp_path), "jobs.npy"))
+    jobs, blob = synth.make_align_jobs(9, 7, seed=4)
+    whole = pyoracle.Oracle("port").classify_reads(jobs, blob)
+    assert merged.tobytes() == whole.tobytes()
+
+
 def test_shard_range_partitions():
     from delly_amd import shard
     for n in (0, 1, 7, 64, 10001):
