@@ -30,6 +30,16 @@ CELLS_PER_U = 2 * 151 * 1001  # fwd + rev DP cells
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+# The side measurements of side_measurements(): (name, junctions, CPU sample, synth.make_batch kwargs).
+# tests/test_gpu_bench_shapes.py bit-compares the HIP path with oracle/_ref on exactly these batches.
+SIDE_PLAN = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
+             ("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
+             ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
+             ("ins_svt4", 5000, 5000, dict(mode="ins")),
+             ("lr_c4_align_consensus", 2048, 128, dict(mode="lr", sub_rate=0.01)),
+             ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)))
+
+
 class _DevPtr:
     """Wraps a raw device pointer for torch.as_tensor (RCCL needs a tensor)."""
 
@@ -38,34 +48,31 @@ class _DevPtr:
 
 
 def cpu_baseline(batch, budget_s=12.0):
-    """The reference's CPU path (oracle/_ref: its own headers) or the C port,
-    timed on this box's host cores with the reference's threading model
-    (src/shortpe.h:175-201) on a bounded sample of the same workload."""
+    """The reference's CPU path (oracle/_ref: its own headers) or the C port, timed on this box's host cores with
+    the reference's threading model (src/shortpe.h:175-201: std::threads on one atomic counter) over the SAME
+    10 000 C2 junctions.  Only the loop body is timed -- ONE alignConsensus() per junction, no diagnostic replay,
+    no marshalling -- and the clock runs inside the C++ driver around thread start .. join
+    (oracle/ref_driver.cpp: dref_time_refine_batch).  Every thread gets >= 32 junctions per pass."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     kind = "reference" if pyoracle.have_reference() else "port"
     orc = pyoracle.Oracle(kind)
     cores = os.cpu_count() or 1
-    from delly_amd import synth
-    # calibrate single-thread rate on a small sample
-    cal = _subbatch(batch, 64)
-    t0 = time.perf_counter()
-    orc.refine_batch(cal, want_alignment=False, n_threads=1)
-    t1 = time.perf_counter() - t0
-    per = t1 / cal.n
-    sub = _subbatch(batch, min(batch.n, max(cores * 8, 2000)))
-    t0 = time.perf_counter()
-    orc.refine_batch(sub, want_alignment=False, n_threads=cores)
-    first = time.perf_counter() - t0
-    reps = int(max(1, min(200, budget_s / max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        orc.refine_batch(sub, want_alignment=False, n_threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": reps * sub.n / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
-            "sample": "%d x the first %d of the %d C2 junctions, %d std::thread workers on an atomic counter "
-                      "(src/shortpe.h:175-201 model, %.1f s); single-thread %.0f alignments/s"
-                      % (reps, sub.n, batch.n, cores, dt, 1.0 / per)}
+    # single thread: ~1 s on a 512-junction prefix
+    cal = _subbatch(batch, 512)
+    s1, n1, _ = orc.time_refine(cal, n_threads=1, reps=1)
+    rate1 = n1 / s1
+    # all cores: the whole batch (>= 32 junctions per thread, else fewer threads), repeated to ~budget_s
+    threads = max(1, min(cores, batch.n // 32))
+    s0, _, _ = orc.time_refine(batch, n_threads=threads, reps=1)   # (also warms the thread stacks / page cache)
+    reps = int(max(1, min(400, budget_s / max(s0, 1e-3))))
+    sN, nN, okN = orc.time_refine(batch, n_threads=threads, reps=reps)
+    return {"value": nN / sN, "unit": "alignments/s", "cores": threads, "kind": kind,
+            "value_one_thread": rate1,
+            "sample": "%d passes over the same %d C2 junctions (%d alignConsensus calls, %d returned true) on %d "
+                      "std::thread workers pulling from one atomic counter (src/shortpe.h:175-201 model), %.1f s "
+                      "measured inside the C++ driver around thread start..join; one thread: %d junctions in %.2f s"
+                      % (reps, batch.n, nN, okN, threads, sN, n1, s1)}
 
 
 def _measured_traffic():
@@ -103,15 +110,8 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         orc = pyoracle.Oracle("reference" if pyoracle.have_reference() else "port")
     cores = os.cpu_count() or 1
     out = {}
-    #        name                       n      cpu sample   batch kwargs
-    plan = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
-            ("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
-            ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
-            ("ins_svt4", 5000, 5000, dict(mode="ins")),
-            ("lr_c4_align_consensus", 2048, 96, dict(mode="lr", sub_rate=0.01)),
-            ("lr_c4_msaedlib_n15", 768, 48, dict(mode="lr", n_reads=15, sub_rate=0.06)))
     want = (lambda name: True) if not only else (lambda name: name in only)
-    plan = tuple(x for x in plan if want(x[0]))
+    plan = tuple(x for x in SIDE_PLAN if want(x[0]))
     # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
     # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
     try:
@@ -169,16 +169,13 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         rb.free()
         if orc is not None and ncpu > 0:
             sub = b if ncpu >= n else synth.make_batch(ncpu, **kw)
-            t0 = time.perf_counter()
-            orc.refine_batch(sub, want_alignment=False, n_threads=cores, params=params)
-            first = time.perf_counter() - t0
-            reps = int(max(1, min(40, 1.5 / max(first, 1e-3))))   # ~1.5 s of CPU work per workload
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                orc.refine_batch(sub, want_alignment=False, n_threads=cores, params=params)
-            dtc = (time.perf_counter() - t0) / reps
-            out[name]["cpu_" + orc.kind] = {"junctions_per_s": sub.n / dtc, "cores": cores,
-                                            "sample": "%d x %d junctions, %.2f s each" % (reps, sub.n, dtc)}
+            threads = max(1, min(cores, sub.n))
+            sec, visits, _ = orc.time_refine(sub, n_threads=threads, reps=1, params=params)
+            reps = int(max(1, min(40, 1.5 / max(sec, 1e-3))))   # ~1.5 s of CPU work per workload
+            if reps > 1:
+                sec, visits, _ = orc.time_refine(sub, n_threads=threads, reps=reps, params=params)
+            out[name]["cpu_" + orc.kind] = {"junctions_per_s": visits / sec, "cores": threads,
+                                            "sample": "%d x %d junctions, %.2f s inside the C++ driver" % (reps, sub.n, sec)}
     # the split-read genotyping classifier (src/coverage.h:412-434), one process_batch of
     # 131072 x 8 AlignJobs (:271) resident in HBM: 26..37-byte probes against 150-byte reads
     try:

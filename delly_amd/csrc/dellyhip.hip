@@ -43,10 +43,21 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     if (_e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, #x, _e); \
   } while (0)
 
+// Owning device allocation: freed by the destructor (every struct that holds one -- batches, job lists, the
+// function-local buffers of the single-item wrappers -- releases its HBM when it goes out of scope).
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
   int alloc(size_t count) {
     release();
     n = count;
@@ -197,7 +208,7 @@ void launch_split(dh::SplitArgs a, int pairs, int max_blocks, int32_t* counters,
   a.work_counter = counters + K;
   hipLaunchKernelGGL(dh::split_pair_kernel<K>, dim3(balanced(pairs)), dim3(dh::WAVE), 0, s, a);
   a.n_work = 2 * pairs;  // same counter: number of deferred pairs (0 -> the kernel returns at once)
-  hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(std::min(2 * pairs, 1024)), dim3(dh::WAVE), 0, s, a);
+  hipLaunchKernelGGL(dh::split_align_kernel<K>, dim3(std::min({2 * pairs, 1024, max_blocks})), dim3(dh::WAVE), 0, s, a);   // (scratch holds max_blocks blocks)
   if (mid) (void)hipEventRecord(mid, s);  // (with several K bins: the last bin's DP end)
   hipLaunchKernelGGL(dh::split_post_kernel<K>, dim3(balanced(2 * pairs)), dim3(dh::WAVE), 0, s, a);
 }
@@ -215,7 +226,7 @@ void launch_quad(dh::SplitArgs a, int n_quads, int n_pairs, int max_blocks, int3
   a.work_counter = counters + 5 + KQ;   // (slots 6..10; the deferred count lives 16 further)
   hipLaunchKernelGGL((dh::split_quad_kernel<KQ, KP>), dim3(balanced(items)), dim3(dh::WAVE), 0, s, a, n_quads);
   a.n_work = seats;   // the list is a flat array of junction indices (-1 = empty seat) for the next two kernels
-  hipLaunchKernelGGL(dh::split_align_kernel<KP>, dim3(std::min(seats, 1024)), dim3(dh::WAVE), 0, s, a);
+  hipLaunchKernelGGL(dh::split_align_kernel<KP>, dim3(std::min({seats, 1024, max_blocks})), dim3(dh::WAVE), 0, s, a);
   if (mid) (void)hipEventRecord(mid, s);
   hipLaunchKernelGGL(dh::split_post_kernel<KP>, dim3(balanced(seats)), dim3(dh::WAVE), 0, s, a);
 }
@@ -663,11 +674,14 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
     c->chr_dev.resize(chr + 1, nullptr);
     c->chr_len.resize(chr + 1, 0);
   }
-  if (c->chr_dev[chr]) (void)hipFree(c->chr_dev[chr]);
-  uint8_t* d = nullptr;
+  uint8_t* d = nullptr;   // allocate and fill the new buffer first: a failure leaves the old chromosome in place
   hipError_t e = hipMalloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
   if (e != hipSuccess) return fail(DELLYHIP_E_NOMEM, "hipMalloc(chromosome)", e);
-  HIPCHK(hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice));
+  if (len) {
+    e = hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(DELLYHIP_E_RUNTIME, "H2D chromosome", e); }
+  }
+  if (c->chr_dev[chr]) (void)hipFree(c->chr_dev[chr]);
   c->chr_dev[chr] = d;
   c->chr_len[chr] = len;
   c->chr_dirty = true;
@@ -690,13 +704,23 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
                              dellyhip_batch** out) {
   if (!c || !out || n < 0 || (n && (!junc || !seq_off))) return fail(DELLYHIP_E_ARG, "bad batch arguments");
   HIPCHK(hipSetDevice(c->device));
+  if (n_seq && (!seq_off || (seq_off[n_seq] && !seq_blob))) return fail(DELLYHIP_E_ARG, "null sequence blob / offsets");
+  for (uint64_t i = 0; i < n_seq; ++i)
+    if (seq_off[i + 1] < seq_off[i] || seq_off[i + 1] - seq_off[i] > 0x7fffffffull)
+      return fail(DELLYHIP_E_ARG, "seq_off is not monotonic");
   for (int i = 0; i < n; ++i) {
     const dellyhip_junction& J = junc[i];
-    if (J.n_seq < 0 || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
+    if (J.n_seq < 0 || J.seq_first > n_seq || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
     if (!with_msa && J.n_seq != 1) return fail(DELLYHIP_E_ARG, "align_consensus needs exactly one sequence per junction");
     if (J.chr < 0 || J.chr2 < 0 || (size_t)J.chr >= c->chr_dev.size() || (size_t)J.chr2 >= c->chr_dev.size() ||
         !c->chr_dev[J.chr] || !c->chr_dev[J.chr2])
       return fail(DELLYHIP_E_ARG, "junction refers to a chromosome that was not uploaded");
+    // The window arithmetic of _initBreakpoint (src/tags.h:151-172) clamps against 0 and target_len only on one side
+    // each; a breakpoint outside its chromosome makes the reference's substr() calls throw / read out of bounds,
+    // so such records are malformed input here too.  Types 0-4 are intra-chromosomal (src/tags.h:22-25).
+    if (J.sv_start < 0 || J.sv_end < 0 || (int64_t)J.sv_start > c->chr_len[J.chr] || (int64_t)J.sv_end > c->chr_len[J.chr2])
+      return fail(DELLYHIP_E_ARG, "junction coordinates outside the chromosome");
+    if (J.svt >= 0 && J.svt <= 4 && J.chr != J.chr2) return fail(DELLYHIP_E_ARG, "svt 0-4 with chr != chr2");
   }
   dellyhip_batch* b = new dellyhip_batch();
   b->n = n;
@@ -857,6 +881,9 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   if (!c->serial_ev) HIPCHK(hipEventCreateWithFlags(&c->serial_ev, hipEventDisableTiming));
   if (c->serial_valid) HIPCHK(hipStreamWaitEvent(s, c->serial_ev, 0));
   HIPCHK(hipEventRecord(e3[0], s));
+  // with_msa == 0: junction_setup treats res[j].status / sr_support as input from an MSA stage; without one they
+  // must be zero on EVERY run, or a junction flagged in run 1 takes the "prior status" branch in run 2
+  if (!b->with_msa) HIPCHK(hipMemsetAsync(b->res.p, 0, (size_t)b->n * sizeof(dellyhip_result), s));
   if (b->with_msa == 2) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
     if (b->lm_items > 0) {
@@ -1030,6 +1057,7 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_spli
 int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* results, char* out_blob,
                          uint64_t out_blob_cap, uint64_t* out_blob_len) {
   if (!c || !b || (!results && b->n)) return fail(DELLYHIP_E_ARG, "null argument");
+  if (b->n && !b->ever_run) return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch: the batch has not been run");
   HIPCHK(hipSetDevice(c->device));
   int rc = dellyhip_batch_sync(c, b);
   if (rc) return rc;

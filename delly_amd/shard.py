@@ -28,7 +28,7 @@ def gather_records(local, world, dist=None, max_count=None, record_bytes=None):
     rec = record_bytes or abi.result_dtype().itemsize
     count = local.numel() // rec
     if world == 1:
-        return local, [count]
+        return local, [count], count
     if max_count is None:
         t = torch.tensor([count], dtype=torch.int64, device=local.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1989,6 +1989,54 @@ static void* worker(void* arg) {
   return NULL;
 }
 
+/* CPU baseline timer (bench.py cpu_baseline, kind "port"): the same worker loop, `reps` passes over the batch,
+ * results discarded (one scratch record per thread), clock around thread start .. join inside this function. */
+typedef struct { batch_t* b; uint64_t total; _Atomic uint64_t* next; _Atomic int64_t* oks; } timed_t;
+static void* timed_worker(void* arg) {
+  timed_t* t = (timed_t*)arg;
+  dellyhip_result R;
+  int64_t mine = 0;
+  for (;;) {
+    uint64_t i = atomic_fetch_add(t->next, 1);
+    if (i >= t->total) break;
+    refine_one(t->b, &t->b->junc[i % (uint64_t)t->b->n_junc], &R);
+    mine += R.ok;
+  }
+  atomic_fetch_add(t->oks, mine);
+  return NULL;
+}
+int dor_time_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                          const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                          const char* blob, const uint64_t* off, int with_msa, int n_threads, int reps,
+                          double* seconds, int64_t* n_ok) {
+  batch_t b;
+  b.p = p; b.n_chr = n_chr; b.chr_seq = chr_seq; b.chr_len = chr_len; b.n_junc = n_junc;
+  b.junc = junc; b.blob = blob; b.off = off; b.results = NULL; b.out_blob = NULL;
+  b.out_cap = 0; b.with_msa = with_msa; b.want_alignment = 0;
+  b.probes = NULL; b.probe_blob = NULL; b.probe_cap = 0;
+  atomic_init(&b.probe_used, 0);
+  atomic_init(&b.used, 0);
+  atomic_init(&b.next, 0);
+  _Atomic uint64_t next;
+  _Atomic int64_t oks;
+  atomic_init(&next, 0);
+  atomic_init(&oks, 0);
+  timed_t t = {&b, (uint64_t)(reps > 1 ? reps : 1) * (uint64_t)(n_junc > 0 ? n_junc : 0), &next, &oks};
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (n_threads <= 1) timed_worker(&t);
+  else {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int k = 0; k < n_threads; ++k) pthread_create(&th[k], NULL, timed_worker, &t);
+    for (int k = 0; k < n_threads; ++k) pthread_join(th[k], NULL);
+    free(th);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (n_ok) *n_ok = atomic_load(&oks);
+  return 0;
+}
+
 int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
                      const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
                      const char* blob, const uint64_t* off, dellyhip_result* results,

@@ -68,6 +68,12 @@ int dor_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr
                      char* out_blob, uint64_t out_cap, uint64_t* out_used, int with_msa,
                      int want_alignment, int n_threads);
 
+/* bench.py cpu_baseline timer: `reps` passes of the worker loop, results discarded, clock inside (seconds) */
+int dor_time_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                          const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                          const char* blob, const uint64_t* off, int with_msa, int n_threads, int reps,
+                          double* seconds, int64_t* n_ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,6 +274,30 @@ class Oracle:
         return res, out[:used.value]
 
 
+def _time_refine(self, batch, with_msa=None, n_threads=1, reps=1, params=None):
+    """bench.py cpu_baseline: `reps` passes of the loop body of src/shortpe.h:183-197 over the batch on n_threads
+    std::threads (atomic work counter), timed INSIDE the C/C++ function around thread start .. join; no diagnostic
+    replay, no result marshalling.  -> (seconds, junction visits, alignConsensus()==true count)"""
+    if with_msa is None:
+        with_msa = batch.with_msa
+    p = params if params is not None else self.params
+    nchr = len(batch.chroms)
+    chr_ptrs = (C.c_char_p * nchr)(*[C.cast(c.ctypes.data, C.c_char_p) for c in batch.chroms])
+    chr_len = np.array([c.size for c in batch.chroms], dtype=np.int64)
+    junc = np.ascontiguousarray(batch.junctions)
+    sec = C.c_double(0)
+    oks = C.c_int64(0)
+    rc = self._f("time_refine_batch")(
+        C.byref(p), nchr, chr_ptrs, _p(chr_len, C.POINTER(C.c_int64)), batch.n, _p(junc, C.c_void_p),
+        _p(batch.seq_blob), _p(batch.seq_off, C.POINTER(C.c_uint64)), int(with_msa), int(n_threads), int(reps),
+        C.byref(sec), C.byref(oks))
+    assert rc == 0
+    return sec.value, int(reps) * batch.n, oks.value
+
+
+Oracle.time_refine = _time_refine
+
+
 def blob_field(res_row, blob, which):
     """Extracts 'cons' | 'allele' | 'aln' bytes of one result row."""
     if which == "cons":

@@ -446,6 +446,77 @@ int dref_refine_batch(const dellyhip_params* p, int n_chr, const char* const* ch
   return (bw.used.load() > out_cap && out_blob) ? -1 : 0;
 }
 
+// CPU baseline timer (bench.py cpu_baseline): ONLY the loop body of src/shortpe.h:183-197 /
+// src/assemble.h:836-861 -- msa()/msaEdlib()/msaWfa() when reads are given, then ONE alignConsensus() --
+// no diagnostic replay, no blob marshalling.  n_threads std::threads pull indices from one atomic counter
+// (the reference's model, src/shortpe.h:175-182) until reps * n_junc junction visits are done; the clock
+// (steady_clock, inside this function) covers thread start to join.  *seconds = wall time of that region,
+// *n_ok = alignConsensus() calls that returned true (keeps the work observable).
+int dref_time_refine_batch(const dellyhip_params* p, int n_chr, const char* const* chr_seq,
+                           const int64_t* chr_len, int n_junc, const dellyhip_junction* junc,
+                           const char* blob, const uint64_t* off, int with_msa, int n_threads, int reps,
+                           double* seconds, int64_t* n_ok) {
+  using namespace torali;
+  RefConfig c = make_config(p);
+  std::vector<uint32_t> tlen(n_chr);
+  for (int i = 0; i < n_chr; ++i) tlen[i] = (uint32_t)chr_len[i];
+  bam_hdr_t hdr;
+  hdr.n_targets = n_chr;
+  hdr.target_len = tlen.data();
+  hdr.target_name = NULL;
+  const bool realign0 = (p->reserved & 1) != 0;
+  const uint64_t total = (uint64_t)std::max(reps, 1) * (uint64_t)std::max(n_junc, 0);
+  std::atomic<uint64_t> next(0);
+  std::atomic<int64_t> oks(0);
+  auto worker = [&]() {
+    int64_t mine = 0;
+    for (;;) {
+      const uint64_t t = next.fetch_add(1, std::memory_order_relaxed);
+      if (t >= total) break;
+      const dellyhip_junction& J = junc[t % (uint64_t)n_junc];
+      StructuralVariantRecord sv;
+      sv.chr = J.chr; sv.chr2 = J.chr2; sv.svStart = J.sv_start; sv.svEnd = J.sv_end; sv.svt = J.svt;
+      sv.insLen = J.ins_len; sv.id = J.svid;
+      bool realign = realign0;
+      if (with_msa) {
+        if (with_msa != 2 && J.n_seq <= 1) continue;
+        if (J.n_seq < 1) continue;
+        std::vector<std::string> sps;
+        for (int32_t k = 0; k < J.n_seq; ++k)
+          sps.push_back(std::string(blob + off[J.seq_first + k], blob + off[J.seq_first + k + 1]));
+        if (with_msa == 2 && sv.svt == 4) {
+          const char* sq = chr_seq[J.chr];
+          int32_t seqlen = (int32_t)hdr.target_len[J.chr];
+          std::string prefix = boost::to_upper_copy(std::string(sq + std::max(sv.svStart - (int32_t)c.minConsWindow, 0), sq + sv.svStart));
+          std::string suffix = boost::to_upper_copy(std::string(sq + sv.svStart, sq + std::min(seqlen, sv.svStart + c.minConsWindow)));
+          msaWfa(c, sps, sv.consensus, prefix, suffix);
+          realign = false;
+        } else if (with_msa == 2) msaEdlib(c, sps, sv.consensus);
+        else msa(c, sps, sv.consensus);
+      } else sv.consensus = std::string(blob + off[J.seq_first], blob + off[J.seq_first + 1]);
+      if (with_msa == 2 && sv.svt != 4) {   // src/assemble.h:840-848
+        int32_t svSize = sv.svEnd - sv.svStart;
+        if (((sv.svt == 0) || (sv.svt == 1)) && (svSize < (int32_t)sv.consensus.size()))
+          sv.consensus = sv.consensus.substr((sv.consensus.size() - svSize) / 2, svSize);
+      }
+      const char* seq = chr_seq[J.chr];
+      const char* sndSeq = (J.chr2 != J.chr) ? chr_seq[J.chr2] : NULL;
+      if (alignConsensus(c, const_cast<bam_hdr_t const*>(&hdr), seq, sndSeq, sv, realign)) ++mine;
+    }
+    oks.fetch_add(mine);
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  if (n_threads <= 1) worker();
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (n_ok) *n_ok = oks.load();
+  return 0;
+}
+
 // std::unordered_set<std::string> iteration order of the host
 // (src/shortpe.h:68,96): inserts the reads in the given order and returns the
 // permutation in which the set iterates (perm[k] = input index, -1 padded when

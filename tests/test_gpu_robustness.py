@@ -1,0 +1,76 @@
+"""-m gpu: host-side robustness of the C-ABI (round-1 advisor findings): device memory is returned by every
+entry point, a resident batch gives the same records on every run, malformed junction records are rejected
+with DELLYHIP_E_ARG before any kernel sees them."""
+import numpy as np
+import pytest
+import torch
+
+from delly_amd import abi, refine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_single_call_entry_points_return_their_device_memory(gpu_ctx):
+    jobs, jblob = synth.make_align_jobs(40, 40, seed=5)
+    nj, nblob = synth.make_nw_jobs(64, seed=5)
+    b = synth.make_batch(64, mode="c2", seed=3)
+    gpu_ctx.set_chromosomes(b.chroms)
+    reads = [bytes(x) for x in np.random.default_rng(1).choice(list(b"ACGT"), (4, 300)).astype(np.uint8)]
+
+    def once():
+        gpu_ctx.classify_reads(jobs, jblob)
+        gpu_ctx.edit_distance_nw_batch(nj, nblob)
+        gpu_ctx.generate_probes(b)
+        gpu_ctx.edlib_align(reads[0], reads[1], 0, 0)
+        gpu_ctx.edlib_align(reads[0][:100], reads[1][:200], 2, 2)
+        gpu_ctx.msa_edlib(reads)
+        gpu_ctx.msa_wfa(reads)
+
+    for _ in range(3):   # warm the allocator (context scratch, code objects)
+        once()
+    before = _free_bytes()
+    for _ in range(25):
+        once()
+    after = _free_bytes()
+    assert before - after < (4 << 20), "device memory leaked: %d bytes over 25 rounds" % (before - after)
+
+
+def test_resident_batch_rerun_is_identical_and_fetch_needs_a_run(gpu_ctx):
+    # junction 0 exceeds the short-read window limit only through its coordinates: consensus of 300 bp, window > 2048
+    b = synth.make_batch(32, mode="mixed", seed=2)
+    gpu_ctx.set_chromosomes(b.chroms)
+    rb = gpu_ctx.upload(b)
+    with pytest.raises(refine.DellyHipError) as e:
+        rb.fetch()
+    assert e.value.code == abi.E_ARG
+    rb.run(); rb.sync()
+    r1, b1 = rb.fetch()
+    rb.run(); rb.sync()
+    r2, b2 = rb.fetch()
+    assert r1.tobytes() == r2.tobytes() and b1.tobytes() == b2.tobytes()
+    rb.free()
+
+
+def test_malformed_junction_records_are_rejected(gpu_ctx):
+    b = synth.make_batch(4, mode="c2", seed=7)
+    gpu_ctx.set_chromosomes(b.chroms)
+    clen = b.chroms[0].size
+    for field, val in (("sv_start", -5), ("sv_end", -1), ("sv_start", clen + 1), ("sv_end", clen + 10)):
+        j = b.junctions.copy()
+        j[field][1] = val
+        with pytest.raises(refine.DellyHipError) as e:
+            gpu_ctx.align_consensus_batch(j, b.seq_blob, b.seq_off)
+        assert e.value.code == abi.E_ARG, field
+    off = b.seq_off.copy()
+    off[2] = off[1] - 1   # not monotonic
+    with pytest.raises(refine.DellyHipError) as e:
+        gpu_ctx.align_consensus_batch(b.junctions, b.seq_blob, off)
+    assert e.value.code == abi.E_ARG
+    # the well-formed batch still runs
+    r, _ = gpu_ctx.align_consensus_batch(b.junctions, b.seq_blob, b.seq_off)
+    assert r.shape[0] == 4
