@@ -146,6 +146,9 @@ struct dellyhip_batch {
   int small_inv_n = 0;
   // long-read MSA (with_msa == 2: msaEdlib)
   DevBuf<int32_t> lm_edit, lm_pair_first;
+  DevBuf<int8_t> lm_hbuf;            // strip passes of read pairs beyond MYERS_ROWS (2 x lm_hbuf_half bytes per pair wavefront)
+  uint64_t lm_hbuf_half = 0;
+  int lm_pair_grid = 1;
   DevBuf<uint8_t> lm_ws;
   dh::LrMsaArgs lm{};
   int lm_items = 0, lm_blocks = 0;
@@ -360,6 +363,15 @@ bool is_lr_shape(const dellyhip_params& P, const dellyhip_junction& J, int m, in
   return (P.reserved & 1) || m > dh::MMAX || n > dh::NMAX;
 }
 
+// Long-read workspaces are per resident wavefront and grow with the product of the batch's longest consensus and
+// window (BASELINE's 10 kb x 20 kb stress shape: ~55 MB of running-max codes per wavefront): the number of resident
+// wavefronts is cut so that one workspace stays below half of the free HBM (at least 1 GiB is always allowed).
+uint64_t ws_budget_bytes() {
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 8ull << 30;
+  return std::max<uint64_t>(1ull << 30, (uint64_t)fr / 2);
+}
+
 // per-block workspace of the long-read strip kernel for consensus <= lr_m, window <= lr_n
 int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, int lr_cnt) {
   dh::LrArgs& R = b->lr;
@@ -381,10 +393,37 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   R.off_stack = take((uint64_t)Q * R.strip_words * 4);
   R.ws_stride = o;
   b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * 4));
+  b->lr_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lr_blocks, ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1)));
   int rc = b->lr_ws.reserve((size_t)R.ws_stride * b->lr_blocks);
   if (rc) return rc;
   R.ws = b->lr_ws.p;
   return 0;
+}
+
+// alignment-column capacity of msaEdlib for reads <= maxlen: every progressive step may add columns (insertions of the
+// new read), 6 % ONT error keeps the total near 1.3 x the read length; twice the longest read + slack, at least the
+// round-1 capacity, at most what the strip kernels take as a consensus
+int lm_acap(int maxlen) {
+  const long want = std::max<long>(4224, (2L * maxlen + 512 + 63) & ~63L);
+  return (int)std::min<long>((dh::LR_MMAX + 1 + 63) & ~63, want);
+}
+
+// workspace layout of lrmsa_kernel for reads <= maxlen
+void lm_layout(dh::LrMsaArgs& M, int maxlen) {
+  M.acap = lm_acap(maxlen);
+  M.ncap = std::min<int>((maxlen + 64) & ~63, (dh::LR_NMAX + 64) & ~63);
+  M.strip_words = dh::lm_dirs_words(M.acap, M.ncap);   // capacity of the direction area (traceback-regime rectangles)
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take((uint64_t)dh::LM_NR * M.acap);                  // alnA at 0
+  M.off_alnB = take((uint64_t)dh::LM_NR * M.acap);
+  M.off_astr = take(M.acap);
+  M.off_bnd = take(4ull * ((uint64_t)M.ncap + 128) * 4);
+  M.off_ops = take((uint64_t)M.acap + M.ncap + 64);
+  M.off_tmp = take((uint64_t)M.acap + M.ncap + 64);
+  M.off_cons = take(M.acap);
+  M.off_dirs = take(M.strip_words * 4);
+  M.ws_stride = o;
 }
 
 // per-block workspace of the long-read insertion kernel
@@ -392,7 +431,6 @@ int setup_lri_workspace(dellyhip_ctx* c, dellyhip_batch* b, int m_max, int n_max
   dh::LrInsArgs& R = b->lri;
   R.mcap = (m_max + 64) & ~63;
   R.ncap = (n_max + 64) & ~63;
-  R.strip_words = dh::lr_strip_words(R.ncap);
   uint64_t o = 0;
   auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
   take(R.mcap);
@@ -404,9 +442,11 @@ int setup_lri_workspace(dellyhip_ctx* c, dellyhip_batch* b, int m_max, int n_max
   R.off_opsR = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_tmp = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_dist = take(2ull * ((uint64_t)R.ncap + 64) * 4);
-  R.off_dirs = take((uint64_t)(R.mcap / dh::LRS + 1) * R.strip_words * 4);
+  R.strip_words = dh::lm_dirs_words(R.mcap, R.ncap);   // capacity of the direction area (traceback-regime rectangles)
+  R.off_dirs = take(R.strip_words * 4);
   R.ws_stride = o;
   b->lri_blocks = std::max(1, std::min(cnt, c->n_cu * 4));
+  b->lri_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lri_blocks, ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1)));
   int rc = b->lri_ws.reserve((size_t)R.ws_stride * b->lri_blocks);
   if (rc) return rc;
   R.ws = b->lri_ws.p;
@@ -416,9 +456,12 @@ int setup_lri_workspace(dellyhip_ctx* c, dellyhip_batch* b, int m_max, int n_max
 // workspace layout of the msaWfa kernel for reads <= maxlen; returns the per-block stride
 uint64_t wfa_layout(dh::LrWfaArgs& W, int maxlen) {
   W.ncap = std::max<int>((maxlen + 64) & ~63, 64);
-  const int acap = dh::WFA_ACAP;
+  // superstring / alignment columns: reads overlap almost completely (they are slices around one junction), so twice
+  // the longest read plus slack holds any superstring the reference builds from them; never below the round-1 8192
+  W.acap = std::min<int>(dh::WFA_ACAP_MAX, std::max<int>(8192, (2 * maxlen + 2048 + 63) & ~63));
+  const int acap = W.acap;
   const int qcap = std::max(W.ncap, acap);
-  W.strip_words = dh::lr_strip_words(qcap);
+  W.strip_words = dh::lm_dirs_words(acap, qcap);   // capacity of the direction area
   uint64_t o = 0;
   auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
   take((uint64_t)(dh::LM_NR + 1) * acap);                 // alnA at 0
@@ -428,7 +471,7 @@ uint64_t wfa_layout(dh::LrWfaArgs& W, int maxlen) {
   W.off_ops = take(2ull * qcap + 128);
   W.off_tmp = take(2ull * qcap + 128);
   W.off_cons = take(acap);
-  W.off_dirs = take((uint64_t)(acap / dh::LRS + 1) * W.strip_words * 4);
+  W.off_dirs = take(W.strip_words * 4);
   W.off_tabI = take((uint64_t)dh::WFA_KTAB * 4);
   W.off_tabJ = take((uint64_t)dh::WFA_KTAB * 4);
   W.off_diag = take(((uint64_t)acap + W.ncap + 128) * 4);
@@ -744,10 +787,18 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       }
     }
   }
+  int msa_maxlen = 1;   // longest read of the batch (with_msa == 2)
   if (with_msa == 2) {  // long-read MSA: consensus / window lengths are only bounded at upload time
-    b->out_cons_cap = (dh::LR_MMAX + 1 + 15) & ~15;
-    b->out_allele_cap = (dh::LR_MMAX + dh::LR_NMAX + 8 + 15) & ~15;
-    b->out_aln_cap = 2 * b->out_allele_cap;
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < junc[i].n_seq; ++k)
+        msa_maxlen = std::max<int>(msa_maxlen, (int)std::min<uint64_t>(seq_off[junc[i].seq_first + k + 1] - seq_off[junc[i].seq_first + k], 1u << 20));
+    // consensus <= alignment columns <= lm_acap(longest read); exact alleles exist only for svEnd - svStart <= indelsize
+    // (src/split.h:606), where the window is contiguous: |svRefStr| <= 2 |consensus| + indelsize (src/split.h:116)
+    const int acap = lm_acap(msa_maxlen);
+    b->out_cons_cap = (acap + 15) & ~15;
+    const long win = std::min<long>(dh::LR_NMAX, 2L * acap + std::max(c->params.indelsize, 0));
+    b->out_allele_cap = (int)((acap + win + 8 + 15) & ~15L);
+    b->out_aln_cap = 2 * (int)((acap + (long)dh::LR_NMAX + 8 + 15) & ~15L);
   }
   if (lr_cnt || lri_cnt) {
     const int mm = std::max(lr_m, lri_m), nn = std::max(lr_n, lri_n);
@@ -807,35 +858,29 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     if (with_msa == 2) {
       // msaEdlib: all-pairs work list + per-block workspace sized from the longest read
       std::vector<int32_t> pf(n + 1, 0);
-      int maxlen = 1;
+      const int maxlen = msa_maxlen;
+      bool long_pairs = false;   // a junction with two reads beyond the rows of one bit-vector pass: strip passes need a byte workspace
       for (int i = 0; i < n; ++i) {
         const int N = std::max(0, std::min(junc[i].n_seq, (int)dh::LM_NR));
         pf[i + 1] = pf[i] + ((junc[i].n_seq <= dh::LM_NR) ? N * (N - 1) / 2 : 0);
+        int nlong = 0;
         for (int k = 0; k < junc[i].n_seq; ++k)
-          maxlen = std::max<int>(maxlen, (int)std::min<uint64_t>(seq_off[junc[i].seq_first + k + 1] - seq_off[junc[i].seq_first + k], 1u << 20));
+          nlong += (seq_off[junc[i].seq_first + k + 1] - seq_off[junc[i].seq_first + k] > (uint64_t)dh::MYERS_ROWS) ? 1 : 0;
+        long_pairs |= nlong >= 2;
       }
+      b->lm_hbuf_half = long_pairs ? (((uint64_t)maxlen + 16 + 255) & ~255ull) : 0;
       b->lm_items = pf[n];
       if ((rc = b->lm_pair_first.alloc(n + 1)) || (rc = b->lm_edit.alloc(std::max<size_t>((size_t)n * dh::LM_NR * dh::LM_NR, 1)))) return bail(rc);
       e = hipMemcpy(b->lm_pair_first.p, pf.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D pair list", e));
       dh::LrMsaArgs& M = b->lm;
-      M.acap = (dh::LR_MMAX + 1 + 63) & ~63;
-      M.ncap = std::min<int>((maxlen + 64) & ~63, (dh::LR_NMAX + 64) & ~63);
-      M.strip_words = dh::lr_strip_words(M.ncap);
-      uint64_t o = 0;
-      auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
-      take((uint64_t)dh::LM_NR * M.acap);                  // alnA at 0
-      M.off_alnB = take((uint64_t)dh::LM_NR * M.acap);
-      M.off_astr = take(M.acap);
-      M.off_bnd = take(4ull * ((uint64_t)M.ncap + 128) * 4);
-      M.off_ops = take((uint64_t)M.acap + M.ncap + 64);
-      M.off_tmp = take((uint64_t)M.acap + M.ncap + 64);
-      M.off_cons = take(M.acap);
-      M.off_dirs = take((uint64_t)(M.acap / dh::LRS + 1) * M.strip_words * 4);
-      M.ws_stride = o;
+      lm_layout(M, maxlen);
       b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4));
+      b->lm_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lm_blocks, ws_budget_bytes() / std::max<uint64_t>(M.ws_stride, 1)));
       if ((rc = b->lm_ws.alloc((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
       M.ws = b->lm_ws.p;
+      b->lm_pair_grid = std::max(1, std::min(b->lm_items, c->n_cu * 16));
+      if (b->lm_hbuf_half && (rc = b->lm_hbuf.alloc((size_t)2 * b->lm_hbuf_half * b->lm_pair_grid))) return bail(rc);
       // insertions: msaWfa kernel
       std::vector<int32_t> wl;
       for (int i = 0; i < n; ++i)
@@ -887,8 +932,9 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   if (b->with_msa == 2) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
     if (b->lm_items > 0) {
-      dh::PairArgs pa{b->junc.p, b->seq_blob.p, b->seq_off.p, b->lm_pair_first.p, b->n, b->lm_items, dh::LM_NR, b->lm_edit.p};
-      hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(std::min(b->lm_items, c->n_cu * 16)), dim3(dh::WAVE), 0, s, pa);
+      dh::PairArgs pa{b->junc.p, b->seq_blob.p, b->seq_off.p, b->lm_pair_first.p, b->n, b->lm_items, dh::LM_NR, b->lm_edit.p,
+                      b->lm_hbuf.p, b->lm_hbuf_half};
+      hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(b->lm_pair_grid), dim3(dh::WAVE), 0, s, pa);
       HIPCHK(hipGetLastError());
     }
     dh::LrMsaArgs M = b->lm;
@@ -1155,20 +1201,12 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   DevBuf<int32_t> dpf, dedit, dlen;
   DevBuf<dellyhip_result> dres;
   dh::LrMsaArgs M{};
-  M.acap = (dh::LR_MMAX + 1 + 63) & ~63;
-  M.ncap = (maxlen + 64) & ~63;
-  M.strip_words = dh::lr_strip_words(M.ncap);
-  uint64_t o = 0;
-  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
-  take((uint64_t)dh::LM_NR * M.acap);
-  M.off_alnB = take((uint64_t)dh::LM_NR * M.acap);
-  M.off_astr = take(M.acap);
-  M.off_bnd = take(4ull * ((uint64_t)M.ncap + 128) * 4);
-  M.off_ops = take((uint64_t)M.acap + M.ncap + 64);
-  M.off_tmp = take((uint64_t)M.acap + M.ncap + 64);
-  M.off_cons = take(M.acap);
-  M.off_dirs = take((uint64_t)(M.acap / dh::LRS + 1) * M.strip_words * 4);
-  M.ws_stride = o;
+  lm_layout(M, maxlen);
+  int nlong = 0;
+  for (int k = 0; k < n_reads; ++k) nlong += (seq_off[k + 1] - seq_off[k] > (uint64_t)dh::MYERS_ROWS) ? 1 : 0;
+  const uint64_t hhalf = (nlong >= 2) ? (((uint64_t)maxlen + 16 + 255) & ~255ull) : 0;
+  DevBuf<int8_t> dhb;
+  if (hhalf && (rc = dhb.alloc((size_t)2 * hhalf * std::max(pf[1], 1)))) return rc;
   if ((rc = dj.alloc(1)) || (rc = dblob.alloc(blob_bytes + 64)) || (rc = doff.alloc(n_reads + 1)) ||
       (rc = dpf.alloc(2)) || (rc = dedit.alloc(dh::LM_NR * dh::LM_NR)) || (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) ||
       (rc = dout.alloc(M.acap)) || (rc = dws.alloc(M.ws_stride)))
@@ -1180,7 +1218,7 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
   HIPCHK(hipMemset(dedit.p, 0, dh::LM_NR * dh::LM_NR * sizeof(int32_t)));
   if (pf[1] > 0) {
-    dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p};
+    dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p, dhb.p, hhalf};
     hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(pf[1]), dim3(dh::WAVE), 0, c->stream, pa);
     HIPCHK(hipGetLastError());
   }
@@ -1231,7 +1269,7 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
   dh::LrWfaArgs W{};
   wfa_layout(W, maxlen);
   if ((rc = dj.alloc(1)) || (rc = dblob.alloc(blob_bytes + 64)) || (rc = doff.alloc(n_reads + 1)) ||
-      (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) || (rc = dout.alloc(dh::WFA_ACAP)) || (rc = dws.alloc(W.ws_stride)) ||
+      (rc = dlen.alloc(1)) || (rc = dres.alloc(1)) || (rc = dout.alloc(W.acap)) || (rc = dws.alloc(W.ws_stride)) ||
       (rc = dpre.alloc(std::max(prefix_len, 1))) || (rc = dsuf.alloc(std::max(suffix_len, 1))))
     return rc;
   HIPCHK(hipMemcpy(dj.p, &J, sizeof J, hipMemcpyHostToDevice));
@@ -1242,7 +1280,7 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
   HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
   HIPCHK(hipMemset(dws.p, 0, W.ws_stride));
   W.junc = dj.p; W.seq_blob = dblob.p; W.seq_off = doff.p; W.p = c->params; W.res = dres.p;
-  W.out_blob = dout.p; W.out_stride = dh::WFA_ACAP; W.out_cons_cap = dh::WFA_ACAP; W.cons_len = dlen.p;
+  W.out_blob = dout.p; W.out_stride = W.acap; W.out_cons_cap = W.acap; W.cons_len = dlen.p;
   W.work_list = nullptr; W.n_work = 1; W.use_anchors = 0;
   W.prefix = dpre.p; W.suffix = dsuf.p; W.prefix_len = prefix_len; W.suffix_len = suffix_len;
   W.ws = dws.p;
@@ -1495,6 +1533,9 @@ struct dellyhip_nwjobs {
   DevBuf<uint8_t> blob;
   DevBuf<int32_t> dist;
   DevBuf<uint32_t> next;
+  DevBuf<int8_t> hbuf;          // strip passes of pairs with both strings beyond MYERS_ROWS
+  uint64_t hbuf_half = 0;
+  int grid = 1;
   hipStream_t last_stream = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   ~dellyhip_nwjobs() {
@@ -1517,6 +1558,15 @@ int dellyhip_nwjobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_nw_j
       (rc = b->dist.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->next.alloc(1)))
     return rc;
   if (n_jobs >= (1ull << 31) - 65536) return fail(DELLYHIP_E_ARG, "too many nw jobs");
+  b->grid = (int)std::min<uint64_t>(std::max<uint64_t>(n_jobs, 1), (uint64_t)std::max(1, c->n_cu) * 28);   // 7 wavefronts per SIMD (71 VGPRs)
+  uint64_t longest = 0;
+  for (uint64_t i = 0; i < n_jobs; ++i)
+    if (jobs[i].query_len > (uint32_t)dh::MYERS_ROWS && jobs[i].target_len > (uint32_t)dh::MYERS_ROWS)
+      longest = std::max<uint64_t>(longest, std::max(jobs[i].query_len, jobs[i].target_len));
+  if (longest) {
+    b->hbuf_half = (longest + 16 + 255) & ~255ull;
+    if ((rc = b->hbuf.alloc((size_t)2 * b->hbuf_half * b->grid))) return rc;
+  }
   if (n_jobs) HIPCHK(hipMemcpyAsync(b->jobs.p, jobs, n_jobs * sizeof(dellyhip_nw_job), hipMemcpyHostToDevice, c->stream));
   if (blob_len) HIPCHK(hipMemcpyAsync(b->blob.p, blob, blob_len, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1533,8 +1583,8 @@ int dellyhip_nwjobs_run(dellyhip_ctx* c, dellyhip_nwjobs* b, void* stream_) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n, b->next.p};
-  const int grid = (int)std::min<uint64_t>(b->n, (uint64_t)std::max(1, c->n_cu) * 28);   // 7 wavefronts per SIMD (71 VGPRs)
+  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n, b->next.p, b->hbuf.p, b->hbuf_half};
+  const int grid = b->grid;
   HIPCHK(hipMemsetAsync(b->next.p, 0, sizeof(uint32_t), st));
   HIPCHK(hipEventRecord(e0, st));
   hipLaunchKernelGGL(dh::nw_jobs_kernel, dim3(grid), dim3(dh::WAVE), 0, st, a);

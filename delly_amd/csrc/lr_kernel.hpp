@@ -28,9 +28,9 @@ namespace dh {
 
 constexpr int LRK = 5;
 constexpr int LRS = WAVE * LRK;                 // rows per strip
-constexpr int LR_QMAX = 13;                     // strips
-constexpr int LR_MMAX = LRS * LR_QMAX - 1;      // 4159
-constexpr int LR_NMAX = 24000;
+constexpr int LR_QMAX = 40;                     // strips
+constexpr int LR_MMAX = LRS * LR_QMAX - 1;      // 12799 (BASELINE's stress shape: 10 kb consensus x 20 kb window)
+constexpr int LR_NMAX = 32000;                  // columns < 2^15 (join key), V' = score + row <= 2m < 2^16 (scaled by 2^15 in an int)
 constexpr int LR_CSHIFT = 15;                   // M pass runs on scores << 15; key = (sum' << 15) | (CINV - col)
 constexpr int LR_CINV = (1 << LR_CSHIFT) - 1;
 constexpr int LR_MASKW = (LR_MMAX + LR_NMAX + 127) / 64;
@@ -532,8 +532,28 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (bit-vector distance, myers_kernel.hpp; the plain strip recurrence lr_nw_distance gives the same numbers)
-    const int dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
-    const int dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
+    // (bit-vector distance, myers_kernel.hpp; pattern = the shorter string, the distance is symmetric; beyond the rows
+    //  of one pass the pattern is cut into strips whose boundary deltas park in the boundary-row arrays)
+    int dF, dR;
+    if (min(m, n) <= MYERS_ROWS) {
+      if (m <= n) {
+        dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
+        dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
+      } else {
+        dF = rfl(myers_nw_auto(ML, S.ref, n, S.cons, m, lane));
+        dR = rfl(myers_nw_auto(ML, S.ref, n, S.rcons, m, lane));
+      }
+    } else {
+      int8_t* hb0 = reinterpret_cast<int8_t*>(bnd0);
+      int8_t* hb1 = reinterpret_cast<int8_t*>(bnd1);
+      if (m <= n) {
+        dF = rfl(myers_nw_big(S.cons, m, S.ref, n, hb0, hb1, lane));
+        dR = rfl(myers_nw_big(S.rcons, m, S.ref, n, hb0, hb1, lane));
+      } else {
+        dF = rfl(myers_nw_big(S.ref, n, S.cons, m, hb0, hb1, lane));
+        dR = rfl(myers_nw_big(S.ref, n, S.rcons, m, hb0, hb1, lane));
+      }
+    }
     if (dR < dF) {   // consensus = revc
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];

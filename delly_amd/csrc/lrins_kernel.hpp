@@ -137,8 +137,26 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
-    const int dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
+    int dF, dR;   // (pattern = the shorter string; strips beyond MYERS_ROWS rows, see lr_kernel.hpp)
+    if (min(m, n) <= MYERS_ROWS) {
+      if (m <= n) {
+        dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
+        dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
+      } else {
+        dF = rfl(myers_nw_auto(ML, S.ref, n, S.cons, m, lane));
+        dR = rfl(myers_nw_auto(ML, S.ref, n, S.rcons, m, lane));
+      }
+    } else {
+      int8_t* hb0 = reinterpret_cast<int8_t*>(bnd);
+      int8_t* hb1 = reinterpret_cast<int8_t*>(bnd + bnd_stride);
+      if (m <= n) {
+        dF = rfl(myers_nw_big(S.cons, m, S.ref, n, hb0, hb1, lane));
+        dR = rfl(myers_nw_big(S.rcons, m, S.ref, n, hb0, hb1, lane));
+      } else {
+        dF = rfl(myers_nw_big(S.ref, n, S.cons, m, hb0, hb1, lane));
+        dR = rfl(myers_nw_big(S.ref, n, S.rcons, m, hb0, hb1, lane));
+      }
+    }
     if (dR < dF) {
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];

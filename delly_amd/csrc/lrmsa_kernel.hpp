@@ -21,8 +21,10 @@
 
 namespace dh {
 
-constexpr int LM_NR = 16;                 // reads per junction (delly lr: maxReadPerSV = 15, src/tegua.h:241)
-constexpr int LM_STACK = 12;              // Hirschberg sub-problems in flight
+constexpr int LM_NR = 32;                 // reads per junction (delly lr: maxReadPerSV = 15 by default, -p; src/tegua.h:241)
+constexpr int LM_STACK = 24;              // Hirschberg sub-problems in flight (depth <= log2 of the longer side + 1)
+constexpr int LM_RBITS = 15;              // row index bits of the location keys: target rows <= 32766, E < 2^17
+constexpr int LM_RMASK = (1 << LM_RBITS) - 1;
 
 struct LrMsaArgs {
   const dellyhip_junction* junc;
@@ -90,8 +92,8 @@ __device__ __forceinline__ uint32_t iupac_partners(int x) {
 // query letters qp[c*qstep].  E[r][0] = r, E[0][c] = c.  DIRS: edlib op code per cell
 // (preference INSERT > DELETE > diagonal) into `dirs`; bout: last slot of the strip per column.
 struct LmKeys {
-  unsigned kf;   // min over rows r0..tlen of (E[r][qlen] << 13) | r           (first optimal end)
-  unsigned kl;   // min over rows r0..tlen of (E[r][qlen] << 13) | (8191 - r)  (last optimal end)
+  unsigned kf;   // min over rows r0..tlen of (E[r][qlen] << 15) | r            (first optimal end)
+  unsigned kl;   // min over rows r0..tlen of (E[r][qlen] << 15) | (32767 - r)  (last optimal end)
 };
 
 // mode bits of lm_pass
@@ -200,8 +202,8 @@ __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen,
     for (int i = 0; i < K; ++i) {
       const int r = q * LRS + lane * K + i - pad;
       if (r >= r0 && r <= tlen) {
-        kf = min(kf, ((unsigned)colq[i] << 13) | (unsigned)r);
-        kl = min(kl, ((unsigned)colq[i] << 13) | (unsigned)(8191 - r));
+        kf = min(kf, ((unsigned)colq[i] << LM_RBITS) | (unsigned)r);
+        kl = min(kl, ((unsigned)colq[i] << LM_RBITS) | (unsigned)(LM_RMASK - r));
       }
     }
 #pragma unroll
@@ -553,8 +555,12 @@ __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tl
 // plain (traceback-regime) NW path of t[0..tlen) vs q[0..qlen): direction strips + windowed
 // run-length traceback; ops appended to `ops` (forward order) at position pos; returns new pos
 __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const uint8_t* qy, int qlen, int mode, int32_t* bndA,
-                                             int32_t* bndB, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                             int32_t* bndB, uint32_t* dirs, uint64_t dirs_cap, uint8_t* tmp,
                                              uint8_t* ops, int pos, int lane) {
+  // code words of THIS rectangle: strips of lr_strip_words(qlen) words.  The traceback regime bounds the rectangle
+  // (edlib.cpp:1189: < 1 MiB of alignment data), so the direction area is sized by lm_dirs_words() on the host, not by
+  // the product of the longest target and the longest query.
+  const uint64_t strip_words = lr_strip_words(qlen);
   const int Q = tlen / LRS + 1;
   int rr = tlen, cc = qlen;
   int tl;
@@ -564,7 +570,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
   const int bv_nl1 = (tlen >= 1) ? (tlen - 1) / (32 * bv_nw) + 2 : 2;
   const uint64_t bv_words = (uint64_t)(((qlen + bv_nl1 - 2 + 15) >> 4) * 16) * bv_nw * bv_nl1;
   if ((mode & LM_EQ) && (mode & LM_EQFAST) && tlen >= 1 && qlen >= 1 && tlen <= MYERS_ROWS &&
-      2 * bv_words <= (uint64_t)Q * strip_words) {
+      2 * bv_words <= dirs_cap) {
     uint32_t* planeH = dirs;
     uint32_t* planeV = dirs + bv_words;
     if (bv_nw == 1) lm_dirs_myers<1>(t, tlen, qy, qlen, planeH, planeV, lane);
@@ -595,8 +601,31 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
   return pos + tl;
 }
 
+// words of direction codes the traceback-regime rectangles of lm_nw_path can need for targets <= tcap and queries <= qcap:
+// max over the query block count of (tl/320 + 1) strips x lr_strip_words(ql), tl the longest target edlib still traces
+// directly (edlib.cpp:1185-1191: (2*8 + 4) * blocks * tl + 2*4*tl < 2^20)
+inline uint64_t lm_dirs_words(int tcap, int qcap) {
+  uint64_t best = (uint64_t)lr_strip_words(64) * 2;
+  for (long long blocks = 1; blocks <= (qcap + 63) / 64; ++blocks) {
+    long long tl = (1024 * 1024 - 1) / (20 * blocks + 8);
+    if (tl > tcap) tl = tcap;
+    if (tl < 1) break;
+    const int ql = (int)std::min<long long>(blocks * 64, qcap);
+    const uint64_t w = (uint64_t)(tl / LRS + 1) * lr_strip_words(ql);
+    if (w > best) best = w;
+    // the bit-plane flavour of the same rectangle (lm_plain_path): two planes of bv_words
+    const long long tb = std::min<long long>(tl, MYERS_ROWS);
+    const int nw = (tb <= WAVE * 32) ? 1 : ((tb <= WAVE * 64) ? 2 : 3);
+    const long long nl1 = (tb - 1) / (32 * nw) + 2;
+    const uint64_t bv = 2ull * (uint64_t)(((ql + nl1 - 2 + 15) >> 4) * 16) * nw * nl1;
+    if (bv > best) best = bv;
+  }
+  return best + 64;
+}
+
 // edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment  (obtainAlignment,
 // edlib.cpp:1163-1389).  Returns the op count, ops[] in forward order; -1 on overflow.
+// (`strip_words` = capacity of `dirs` in words, lm_dirs_words())
 __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int mode, int32_t* bnd,
                                           int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                           uint8_t* ops, int ops_cap, int lane) {
@@ -623,6 +652,7 @@ __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const u
     const long long blocks = (ql + 63) / 64;
     const long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
     if (sz < 1024 * 1024) {
+      if ((uint64_t)(tl / LRS + 1) * lr_strip_words(ql) > strip_words) return -1;   // (direction area: sized by lm_dirs_words)
       pos = lm_plain_path(target + t0, tl, query + q0, ql, mode, bndA, bndB, dirs, strip_words, tmp, ops, pos, lane);
       continue;
     }
@@ -676,9 +706,9 @@ __device__ __forceinline__ void lm_locate(const uint8_t* tp, int tstep, int tn, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  ed = (int)(kf >> 13);
-  first = (int)(kf & 8191u);
-  last = 8191 - (int)(kl & 8191u);
+  ed = (int)(kf >> LM_RBITS);
+  first = (int)(kf & (unsigned)LM_RMASK);
+  last = LM_RMASK - (int)(kl & (unsigned)LM_RMASK);
 }
 
 __device__ __forceinline__ int lm_fill_inserts(uint8_t* ops, int qn, int lane) {
@@ -688,7 +718,7 @@ __device__ __forceinline__ int lm_fill_inserts(uint8_t* ops, int qn, int lane) {
   return qn;
 }
 
-// edlibAlign(Q, T, HW, {DISTANCE | LOC | PATH}) (edlib.cpp:139-300); tn >= 1, qn >= 1, tn <= 8190
+// edlibAlign(Q, T, HW, {DISTANCE | LOC | PATH}) (edlib.cpp:139-300); tn >= 1, qn >= 1, tn <= LM_RMASK - 1
 __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* Qy, int qn, int mode, bool loc, bool path,
                                        int32_t* bnd, int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                        uint8_t* ops, int ops_cap, int lane) {

@@ -15,7 +15,7 @@ namespace dh {
 constexpr int WFA_KMER = 7;                 // DELLY_KMER, src/tags.h:19
 constexpr int WFA_KTAB = 65536;             // std::pow(4, DELLY_KMER + 1)
 constexpr uint32_t WFA_DUP = 0xffffffffu;   // DELLY_DUPLICATE, src/tags.h:15
-constexpr int WFA_ACAP = 8192;              // alignment columns / superstring capacity (row keys hold 13 bits)
+constexpr int WFA_ACAP_MAX = LM_RMASK - 1;  // alignment columns / superstring capacity (row keys hold LM_RBITS bits); per batch: LrWfaArgs::acap
 constexpr int WFA_PCAP = 4096;              // reference anchor (prefix / suffix) capacity
 
 struct LrWfaArgs {
@@ -39,6 +39,7 @@ struct LrWfaArgs {
   uint8_t* ws;
   uint64_t ws_stride;
   int32_t ncap;              // read length capacity
+  int32_t acap;              // alignment columns / superstring capacity of this batch (<= WFA_ACAP_MAX)
   uint64_t off_alnB, off_astr, off_bnd, off_ops, off_tmp, off_cons, off_dirs, off_tabI, off_tabJ, off_diag, off_supA, off_supB,
       off_pre, off_suf, off_edit;   // alnA at 0
   uint64_t strip_words;
@@ -134,8 +135,8 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
   uint8_t* pre = ws + A.off_pre;
   uint8_t* suf = ws + A.off_suf;
   int32_t* E = reinterpret_cast<int32_t*>(ws + A.off_edit);
-  const int bnd_stride = max(A.ncap, WFA_ACAP) + 128;
-  const int acap = WFA_ACAP;
+  const int bnd_stride = max(A.ncap, A.acap) + 128;
+  const int acap = A.acap;
   const int ops_cap = 2 * max(acap, A.ncap) + 32;
   const uint8_t* blob = A.seq_blob;
   if (N >= 1) {
@@ -148,7 +149,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       }
       __syncthreads();
       for (int r = 0; r < N; ++r)
-        if (L.rlen[r] > A.ncap || L.rlen[r] > MYERS_ROWS || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = DELLYHIP_E_LIMIT;
+        if (L.rlen[r] > A.ncap || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = DELLYHIP_E_LIMIT;
     }
     // reference anchors (src/assemble.h:855-856)
     int pn = 0, sn = 0;
@@ -195,7 +196,10 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           uint32_t lI = min(seqlen, (uint32_t)lenI - oI), lJ = min(seqlen, (uint32_t)lenJ - oJ);   // substr clamps
           int d;
           if (lI == 0 || lJ == 0) d = (int)max(lI, lJ);
-          else d = rfl(myers_nw(sI + oI, (int)lI, sJ + oJ, (int)lJ, lane));
+          else {   // (strings beyond the rows of one bit-vector pass: strips, boundary deltas parked in the bnd area)
+            int8_t* hb = reinterpret_cast<int8_t*>(bnd);
+            d = rfl(myers_nw_big(sI + oI, (int)lI, sJ + oJ, (int)lJ, hb, hb + 2 * bnd_stride, lane));
+          }
           const int score = (d * 1000) / (int)max(lI, lJ);
           if (lane == 0) {
             E[a * LM_NR + b] = score;

@@ -40,8 +40,13 @@ __device__ __noinline__ uint32_t myers_eq_slow(const uint8_t* pattern, int pn, i
 
 // Returns the NW edit distance of pattern[0..pn) vs text[0..tn) (both > 0, pn <= 64*32*NWORDS).
 // pattern / text: any address space (LDS or global); exact byte comparison.
+// Strips: a pattern longer than 64*32*NWORDS rows is cut into strips that are swept one after the other over the
+// whole text (myers_nw_big).  `row_base` = rows above this strip (D[row_base + i][0] = row_base + i); hin_buf[c]
+// (c = 1..tn) = the horizontal delta D[row_base][c] - D[row_base][c-1] leaving the strip above (nullptr: row 0 of the
+// matrix, +1 everywhere); hout_buf[c] receives the delta leaving this strip's last row (the strip must be full).
 template <int NWORDS>
-__device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
+__device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane,
+                                              int row_base = 0, const int8_t* hin_buf = nullptr, int8_t* hout_buf = nullptr) {
   MyersWord W[NWORDS];
   uint32_t Pv[NWORDS], Mv[NWORDS];
   const int row0 = lane * 32 * NWORDS;   // zero-based first row of this lane
@@ -62,7 +67,7 @@ __device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, co
     Mv[w] = 0;
   }
   // score at the bottom row of this lane's last word, column 0
-  int score = row0 + 32 * NWORDS;
+  int score = row_base + row0 + 32 * NWORDS;
   const int lastlane = (pn - 1) / (32 * NWORDS);
   const int T = tn + lastlane;
   const int nblk = (T + 15) >> 4;
@@ -70,14 +75,16 @@ __device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, co
   int b = NOMATCH;
   int c = -lane;
   int fin = 0;
+  int outv = 0;
   for (int blk = 0; blk < nblk; ++blk) {
     const int ci = blk * 16 + (lane & 15);
     const int chunk = (ci < tn) ? (int)text[ci] : NOMATCH;
+    const int bchunk = (hin_buf && ci + 1 <= tn) ? (int)hin_buf[ci + 1] : 1;   // lane 0's column at step 16*blk + f is 16*blk + f + 1
 #pragma unroll 1
     for (int f = 0; f < 16; ++f) {   // rolled: ~60 instructions per step, the body must stay I-cache resident
       const int newc = __builtin_amdgcn_readlane(chunk, f);
       b = dpp_from_prev(b, newc);
-      const int hin0 = dpp_from_prev(hcarry, 1);
+      const int hin0 = dpp_from_prev(hcarry, __builtin_amdgcn_readlane(bchunk, f));
       c += 1;
       if ((unsigned)(c - 1) < (unsigned)tn) {
         const int code = myers_code(b);
@@ -127,6 +134,14 @@ __device__ __noinline__ int myers_nw_distance(const uint8_t* pattern, int pn, co
           fin = s;
         }
       }
+      if (hout_buf) {   // the last lane's delta of column 16*blk + f - 62 parks in lane f
+        const int sv = __builtin_amdgcn_readlane(hcarry, 63);
+        outv = (lane == f) ? sv : outv;
+      }
+    }
+    if (hout_buf) {
+      const int col = blk * 16 + lane - 62;
+      if (lane < 16 && col >= 1 && col <= tn) hout_buf[col] = (int8_t)outv;
     }
   }
   return __shfl(fin, lastlane);
@@ -136,6 +151,23 @@ __device__ __forceinline__ int myers_nw(const uint8_t* pattern, int pn, const ui
   if (pn <= WAVE * 32) return myers_nw_distance<1>(pattern, pn, text, tn, lane);
   if (pn <= WAVE * 64) return myers_nw_distance<2>(pattern, pn, text, tn, lane);
   return myers_nw_distance<3>(pattern, pn, text, tn, lane);
+}
+
+// any pattern length: strips of MYERS_ROWS rows; hb0 / hb1: two byte arrays of tn + 16 entries (global memory)
+__device__ __forceinline__ int myers_nw_big(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int8_t* hb0, int8_t* hb1,
+                                            int lane) {
+  if (pn <= MYERS_ROWS) return myers_nw(pattern, pn, text, tn, lane);
+  const int S = (pn + MYERS_ROWS - 1) / MYERS_ROWS;
+  int d = 0;
+  for (int q = 0; q < S; ++q) {
+    const int base = q * MYERS_ROWS;
+    const int8_t* hin = (q > 0) ? ((q & 1) ? hb0 : hb1) : nullptr;
+    int8_t* hout = (q + 1 < S) ? ((q & 1) ? hb1 : hb0) : nullptr;
+    d = myers_nw_distance<MYERS_NW>(pattern + base, min(MYERS_ROWS, pn - base), text, tn, lane, base, hin, hout);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  return d;
 }
 
 // ---- branch-free variant for the batched long-read genotyping distances ---------------------------------
@@ -296,6 +328,8 @@ struct PairArgs {
   int32_t n_items;
   int32_t nrmax;               // row stride of a junction's matrix
   int32_t* edit;               // edit[j*nrmax*nrmax + a*nrmax + b]
+  int8_t* hbuf;                // per block: 2 x hbuf_half bytes for the strip passes of pairs with both reads > MYERS_ROWS
+  uint64_t hbuf_half;          // (0: no such pair in the batch)
 };
 
 __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
@@ -324,7 +358,12 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
     const int la = (int)(A.seq_off[J.seq_first + a + 1] - oa), lb = (int)(A.seq_off[J.seq_first + bb + 1] - ob);
     int d;
     if (la == 0 || lb == 0) d = max(la, lb);                 // edlib.cpp:160-166
-    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = -1;     // beyond the kernel limit (flagged by the consumer)
+    else if (la > MYERS_ROWS && lb > MYERS_ROWS) {           // strips of 6144 rows (pattern = the shorter read)
+      int8_t* hb = A.hbuf + (size_t)blockIdx.x * 2 * A.hbuf_half;
+      if (!A.hbuf || (uint64_t)max(la, lb) + 16 > A.hbuf_half) d = -1;  // (cannot happen: the host sizes hbuf from the longest read)
+      else if (la <= lb) d = myers_nw_big(A.seq_blob + oa, la, A.seq_blob + ob, lb, hb, hb + A.hbuf_half, lane);
+      else d = myers_nw_big(A.seq_blob + ob, lb, A.seq_blob + oa, la, hb, hb + A.hbuf_half, lane);
+    }
     else if (la <= lb || lb > MYERS_ROWS) d = myers_nw_auto(L, A.seq_blob + oa, la, A.seq_blob + ob, lb, lane);   // (the blob is padded)
     else d = myers_nw_auto(L, A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
     if (lane == 0) {
@@ -342,6 +381,8 @@ struct NwArgs {
   int32_t* dist;
   uint64_t n_jobs;
   uint32_t* next;   // work counter, zeroed before the launch: wavefronts pull job indices (pair lengths vary)
+  int8_t* hbuf;     // per block: 2 x hbuf_half bytes for pairs with both strings > MYERS_ROWS (strip passes); 0 = none
+  uint64_t hbuf_half;
 };
 
 __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
@@ -364,8 +405,12 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
     const uint8_t* b = A.blob + J.target_off;
     int d;
     if (la == 0 || lb == 0) d = max(la, lb);                              // edlib.cpp:157-163
-    else if (la > MYERS_ROWS && lb > MYERS_ROWS) d = DELLYHIP_E_LIMIT;
-    else {
+    else if (la > MYERS_ROWS && lb > MYERS_ROWS) {
+      int8_t* hb = A.hbuf + (size_t)blockIdx.x * 2 * A.hbuf_half;
+      if (!A.hbuf || (uint64_t)max(la, lb) + 16 > A.hbuf_half) d = DELLYHIP_E_LIMIT;
+      else if (la <= lb) d = myers_nw_big(a, la, b, lb, hb, hb + A.hbuf_half, lane);
+      else d = myers_nw_big(b, lb, a, la, hb, hb + A.hbuf_half, lane);
+    } else {
       const uint8_t* pat = (la <= lb) ? a : b;                             // pattern = the shorter string (symmetric)
       const uint8_t* txt = (la <= lb) ? b : a;
       const int pn = min(la, lb), tn = max(la, lb);

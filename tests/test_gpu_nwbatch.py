@@ -12,10 +12,9 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "nw_jobs.npz")
 
 
 def _check(got, want, jobs):
-    big = np.minimum(jobs["query_len"], jobs["target_len"]) > 6144
-    assert (got[big] == abi.E_LIMIT).all()
-    bad = np.nonzero(got[~big] != want[~big])[0]
-    assert bad.size == 0, (bad[:8], got[~big][bad[:8]], want[~big][bad[:8]])
+    # (pairs with both strings beyond one bit-vector pass -- 6144 rows -- run in strips since round 2: no size limit)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:8], got[bad[:8]], want[bad[:8]])
 
 
 @pytest.mark.parametrize("label", ["plain", "weird"])
@@ -24,8 +23,9 @@ def test_nw_batch_reproduces_reference_distances(gpu_ctx, label):
     jobs, blob, want = z[label + "_jobs"], z[label + "_blob"], z[label + "_dist"]
     got = gpu_ctx.edit_distance_nw_batch(jobs, blob)
     _check(got, want, jobs)
-    if label == "weird":
-        assert (got == abi.E_LIMIT).sum() > 0
+    if label == "weird":   # the set holds pairs with both strings > 6144 bytes
+        assert (np.minimum(jobs["query_len"], jobs["target_len"]) > 6144).sum() > 0
+    assert (got != abi.E_LIMIT).all()
 
 
 def test_nw_batch_vs_port(gpu_ctx, port):
