@@ -161,8 +161,9 @@ struct dellyhip_batch {
   DevBuf<int32_t> ref_len;
   // MSA stage
   DevBuf<uint8_t> msa_ws;
-  uint64_t msa_ws_stride = 0;
-  int msa_nmax = 2;
+  DevBuf<uint8_t> msa_big_ws;        // msa_big instance: junctions beyond the standard instance's shapes
+  dh::MsaPlan msa_plan;
+  int msa_big_grid = 0;
   // timing
   std::vector<hipEvent_t> ev;        // 4 events per launch since the last kernel_ms()
   hipEvent_t last = nullptr;
@@ -600,6 +601,28 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   return 0;
 }
 
+// consensus lengths known (h_cons_len, after an MSA stage): window lengths, routing to the short-read / strip kernels,
+// strip-kernel workspaces, K bins
+int route_after_msa(dellyhip_ctx* c, dellyhip_batch* b) {
+  int rc;
+  int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
+  b->h_win_len.resize(b->n);
+  for (int i = 0; i < b->n; ++i) {
+    const int m = b->h_cons_len[i];
+    const int w = host_window_len(c->params, b->h_junc[i], m, c->chr_len);
+    b->h_win_len[i] = w;
+    if (is_lr_shape(c->params, b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
+      if (b->h_junc[i].svt == 4) { lri_m = std::max(lri_m, m); lri_n = std::max(lri_n, w); ++lri_cnt; }
+      else { lr_m = std::max(lr_m, m); lr_n = std::max(lr_n, w); ++lr_cnt; }
+    }
+  }
+  b->lr_blocks = 0;
+  b->lri_blocks = 0;
+  if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return rc;
+  if (lri_cnt && (rc = setup_lri_workspace(c, b, lri_m, lri_n, lri_cnt))) return rc;
+  return build_bins(b, c->params);
+}
+
 }  // namespace
 
 // long-read loop, small inversions (src/assemble.h:850-853): the consensus is restored, consBp shifted
@@ -737,7 +760,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->small_inv.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->small_inv.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -799,6 +822,20 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     const long win = std::min<long>(dh::LR_NMAX, 2L * acap + std::max(c->params.indelsize, 0));
     b->out_allele_cap = (int)((acap + win + 8 + 15) & ~15L);
     b->out_aln_cap = 2 * (int)((acap + (long)dh::LR_NMAX + 8 + 15) & ~15L);
+  }
+  if (with_msa == 1) {
+    // msa(): a consensus is at most the alignment's columns; reads of one junction overlap the breakpoint, so twice the
+    // longest read bounds it in practice (longer: DELLYHIP_E_LIMIT for that junction).  Batches of <= 128 bp reads keep
+    // the short-read slot sizes.
+    b->msa_plan = dh::msa_prepare(b->h_junc, seq_off);
+    const int cc = std::min<int>(dh::msa_big::LCAP, (2 * b->msa_plan.maxlen + 64 + 15) & ~15);
+    if (cc > dh::OUT_CONS_CAP) {
+      const long win2 = std::min<long>(dh::LR_NMAX, 2L * cc + std::max(c->params.indelsize, 0));   // contiguous window (src/split.h:116)
+      const long winmax = std::min<long>(dh::LR_NMAX, std::max<long>(win2, 4L * cc));                // two windows (:117)
+      b->out_cons_cap = cc;
+      b->out_allele_cap = (int)((cc + win2 + 8 + 15) & ~15L);
+      b->out_aln_cap = 2 * (int)((cc + winmax + 8 + 15) & ~15L);
+    }
   }
   if (lr_cnt || lri_cnt) {
     const int mm = std::max(lr_m, lri_m), nn = std::max(lr_n, lri_n);
@@ -897,8 +934,12 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         b->wfa.ws = b->wfa_ws.p;
       }
     } else {
-      if ((rc = dh::msa_prepare(b->h_junc, seq_off, b->msa_ws_stride, &b->msa_nmax))) return bail(fail(rc, "msa_prepare"));
-      if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, b->msa_ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+      const dh::MsaPlan& mp = b->msa_plan;
+      if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+      // msa_big: as many resident wavefronts as junctions are expected there; a few stand by for the unpredictable
+      // case (a node of the standard instance growing beyond its 512 columns)
+      b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
+      if ((rc = b->msa_big_ws.alloc(std::max<uint64_t>(1, mp.big_ws_stride * (uint64_t)b->msa_big_grid)))) return bail(rc);
     }
   }
   *out = b;
@@ -992,23 +1033,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
         HIPCHK(hipMemcpy(b->small_inv.p, si.data(), si.size() * sizeof(SmallInv), hipMemcpyHostToDevice));
       }
     }
-    // consensus lengths known: window lengths, routing, strip-kernel workspace
-    int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
-    b->h_win_len.resize(b->n);
-    for (int i = 0; i < b->n; ++i) {
-      const int m = b->h_cons_len[i];
-      const int w = host_window_len(c->params, b->h_junc[i], m, c->chr_len);
-      b->h_win_len[i] = w;
-      if (is_lr_shape(c->params, b->h_junc[i], m, w) && m <= dh::LR_MMAX && w <= dh::LR_NMAX) {
-        if (b->h_junc[i].svt == 4) { lri_m = std::max(lri_m, m); lri_n = std::max(lri_n, w); ++lri_cnt; }
-        else { lr_m = std::max(lr_m, m); lr_n = std::max(lr_n, w); ++lr_cnt; }
-      }
-    }
-    b->lr_blocks = 0;
-    b->lri_blocks = 0;
-    if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return rc;
-    if (lri_cnt && (rc = setup_lri_workspace(c, b, lri_m, lri_n, lri_cnt))) return rc;
-    if ((rc = build_bins(b, c->params))) return rc;
+    if ((rc = route_after_msa(c, b))) return rc;
   } else if (b->with_msa) {
     if ((rc = ensure_scratch(c))) return rc;
     HIPCHK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(int32_t), s));
@@ -1022,18 +1047,22 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.out_stride = b->out_stride;
     ma.cons_len = b->cons_len.p;
     ma.ws = b->msa_ws.p;
-    ma.ws_stride = b->msa_ws_stride;
+    ma.ws_stride = b->msa_plan.ws_stride;
+    ma.out_cons_cap = b->out_cons_cap;
+    ma.big_counter = c->counters.p + 9;
     ma.n_work = b->n;
     ma.work_counter = c->counters.p;
     ma.defer_counter = c->counters.p + 8;
     ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
     int grid = std::min(b->n, c->n_cu * 8);
-    if ((rc = dh::msa_launch(ma, grid, b->msa_nmax, s))) return fail(rc, "msa_launch");
+    if ((rc = dh::msa_launch(ma, grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
+                             b->msa_plan.big_nmax)))
+      return fail(rc, "msa_launch");
     HIPCHK(hipGetLastError());
     // consensus lengths decide the K bin of the split kernel
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if ((rc = build_bins(b, c->params))) return rc;
+    if ((rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
   }
   HIPCHK(hipEventRecord(e3[1], s));
   if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
