@@ -37,7 +37,9 @@ SIDE_PLAN = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
              ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
              ("ins_svt4", 5000, 5000, dict(mode="ins")),
              ("lr_c4_align_consensus", 2048, 128, dict(mode="lr", sub_rate=0.01)),
-             ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)))
+             ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)),
+             # INS 800 bp, 15 reads of ~3.8 kb at 6 % error: msaWfa + alignConsensus (splitAlign)
+             ("lr_ins_msawfa_n15", 512, 64, dict(mode="lrins", n_reads=15, sub_rate=0.06)))
 
 
 class _DevPtr:
@@ -112,6 +114,28 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     out = {}
     want = (lambda name: True) if not only else (lambda name: name in only)
     plan = tuple(x for x in SIDE_PLAN if want(x[0]))
+    # SURVEY.md 8d "GPU time includes H2D/D2H and host marshalling": the same 10 000 C2 junctions through the host-buffer
+    # entry point dellyhip_align_consensus_batch -- upload of records + consensus bytes, host binning, kernels,
+    # device-side compaction, download of records + consensus / allele bytes (chromosome resident).  Never `value`.
+    try:
+        if not want("u_c2_host_inclusive"):
+            raise KeyError("skipped")
+        bb = synth.make_batch(10000, mode="c2")
+        ctx.set_chromosomes(bb.chroms)
+        ctx.refine(bb)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res, blob = ctx.refine(bb)
+        dt = (time.perf_counter() - t0) / reps
+        out["u_c2_host_inclusive"] = {"junctions": bb.n, "junctions_per_s": bb.n / dt, "ms_per_call": dt * 1e3,
+                                      "refined_ok": int(res["ok"].sum()), "bytes_up": int(bb.seq_blob.size + bb.junctions.nbytes + bb.seq_off.nbytes),
+                                      "bytes_down": int(res.nbytes + blob.size),
+                                      "note": "dellyhip_align_consensus_batch from host buffers: H2D + binning + kernels + compaction + D2H"}
+    except KeyError:
+        pass
+    except Exception as e:  # side figure only
+        out["u_c2_host_inclusive"] = {"error": repr(e)}
     # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
     # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
     try:
@@ -150,7 +174,7 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         out["u_c2_two_batches_in_flight"] = {"error": repr(e)}
     for name, n, ncpu, kw in plan:
         b = synth.make_batch(n, **kw)
-        lr = kw["mode"] == "lr"
+        lr = kw["mode"].startswith("lr")
         params = abi.params_lr(realign=True) if lr else abi.params_sr()
         if lr and name == "lr_c4_align_consensus":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
             ctx = refine.Context(params=params, device=device)
@@ -280,6 +304,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
+                         "overlapping step k) on ONE GPU with a one-rank communicator")
     args = ap.parse_args()
 
     import torch
@@ -305,26 +332,54 @@ def main():
     n = args.junctions
     batch = synth.make_batch(n, mode="c2", first=rank * n)  # weak scaling: shard by junction index
     ctx = refine.Context(device=local)
-    ctx.set_chromosomes(batch.chroms)
-    rb = ctx.upload(batch)
-    side = torch.cuda.Stream(device=local)  # kernels and the RCCL gather are ordered on this stream
+    side = torch.cuda.Stream(device=local)  # the kernels are launched on this stream
     stream = side.cuda_stream
-    ptr, nbytes = rb.device_results()
-    res_t = gathered = None
-    if world > 1:
-        res_t = torch.as_tensor(_DevPtr(ptr, nbytes), device="cuda:%d" % local)
-        gathered = torch.empty(world * nbytes, dtype=torch.uint8, device="cuda:%d" % local)
+    comm = None
+    gather_kind = "none (one GPU: results stay in HBM)"
+    rbs = []
+    multi = world > 1 or args.force_comm
+    if not multi:
+        ctx.set_chromosomes(batch.chroms)
+        rbs.append(ctx.upload(batch))
+    else:
+        # N > 1: every rank keeps TWO resident batches of n junctions and alternates; the results of the batch refined in
+        # the previous step are gathered to rank 0's HBM -- dellyhip_gather_results_device in the host library: RCCL called
+        # directly (ncclAllGather of the counts, grouped ncclSend / ncclRecv of the records + consensus / allele bytes,
+        # SURVEY.md 8e) -- while the kernels of the current step run on their own stream.  One run + one gather per step.
+        # The 128-byte RCCL id travels through torch.distributed.
+        b2 = synth.make_batch(n, mode="c2", first=(world + rank) * n)
+        chrom = __import__("numpy").concatenate([batch.chroms[0], b2.chroms[0]])
+        j2 = b2.junctions.copy()
+        j2["sv_start"] += batch.chroms[0].size
+        j2["sv_end"] += batch.chroms[0].size
+        b2 = synth.Batch([chrom], j2, b2.seq_blob, b2.seq_off, b2.with_msa, b2.truth)
+        ctx.set_chromosomes([chrom])
+        rbs = [ctx.upload(batch), ctx.upload(b2)]
+        ids = [refine.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = refine.Comm(ctx, rank, world, ids[0])
+        gather_kind = ("dellyhip_gather_results_device: RCCL ncclSend/ncclRecv of records + consensus/allele bytes to rank 0, "
+                       "gather of step k-1 overlapping the kernels of step k")
+    rb = rbs[0]
+    gathered_n = [0, 0]
+    k_step = [0]
 
     def step():
+        cur = rbs[k_step[0] % len(rbs)]
         with torch.cuda.stream(side):
-            rb.run(stream)
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, res_t)
+            cur.run(stream)
+        if comm is not None:
+            prev = rbs[(k_step[0] + 1) % 2]
+            if k_step[0] > 0:
+                gathered_n[0], gathered_n[1] = prev.gather_device(comm, 0)   # (waits for prev's kernels, not for cur's)
+        k_step[0] += 1
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    rb.kernel_ms()  # reset the kernel timers
+    for x in rbs:
+        x.kernel_ms()  # reset the kernel timers
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -338,8 +393,14 @@ def main():
     dt = time.perf_counter() - t0
     ms_split, ms_msa, launches = rb.kernel_ms()
     ms_dp = rb.dp_kernel_ms()
+    for other in rbs[1:]:
+        other.sync()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -367,7 +428,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU, 150 bp consensus x 1 kb "
                                    "ref window, alignConsensus (longNeedle + split detection), bit-exact" % n,
-                       "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world},
+                       "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
+                       "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if comm is not None else None),
+                       "ms_per_step_per_rank": per_rank_ms, "kernels_ms_per_step_rank0": ms_split},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "split_quad_kernel<5,3> (packed int16 longNeedle DP, 4 junctions per wavefront)",
@@ -384,11 +447,14 @@ def main():
         if world == 1 and not args.no_extras:
             rb.free()
             rb = None
+            rbs = []
             out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline,
                                                 only=set(filter(None, args.only_extras.split(','))) or None)
         print(json.dumps(out), flush=True)
-    if rb is not None:
-        rb.free()
+    for x in rbs:
+        x.free()
+    if comm is not None:
+        comm.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdellyhip.so")
 SOURCES = ["dellyhip.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + ["../../include/dellyhip.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + ["../../include/dellyhip.h"]
 
 
 def _stale():
@@ -24,7 +24,7 @@ def build_lib(force=False, verbose=False, out=None, extra_flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-Wno-unused-value",  # profile-Gotoh scores must round like the reference
-           "-o", out or LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", out or LIB] + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]   # (dlopen of RCCL at the first multi-GPU gather)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -24,6 +24,7 @@
 #include "lrwfa_kernel.hpp"
 #include "classify_kernel.hpp"
 #include "probes_kernel.hpp"
+#include "comm.hpp"
 
 namespace {
 
@@ -295,7 +296,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     HIPCHK(hipGetLastError());
   }
   if (!any_bin && b->mid) HIPCHK(hipEventRecord(b->mid, s));  // keeps the per-launch event quartet complete
-  if (b->ins_count > 0 && !direct) {
+  if (b->ins_count > 0) {   // (direct mode: dellyhip_split_align)
     a.work_list = b->work.p + b->ins_first;
     a.n_work = b->ins_count;
     const int rounds = (b->ins_count + c->scratch_blocks - 1) / c->scratch_blocks;
@@ -505,8 +506,8 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     int kk = (m + 1 + dh::WAVE - 1) / dh::WAVE;
     kk = std::max(1, std::min(kk, dh::KMAX));
     const dellyhip_junction& J = b->h_junc[i];
-    if (!direct && J.svt == 4) {  // splitAlign path: own kernels, one junction per wavefront
-      if (!b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
+    if (J.svt == 4) {  // splitAlign path: own kernels, one junction per wavefront
+      if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
           b->lri_blocks > 0)
         lriv.push_back(i);
       else ins.push_back(i);
@@ -1129,6 +1130,40 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_spli
   return 0;
 }
 
+// device-side compaction of a run batch: b->blob_off[i] = bytes of junctions < i, b->blob_compact = the used bytes
+// back to back; *used = total.  The stream is synchronised on return.
+static int compact_batch(dellyhip_ctx* c, dellyhip_batch* b, std::vector<uint64_t>& off, uint64_t* used) {
+  int rc;
+  *used = 0;
+  off.assign((size_t)b->n + 1, 0);
+  if (b->n == 0) return 0;
+  if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
+  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, b->res.p, b->n, b->blob_off.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(off.data(), b->blob_off.p, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *used = off[b->n];
+  if (*used > 0) {
+    if ((rc = b->blob_compact.reserve(*used))) return rc;
+    hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, c->stream, b->res.p,
+                       b->out_blob.p, b->blob_off.p, b->blob_compact.p, b->n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+// blob offsets of a record after compaction: its three pieces start at `at`
+static void rebase_offsets(dellyhip_result& R, uint64_t at) {
+  const uint64_t l0 = (uint64_t)std::max(R.cons_len, 0), l1 = (uint64_t)std::max(R.allele_len, 0),
+                 l2 = 2ull * (uint64_t)std::max(R.aln_len, 0);
+  R.cons_off = l0 ? at : 0;
+  at += l0;
+  R.allele_off = l1 ? at : 0;
+  at += l1;
+  R.aln_off = l2 ? at : 0;
+}
+
 int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* results, char* out_blob,
                          uint64_t out_blob_cap, uint64_t* out_blob_len) {
   if (!c || !b || (!results && b->n)) return fail(DELLYHIP_E_ARG, "null argument");
@@ -1140,39 +1175,207 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
   if (b->n) {
     // compact on the device, move only the bytes that are used (a few hundred per junction
     // instead of the fixed slot)
-    if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
-    hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, b->res.p, b->n, b->blob_off.p);
-    HIPCHK(hipGetLastError());
-    std::vector<uint64_t> off((size_t)b->n + 1);
-    HIPCHK(hipMemcpyAsync(off.data(), b->blob_off.p, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    used = off[b->n];
+    std::vector<uint64_t> off;
+    if ((rc = compact_batch(c, b, off, &used))) return rc;
     if (used > 0 && (!out_blob || used > out_blob_cap)) {
       if (out_blob_len) *out_blob_len = used;
       return fail(DELLYHIP_E_ARG, "out_blob too small");
     }
-    if (used > 0) {
-      if ((rc = b->blob_compact.reserve(used))) return rc;
-      hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, c->stream, b->res.p,
-                         b->out_blob.p, b->blob_off.p, b->blob_compact.p, b->n);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(out_blob, b->blob_compact.p, used, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    for (int i = 0; i < b->n; ++i) {
-      dellyhip_result& R = results[i];
-      uint64_t at = off[i];
-      const uint64_t l0 = (uint64_t)std::max(R.cons_len, 0), l1 = (uint64_t)std::max(R.allele_len, 0),
-                     l2 = 2ull * (uint64_t)std::max(R.aln_len, 0);
-      R.cons_off = l0 ? at : 0;
-      at += l0;
-      R.allele_off = l1 ? at : 0;
-      at += l1;
-      R.aln_off = l2 ? at : 0;
-    }
+    HIPCHK(hipMemcpyAsync(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
+    if (used > 0) HIPCHK(hipMemcpyAsync(out_blob, b->blob_compact.p, used, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < b->n; ++i) rebase_offsets(results[i], off[i]);
   }
   if (out_blob_len) *out_blob_len = used;
+  return 0;
+}
+
+// ---- multi-GPU: cost-balanced sharding + RCCL gather of the results ---------------------------
+struct dellyhip_comm {
+  int32_t rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  DevBuf<uint64_t> d_counts;   // (count, bytes) of every rank
+  DevBuf<uint8_t> rec_all, blob_all;   // root: receive areas
+};
+
+int dellyhip_shard_by_cost(const dellyhip_params* P, int32_t n, const dellyhip_junction* junc, const uint64_t* seq_off,
+                           uint64_t n_seq, int32_t world, int32_t* owner) {
+  if (n < 0 || world < 1 || (n && (!junc || !seq_off || !owner))) return fail(DELLYHIP_E_ARG, "bad argument");
+  std::vector<double> cost((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const dellyhip_junction& J = junc[i];
+    if (J.n_seq < 0 || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
+    const double N = (double)J.n_seq;
+    const double bytes = (double)(seq_off[J.seq_first + J.n_seq] - seq_off[J.seq_first]);
+    const double L = N > 0 ? bytes / N : 0.0;
+    const double m = L;   // consensus ~ one read length (given consensus: exactly)
+    const double span = std::max(0.0, (double)J.sv_end - (double)J.sv_start);
+    const double win = (J.svt == 2 && P && span <= (double)P->indelsize) ? 2.0 * m + span : 4.0 * m;   // src/split.h:116-117
+    cost[i] = (N > 1 ? N * N * L * L / 2.0 + (N - 1) * L * L * 4.0 : 0.0) + 2.0 * m * win + 1.0;
+  }
+  dh::balance_by_cost(cost.data(), n, world, owner);
+  return 0;
+}
+
+int dellyhip_comm_unique_id(void* id128) {
+  if (!id128) return fail(DELLYHIP_E_ARG, "null argument");
+  dh::RcclApi& A = dh::rccl_api();
+  if (!A.error.empty()) return fail(DELLYHIP_E_RUNTIME, A.error.c_str());
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId");
+  ncclUniqueId id;
+  const ncclResult_t r = A.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+int dellyhip_comm_create(dellyhip_ctx* c, const void* id128, int32_t rank, int32_t world, dellyhip_comm** out) {
+  if (!c || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<dellyhip_comm> m(new dellyhip_comm());
+  m->rank = rank;
+  m->world = world;
+  if (world > 1 || id128) {   // (world == 1 with an id: a real one-rank RCCL communicator -- exercises the RCCL path on one GPU)
+    dh::RcclApi& A = dh::rccl_api();
+    if (!A.error.empty()) return fail(DELLYHIP_E_RUNTIME, A.error.c_str());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    const ncclResult_t r = A.CommInitRank(&m->nccl, world, id, rank);
+    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+    int rc = m->d_counts.alloc(2 * (size_t)world + 2);
+    if (rc) return rc;
+  }
+  *out = m.release();
+  return 0;
+}
+
+void dellyhip_comm_destroy(dellyhip_comm* m) {
+  if (!m) return;
+  if (m->nccl) (void)dh::rccl_api().CommDestroy(m->nccl);
+  delete m;
+}
+
+// the exchange itself: afterwards the root holds every rank's records (rank order) and compact blobs in HBM
+static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, std::vector<uint64_t>& all,
+                         std::vector<uint64_t>& first_n, std::vector<uint64_t>& first_b, const void** d_rec, const void** d_blob) {
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc) return rc;
+  std::vector<uint64_t> off;
+  uint64_t used = 0;
+  if ((rc = compact_batch(c, b, off, &used))) return rc;
+  const int W = m->world;
+  const bool is_root = m->rank == root;
+  all.assign(2 * (size_t)W, 0);
+  if (!m->nccl) {   // one rank, no communicator
+    all[0] = (uint64_t)b->n;
+    all[1] = used;
+  } else {
+    dh::RcclApi& A = dh::rccl_api();
+    const uint64_t mine[2] = {(uint64_t)b->n, used};
+    HIPCHK(hipMemcpyAsync(m->d_counts.p + 2 * W, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = A.AllGather(m->d_counts.p + 2 * W, m->d_counts.p, 2, ncclUint64, m->nccl, c->stream);
+    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+    HIPCHK(hipMemcpyAsync(all.data(), m->d_counts.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  uint64_t tot_n = 0, tot_b = 0;
+  first_n.assign(W + 1, 0);
+  first_b.assign(W + 1, 0);
+  for (int r = 0; r < W; ++r) {
+    first_n[r] = tot_n;
+    first_b[r] = tot_b;
+    tot_n += all[2 * r];
+    tot_b += all[2 * r + 1];
+  }
+  first_n[W] = tot_n;
+  first_b[W] = tot_b;
+  const uint8_t* rec_src = reinterpret_cast<const uint8_t*>(b->res.p);
+  *d_rec = rec_src;
+  *d_blob = b->blob_compact.p;
+  if (W > 1) {
+    dh::RcclApi& A = dh::rccl_api();
+    if (is_root) {
+      if ((rc = m->rec_all.reserve(std::max<uint64_t>(tot_n * sizeof(dellyhip_result), 1))) || (rc = m->blob_all.reserve(std::max<uint64_t>(tot_b, 1))))
+        return rc;
+    }
+    ncclResult_t r = A.GroupStart();
+    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+    if (!is_root) {
+      if (b->n) r = A.Send(rec_src, (size_t)b->n * sizeof(dellyhip_result), ncclUint8, root, m->nccl, c->stream);
+      if (r == ncclSuccess && used) r = A.Send(b->blob_compact.p, used, ncclUint8, root, m->nccl, c->stream);
+    } else {
+      for (int q = 0; q < W && r == ncclSuccess; ++q) {
+        if (q == root) continue;
+        if (all[2 * q]) r = A.Recv(m->rec_all.p + first_n[q] * sizeof(dellyhip_result), all[2 * q] * sizeof(dellyhip_result), ncclUint8, q, m->nccl, c->stream);
+        if (r == ncclSuccess && all[2 * q + 1]) r = A.Recv(m->blob_all.p + first_b[q], all[2 * q + 1], ncclUint8, q, m->nccl, c->stream);
+      }
+    }
+    const ncclResult_t r2 = A.GroupEnd();
+    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+    if (r2 != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r2));
+    if (is_root) {   // the root's own share, device to device
+      if (b->n) HIPCHK(hipMemcpyAsync(m->rec_all.p + first_n[root] * sizeof(dellyhip_result), rec_src, (size_t)b->n * sizeof(dellyhip_result), hipMemcpyDeviceToDevice, c->stream));
+      if (used) HIPCHK(hipMemcpyAsync(m->blob_all.p + first_b[root], b->blob_compact.p, used, hipMemcpyDeviceToDevice, c->stream));
+      *d_rec = m->rec_all.p;
+      *d_blob = m->blob_all.p;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int dellyhip_gather_results_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, const void** d_records,
+                                   uint64_t* n_results, const void** d_blob, uint64_t* blob_bytes) {
+  if (!c || !m || !b || root < 0 || root >= m->world) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (b->n && !b->ever_run) return fail(DELLYHIP_E_ARG, "dellyhip_gather_results_device: the batch has not been run");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint64_t> all, first_n, first_b;
+  const void *dr = nullptr, *db = nullptr;
+  int rc = gather_device(c, m, b, root, all, first_n, first_b, &dr, &db);
+  if (rc) return rc;
+  const bool is_root = m->rank == root;
+  if (d_records) *d_records = is_root ? dr : nullptr;
+  if (d_blob) *d_blob = is_root ? db : nullptr;
+  if (n_results) *n_results = first_n[m->world];
+  if (blob_bytes) *blob_bytes = first_b[m->world];
+  return 0;
+}
+
+int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, dellyhip_result* results,
+                            uint64_t results_cap, uint64_t* n_results, char* out_blob, uint64_t out_blob_cap,
+                            uint64_t* out_blob_len, int32_t* counts) {
+  if (!c || !m || !b || root < 0 || root >= m->world) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (b->n && !b->ever_run) return fail(DELLYHIP_E_ARG, "dellyhip_gather_results: the batch has not been run");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint64_t> all, first_n, first_b;
+  const void *dr = nullptr, *db = nullptr;
+  // (a root whose buffers turn out too small has still taken part in the exchange: the senders never block on it)
+  int rc = gather_device(c, m, b, root, all, first_n, first_b, &dr, &db);
+  if (rc) return rc;
+  const int W = m->world;
+  const uint64_t tot_n = first_n[W], tot_b = first_b[W];
+  if (n_results) *n_results = tot_n;
+  if (out_blob_len) *out_blob_len = tot_b;
+  if (m->rank != root) return 0;
+  if (!((tot_n == 0 || (results && tot_n <= results_cap)) && (tot_b == 0 || (out_blob && tot_b <= out_blob_cap))))
+    return fail(DELLYHIP_E_ARG, "dellyhip_gather_results: results / out_blob too small (needed sizes returned)");
+  if (counts)
+    for (int r = 0; r < W; ++r) counts[r] = (int32_t)all[2 * r];
+  if (tot_n) {
+    HIPCHK(hipMemcpyAsync(results, dr, tot_n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
+    if (tot_b) HIPCHK(hipMemcpyAsync(out_blob, db, tot_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // blob offsets: each rank's pieces lie back to back in its compact blob in junction order
+    for (int r = 0; r < W; ++r) {
+      uint64_t at = first_b[r];
+      for (uint64_t k = first_n[r]; k < first_n[r + 1]; ++k) {
+        dellyhip_result& R = results[k];
+        const uint64_t len = (uint64_t)std::max(R.cons_len, 0) + (uint64_t)std::max(R.allele_len, 0) + 2ull * (uint64_t)std::max(R.aln_len, 0);
+        rebase_offsets(R, at);
+        at += len;
+      }
+    }
+  }
   return 0;
 }
 
@@ -1328,17 +1531,18 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
   return 0;
 }
 
-int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,
-                         int32_t aln_cap, int32_t* aln_len, int32_t* found) {
+// one direct (consensus, window) pair through the short-read kernels: svt 2 = longNeedle, svt 4 = splitAlign
+static int direct_pair(dellyhip_ctx* c, int svt, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,
+                       int32_t aln_cap, int32_t* aln_len, int32_t* found, const char* what) {
   if (!c || !s1 || !s2 || !aln_len || !found || m < 0 || n < 0) return fail(DELLYHIP_E_ARG, "bad argument");
-  if (m > dh::MMAX || n > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "longNeedle operand exceeds the short-read kernel limits");
+  if (m > dh::MMAX || n > dh::NMAX) return fail(DELLYHIP_E_LIMIT, what);
   HIPCHK(hipSetDevice(c->device));
   dellyhip_batch* b = new dellyhip_batch();
   b->n = 1;
   b->want_alignment = 1;
   b->out_stride = (dh::OUT_CONS_CAP + dh::OUT_ALLELE_CAP + dh::OUT_ALN_CAP + 15) & ~15ull;
   dellyhip_junction J{};
-  J.svt = 2;
+  J.svt = svt;
   J.n_seq = 1;
   b->h_junc.assign(1, J);
   b->h_cons_len.assign(1, m);
@@ -1364,10 +1568,10 @@ int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char*
   uint64_t used = 0;
   if (!rc) rc = dellyhip_batch_fetch(c, b, &R, blob.data(), blob.size(), &used);
   if (!rc) {
-    if (R.status) rc = fail(R.status, "longNeedle: kernel limit");
+    if (R.status) rc = fail(R.status, what);
     else {
       *found = R.ok;
-      *aln_len = R.aln_len;
+      *aln_len = R.ok ? R.aln_len : 0;
       if (R.ok) {
         if (R.aln_len > aln_cap || !align_rows) rc = fail(DELLYHIP_E_ARG, "align_rows too small");
         else {
@@ -1379,6 +1583,17 @@ int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char*
   }
   dellyhip_batch_free(c, b);
   return rc;
+}
+
+int dellyhip_long_needle(dellyhip_ctx* c, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,
+                         int32_t aln_cap, int32_t* aln_len, int32_t* found) {
+  return direct_pair(c, 2, s1, m, s2, n, align_rows, aln_cap, aln_len, found, "longNeedle operand exceeds the short-read kernel limits");
+}
+
+int dellyhip_split_align(dellyhip_ctx* c, const char* cons, int32_t m, const char* ref, int32_t n, char* align_rows,
+                         int32_t aln_cap, int32_t* aln_len, int32_t* found) {
+  if (m < 1 || n < 3) return fail(DELLYHIP_E_LIMIT, "splitAlign: |cons| >= 1 and |svRefStr| >= 3 (src/split.h:513-517 indexes distRev[n-2])");
+  return direct_pair(c, 4, cons, m, ref, n, align_rows, aln_cap, aln_len, found, "splitAlign operand exceeds the short-read kernel limits");
 }
 
 int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const char* target, int32_t tn, int32_t mode,

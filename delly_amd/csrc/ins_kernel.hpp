@@ -390,7 +390,8 @@ __device__ void process_ins(const SplitArgs& A, int j, InsLds& L, uint32_t* scra
     }
   }
   X.go = go;
-  split_detect(A, X, L.s, L.p, go, Ltot, Ltot, lane);
+  if (go && X.direct && lane == 0) X.out->ok = 1;   // dellyhip_split_align: splitAlign() returned true, rows written by masks_finish
+  split_detect(A, X, L.s, L.p, go && !X.direct, Ltot, Ltot, lane);
 }
 
 // ---- single edlibAlign call (parity tests; edlib.h:242-246) ----------------------------

@@ -31,6 +31,8 @@ EXPORTS = [
     "dellyhip_jobs_free", "dellyhip_jobs_kernel_ms",
     "dellyhip_edit_distance_nw_batch", "dellyhip_nwjobs_upload", "dellyhip_nwjobs_run", "dellyhip_nwjobs_fetch",
     "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
+    "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
+    "dellyhip_gather_results", "dellyhip_gather_results_device",
 ]
 
 
@@ -55,6 +57,7 @@ def load_library():
         lib.dellyhip_destroy.restype = None
         lib.dellyhip_jobs_free.restype = None
         lib.dellyhip_nwjobs_free.restype = None
+        lib.dellyhip_comm_destroy.restype = None
         _lib = lib
     return _lib
 
@@ -67,6 +70,51 @@ def _u8(a):
 
 def _p(a, typ=C.c_char_p):
     return a.ctypes.data_as(typ)
+
+
+def shard_by_cost(junctions, seq_off, world, params=None):
+    """owner[i] = rank of junction i, balanced by predicted cost (dellyhip_shard_by_cost; pure host arithmetic, no GPU)."""
+    lib = load_library()
+    p = params if params is not None else abi.params_sr()
+    junc = np.ascontiguousarray(junctions)
+    off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+    owner = np.zeros(junc.shape[0], dtype=np.int32)
+    rc = lib.dellyhip_shard_by_cost(C.byref(p), int(junc.shape[0]), _p(junc, C.c_void_p), _p(off, C.POINTER(C.c_uint64)),
+                                    C.c_uint64(off.size - 1), int(world), _p(owner, C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise DellyHipError(rc, lib.dellyhip_last_error().decode())
+    return owner
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it and hands it to the other ranks)."""
+    lib = load_library()
+    buf = (C.c_ubyte * 128)()
+    rc = lib.dellyhip_comm_unique_id(buf)
+    if rc != 0:
+        raise DellyHipError(rc, lib.dellyhip_last_error().decode())
+    return bytes(buf)
+
+
+class Comm:
+    """One RCCL communicator per process / GPU (dellyhip_comm_create); world == 1 needs no id."""
+
+    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._c = C.c_void_p()
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        ctx._check(ctx.lib.dellyhip_comm_create(ctx._ctx, idbuf, self.rank, self.world, C.byref(self._c)))
+
+    def close(self):
+        if self._c:
+            self.ctx.lib.dellyhip_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -190,6 +238,17 @@ class Context:
         L = ln.value if found.value else 0
         return bool(found.value), rows[:L].tobytes(), rows[cap:cap + L].tobytes()
 
+    def split_align(self, cons, ref):
+        """splitAlign + the row swap of _consRefAlignment (src/split.h:480-552) -> (found, cons row, ref row)"""
+        s1, s2 = _u8(cons), _u8(ref)
+        cap = s1.size + s2.size + 8
+        rows = np.zeros(2 * cap, dtype=np.uint8)
+        ln, found = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.dellyhip_split_align(self._ctx, _p(s1), s1.size, _p(s2), s2.size, _p(rows), cap,
+                                                  C.byref(ln), C.byref(found)))
+        L = ln.value if found.value else 0
+        return bool(found.value), rows[:L].tobytes(), rows[cap:cap + L].tobytes()
+
     def edlib_align(self, q, t, mode, task=2):
         """edlibAlign(q, t, {k=-1, mode, task}) -> (editDistance, numLocations, endLoc, startLoc, ops)"""
         q, t = _u8(q), _u8(t)
@@ -307,6 +366,32 @@ class ResidentBatch:
         self.ctx._check(self.ctx.lib.dellyhip_batch_fetch(self.ctx._ctx, self._b, _p(res, C.c_void_p), _p(out),
                                                           C.c_uint64(cap), C.byref(used)))
         return res, out[:used.value]
+
+    def gather(self, comm, root=0, results_cap=None, blob_cap=None):
+        """dellyhip_gather_results: records + consensus / allele bytes of every rank's batch on `root`
+        -> (results, blob, counts) there, (None, None, None) elsewhere.  Collective."""
+        is_root = comm.rank == root
+        ncap = int(results_cap if results_cap is not None else self.n * comm.world + 64)
+        bcap = int(blob_cap if blob_cap is not None else (self.n * 3100 + 8 * self._blob_bytes) * comm.world + 64)
+        res = np.zeros(ncap if is_root else 0, dtype=abi.result_dtype())
+        out = np.zeros(bcap if is_root else 0, dtype=np.uint8)
+        counts = np.zeros(comm.world, dtype=np.int32)
+        n_res, used = C.c_uint64(0), C.c_uint64(0)
+        self.ctx._check(self.ctx.lib.dellyhip_gather_results(
+            self.ctx._ctx, comm._c, self._b, int(root), _p(res, C.c_void_p) if is_root else None, C.c_uint64(ncap if is_root else 0),
+            C.byref(n_res), _p(out) if is_root else None, C.c_uint64(bcap if is_root else 0), C.byref(used),
+            _p(counts, C.POINTER(C.c_int32)) if is_root else None))
+        if not is_root:
+            return None, None, None
+        return res[:n_res.value], out[:used.value], counts
+
+    def gather_device(self, comm, root=0):
+        """dellyhip_gather_results_device: the same exchange, results left in the root's HBM -> (records, blob bytes) gathered"""
+        dr, db = C.c_void_p(), C.c_void_p()
+        n_res, nb = C.c_uint64(0), C.c_uint64(0)
+        self.ctx._check(self.ctx.lib.dellyhip_gather_results_device(self.ctx._ctx, comm._c, self._b, int(root), C.byref(dr), C.byref(n_res),
+                                                                   C.byref(db), C.byref(nb)))
+        return n_res.value, nb.value
 
     def free(self):
         if self._b:

@@ -18,6 +18,41 @@ def shard_range(n_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
+def shard_by_cost(batch, rank, world, params=None):
+    """Cost-balanced junction assignment (dellyhip_shard_by_cost in the host library): indices of the
+    junctions rank `rank` refines.  Every rank computes the same assignment from the same junction list."""
+    from . import refine
+    owner = refine.shard_by_cost(batch.junctions, batch.seq_off, world, params)
+    return np.nonzero(owner == rank)[0]
+
+
+def gather_results(local_rec, local_blob, world, dist=None):
+    """torch.distributed mirror of dellyhip_gather_results (the product path uses RCCL directly inside the host library;
+    this one runs on gloo for the CPU tests): all-gathers the fixed-size records and the variable-length consensus /
+    allele bytes, rebases the blob offsets.  local_rec: structured array (abi.result_dtype) whose *_off fields point into
+    local_blob (np.uint8, compact).  -> (records in rank order, blob, counts)"""
+    import torch
+    dt = abi.result_dtype()
+    rec_t = torch.from_numpy(np.frombuffer(np.ascontiguousarray(local_rec).tobytes(), dtype=np.uint8).copy())
+    if world == 1:
+        return local_rec.copy(), np.asarray(local_blob, dtype=np.uint8).copy(), [int(local_rec.shape[0])]
+    gathered, counts, mx = gather_records(rec_t, world, dist)
+    recs = merge_records(gathered.cpu().numpy(), counts, mx, sort_key=None).copy()
+    blob_t = torch.from_numpy(np.ascontiguousarray(local_blob, dtype=np.uint8).copy())
+    gb, bcounts, bmx = gather_records(blob_t, world, dist, record_bytes=1)
+    gb = gb.cpu().numpy().reshape(world, bmx)
+    blob = np.concatenate([gb[r, :bcounts[r]] for r in range(world)]) if world else np.zeros(0, np.uint8)
+    base = np.concatenate([[0], np.cumsum(bcounts)])[:-1]
+    pos = 0
+    for r, c in enumerate(counts):
+        seg = recs[pos:pos + c]
+        for f, ln, mult in (("cons_off", "cons_len", 1), ("allele_off", "allele_len", 1), ("aln_off", "aln_len", 2)):
+            has = seg[ln] > 0
+            seg[f][has] += np.uint64(base[r])
+        pos += c
+    return recs, blob, counts
+
+
 def gather_records(local, world, dist=None, max_count=None, record_bytes=None):
     """All-gathers fixed-size result records (a uint8 torch tensor of
     count*sizeof(dellyhip_result) bytes, on the device of the backend).  Ranks

@@ -81,6 +81,24 @@ class Batch:
                 for k in range(int(j["n_seq"]))]
 
 
+def subset(batch, idx):
+    """The junctions idx (any order) of a batch as a batch of their own: same chromosomes, reads re-packed."""
+    idx = np.asarray(idx, dtype=np.int64)
+    junc = batch.junctions[idx].copy()
+    parts, off, first = [], [0], 0
+    for k, i in enumerate(idx):
+        f, n = int(batch.junctions["seq_first"][i]), int(batch.junctions["n_seq"][i])
+        for q in range(n):
+            a, b = int(batch.seq_off[f + q]), int(batch.seq_off[f + q + 1])
+            parts.append(batch.seq_blob[a:b])
+            off.append(off[-1] + (b - a))
+        junc["seq_first"][k] = first
+        first += n
+    blob = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+    truth = [batch.truth[int(i)] for i in idx] if batch.truth is not None else None
+    return Batch(batch.chroms, junc, blob, np.asarray(off, dtype=np.uint64), batch.with_msa, truth)
+
+
 def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_flank=75,
                sub_rate=0.005, del_len=700):
     """Builds junctions first..first+n-1.
@@ -97,6 +115,9 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   indelsize (two windows), INV, DUP; every third junction's consensus is given
                   reverse-complemented (the orientation test of src/split.h:564-572 must flip it).
                   Use with abi.params_lr(realign=True).
+    mode "lrins": long-read insertions: svt 4, 800 bp of novel sequence (del_len = inserted
+                  length), flanks of 1.2-1.5 kb, i.e. reads of ~3.8 kb; n_reads > 0: the loop body msaWfa +
+                  alignConsensus (src/assemble.h:855-860).  Use with abi.params_lr(realign=True).
     mode "ins"  : svt 4 insertions (splitAlign path, src/split.h:480-538): 16..120 bp
                   novel or tandem-duplicated sequence, soft-masked / N-containing
                   reference stretches, pure-reference negatives.
@@ -104,7 +125,8 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   many distinct split reads per junction, host order = as generated).
     """
     two_chr = mode == "mixed"
-    WINDOW = WINDOW_LR if mode == "lr" else globals()["WINDOW"]
+    lr_like = mode in ("lr", "lrins")
+    WINDOW = WINDOW_LR if lr_like else globals()["WINDOW"]
     chrA = np.empty(n * WINDOW, dtype=np.uint8)
     chrB = np.empty(n * WINDOW if two_chr else 0, dtype=np.uint8)
     junc = np.zeros(n, dtype=abi.junction_dtype())
@@ -150,6 +172,13 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                 kind, svt, ell = "inv0", 0, 3500
             elif sel == 5:
                 kind, svt, ell = "dup", 3, 3000
+        elif mode == "lrins":
+            s = 6000
+            svt = 4
+            kind = "ins"
+            flankL = int(rng.integers(1200, 1500))
+            flankR = int(rng.integers(1200, 1500))
+            ell = int(del_len) if del_len != 700 else 800
         elif mode == "ins":
             svt = 4
             sel = j % 10
@@ -192,7 +221,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             h = int(rng.integers(2, 11))
             G[e:e + h] = G[s:s + h]
         # ALT haplotype around the junction (left part ‖ right part), 150+150
-        L = max(1200 if mode == "lr" else 150, flankL, flankR)
+        L = max(1200 if mode == "lr" else 150, flankL, flankR) + (50 if mode == "lrins" else 0)
         if kind in ("del", "nrun", "hom"):
             left, right = G[s - L:s], G[e:e + L]
         elif kind == "noref":
@@ -237,7 +266,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         rec["seq_first"] = len(seqs)
         if n_reads <= 0:
             cons = _mutate(rng, alt[L - flankL:L + flankR], sub_rate)
-            if mode == "lr":
+            if lr_like:
                 # sparse 1-base indels on top of the substitutions, then orientation
                 keep = rng.random(cons.size) >= 0.004
                 cons = cons[keep]
@@ -250,13 +279,13 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         else:
             seen = set()
             lo, hi = 25, alt.size - read_len - 25
-            if mode == "lr":   # long reads span the junction: ~L - 100 bases of each flank
+            if lr_like:   # long reads span the junction: ~L - 100 bases of each flank
                 lo, hi = 0, 100
             tries = 0
             while len(seen) < n_reads and tries < 50 * n_reads:
                 tries += 1
                 o = int(rng.integers(lo, hi + 1))
-                if mode == "lr":
+                if lr_like:
                     r = _ont(rng, alt[o:alt.size - int(rng.integers(0, 101))], sub_rate)
                 else:
                     r = _mutate(rng, alt[o:o + read_len], sub_rate)
@@ -271,7 +300,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
     off[1:] = np.cumsum([x.size for x in seqs], dtype=np.uint64)
     blob = np.concatenate(seqs) if seqs else np.zeros(0, dtype=np.uint8)
     chroms = [chrA, chrB] if two_chr else [chrA]
-    return Batch(chroms, junc, blob, off, (2 if mode == "lr" else 1) if n_reads > 0 else 0, truth)
+    return Batch(chroms, junc, blob, off, (2 if lr_like else 1) if n_reads > 0 else 0, truth)
 
 
 def make_align_jobs(n_sv, reads_per_bp=40, *, seed=7, read_len=150, flank=13, sub_rate=0.005, weird=False):

@@ -189,6 +189,42 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_sp
  * dellyhip_batch_kernel_ms() call (HIP events on the launch stream). */
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
+/* ---- multi-GPU: junction sharding + gather of the results to one rank ------------------------ */
+
+/* owner[i] = rank (0 .. world-1) of junction i, balanced by predicted cost -- N^2 L^2 for the pairwise stage of
+ * msa()/msaEdlib(), (N-1) L^2 for the progressive alignments, |consensus| x |svRefStr| for the split alignment
+ * (N reads of mean length L; consensus ~ L for short reads, given for n_seq == 1) -- longest first onto the lightest
+ * rank.  Pure host arithmetic (no GPU needed); every rank computes the same assignment from the same junction list.
+ * Junctions are independent (src/shortpe.h:183-197 touches only svs[svid]), so any assignment gives the same results. */
+int dellyhip_shard_by_cost(const dellyhip_params* params, int32_t n_junctions, const dellyhip_junction* junctions,
+                           const uint64_t* seq_off, uint64_t n_seq, int32_t world, int32_t* owner);
+
+/* One communicator per process (one process per GPU), RCCL over xGMI.  Rank 0 fills id128 (128 bytes,
+ * ncclUniqueId) with dellyhip_comm_unique_id and hands it to the other ranks by any means (file, MPI, torch.distributed
+ * store); every rank then calls dellyhip_comm_create.  world == 1 needs no id and never loads RCCL. */
+typedef struct dellyhip_comm dellyhip_comm;
+int dellyhip_comm_unique_id(void* id128);
+int dellyhip_comm_create(dellyhip_ctx* ctx, const void* id128, int32_t rank, int32_t world, dellyhip_comm** out);
+void dellyhip_comm_destroy(dellyhip_comm* comm);
+
+/* Gathers what dellyhip_batch_fetch returns -- result records AND consensus / "REF,ALT" (/ alignment) bytes -- of every
+ * rank's batch to `root`: the all-gatherv of SURVEY.md 8e (RCCL has none: one ncclAllGather of the counts, then grouped
+ * ncclSend / ncclRecv of the two variable-length pieces).  Collective: every rank calls it with its own batch (run
+ * before; n = 0 is fine).  On root: results[0 .. sum counts) in rank order (rank r's junctions in its batch order; sort
+ * by svid for the CPU order), blob offsets rebased into out_blob, counts[r] = junctions of rank r.  Other ranks pass
+ * NULL buffers.  results_cap in records, out_blob_cap in bytes (DELLYHIP_E_ARG with the needed sizes in *n_results /
+ * *out_blob_len when too small). */
+int dellyhip_gather_results(dellyhip_ctx* ctx, dellyhip_comm* comm, dellyhip_batch* b, int32_t root,
+                            dellyhip_result* results, uint64_t results_cap, uint64_t* n_results, char* out_blob,
+                            uint64_t out_blob_cap, uint64_t* out_blob_len, int32_t* counts);
+
+/* The same exchange, results left in the root's HBM (pipelined callers: the gather of batch k overlaps the refinement
+ * of batch k+1; a later dellyhip_gather_results / hipMemcpy moves them to the host): *d_records = n_results records in
+ * rank order, *d_blob = the ranks' compact blobs back to back (offsets inside the records are still per rank, as
+ * dellyhip_batch_run left them).  The pointers stay valid until the next gather on this communicator. */
+int dellyhip_gather_results_device(dellyhip_ctx* ctx, dellyhip_comm* comm, dellyhip_batch* b, int32_t root,
+                                   const void** d_records, uint64_t* n_results, const void** d_blob, uint64_t* blob_bytes);
+
 /* Long-read flavour of dellyhip_refine_batch: the loop body of src/assemble.h:833-872 for
  * non-insertion junctions -- msaEdlib(c, seqStore[svid], consensus) (src/assemble.h:383-473)
  * followed by alignConsensus(c, hdr, seq, NULL, sv, realign) with the `delly lr` parameters
@@ -318,6 +354,13 @@ int dellyhip_nwjobs_kernel_ms(dellyhip_ctx* ctx, dellyhip_nwjobs* b, double* ms,
  * src/needle.h:45-222 as called from src/split.h:555.  align_rows receives the
  * 2 x *aln_len gapped alignment (row-major, row stride aln_cap). */
 int dellyhip_long_needle(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
+                         char* align_rows, int32_t aln_cap, int32_t* aln_len, int32_t* found);
+
+/* bool splitAlign(cons, svRefStr, align)  src/split.h:480-538 (the svt 4 branch of _consRefAlignment, :546-552).
+ * align_rows as for dellyhip_long_needle, in _consRefAlignment's orientation: row 0 = consensus, row 1 = reference
+ * (splitAlign itself returns them the other way round; the caller swaps).  Short-read insertion shapes:
+ * |cons| <= 319, 3 <= |svRefStr| <= 2048. */
+int dellyhip_split_align(dellyhip_ctx* ctx, const char* cons, int32_t m, const char* ref, int32_t n,
                          char* align_rows, int32_t aln_cap, int32_t* aln_len, int32_t* found);
 
 /* EdlibAlignResult edlibAlign(query, queryLength, target, targetLength,

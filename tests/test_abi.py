@@ -66,3 +66,20 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "delly_oracle" not in txt, f
                 assert "libdelly_ref" not in txt, f
+
+
+def test_compiled_cpp_caller_builds_and_fails_loudly_without_a_device():
+    """tests/cpp/dropin_test: the drop-in headers compile against the reference's tags.h / align.h, the struct layouts
+    agree with the library, and without a usable GPU torali::msa() throws (no CPU path)."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "dropin_test")
+    if not os.path.exists(exe):
+        if not os.path.isdir("/root/reference/src"):
+            pytest.skip("tests/cpp/_build/dropin_test not built and /root/reference absent")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")])
+    r = subprocess.run([exe, "abi"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "nodevice"], capture_output=True, text=True)
+        assert r.returncode == 0 and "loud failure" in r.stdout, r.stdout + r.stderr

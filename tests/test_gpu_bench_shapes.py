@@ -21,7 +21,7 @@ import bench  # noqa: E402  (SIDE_PLAN only; main() is not run)
 THREADS = os.cpu_count() or 1
 # junctions compared per workload (None = the whole benched batch)
 COMPARE_N = {"u_full_n20": None, "u_full_n5": None, "ins_svt4": None, "lr_c4_align_consensus": 256,
-             "lr_c4_msaedlib_n15": 64}
+             "lr_c4_msaedlib_n15": 64, "lr_ins_msawfa_n15": 64}
 
 
 def _check(ctx, ref, b, params, label, n_cmp=None):
@@ -43,7 +43,7 @@ def test_headline_batch_10000_c2_junctions_vs_reference(gpu_ctx, reference):
 @pytest.mark.parametrize("name", [x[0] for x in bench.SIDE_PLAN if x[0] in COMPARE_N])
 def test_side_measurement_batches_vs_reference(reference, name):
     _, n, _, kw = [x for x in bench.SIDE_PLAN if x[0] == name][0]
-    lr = kw["mode"] == "lr"
+    lr = kw["mode"].startswith("lr")
     params = abi.params_lr(realign=True) if lr else abi.params_sr()
     ctx = refine.Context(params=params)
     try:

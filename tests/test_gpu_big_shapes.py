@@ -19,6 +19,15 @@ def lr_ctx():
     ctx.close()
 
 
+@pytest.fixture
+def lr_reference(reference):
+    """the session-wide reference checker with the `delly lr` parameters for the single-item calls, restored afterwards"""
+    old = reference.params
+    reference.params = abi.params_lr()
+    yield reference
+    reference.params = old
+
+
 def _big_deletions(shapes, seed=11, err=0.01, revcomp_every=0):
     """one DEL junction per (flank, ell): consensus = 2*flank bases of the ALT haplotype with ONT-like errors"""
     rng = np.random.default_rng(seed)
@@ -70,8 +79,8 @@ def _reads(rng, n, length, err, ins=0):
     return [bytes(synth._ont(rng, base[int(rng.integers(0, 40)):L - int(rng.integers(0, 40))], err)) for _ in range(n)], base
 
 
-def test_msa_edlib_reads_beyond_6144_vs_reference(lr_ctx, reference):
-    reference.params = abi.params_lr()
+def test_msa_edlib_reads_beyond_6144_vs_reference(lr_ctx, lr_reference):
+    reference = lr_reference
     rng = np.random.default_rng(21)
     for n, length in ((4, 7000), (6, 9000), (3, 12000)):
         reads, _ = _reads(rng, n, length, 0.05)
@@ -81,8 +90,8 @@ def test_msa_edlib_reads_beyond_6144_vs_reference(lr_ctx, reference):
         assert len(got[1]) > 6144
 
 
-def test_msa_wfa_reads_beyond_6144_vs_reference(lr_ctx, reference):
-    reference.params = abi.params_lr()
+def test_msa_wfa_reads_beyond_6144_vs_reference(lr_ctx, lr_reference):
+    reference = lr_reference
     rng = np.random.default_rng(22)
     for n, length, ins in ((4, 5000, 2500), (5, 6000, 4000)):
         reads, base = _reads(rng, n, length, 0.04, ins=ins)

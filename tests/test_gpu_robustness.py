@@ -74,3 +74,34 @@ def test_malformed_junction_records_are_rejected(gpu_ctx):
     # the well-formed batch still runs
     r, _ = gpu_ctx.align_consensus_batch(b.junctions, b.seq_blob, b.seq_off)
     assert r.shape[0] == 4
+
+
+def test_gather_results_single_rank_equals_fetch(gpu_ctx):
+    """dellyhip_gather_results with world = 1 (no RCCL): records, rebased offsets and bytes equal dellyhip_batch_fetch"""
+    b = synth.make_batch(200, mode="mixed", n_reads=4, seed=6)
+    gpu_ctx.set_chromosomes(b.chroms)
+    rb = gpu_ctx.upload(b)
+    rb.run(); rb.sync()
+    r1, b1 = rb.fetch()
+    comm = refine.Comm(gpu_ctx, 0, 1)
+    r2, b2, counts = rb.gather(comm, 0)
+    comm.close()
+    rb.free()
+    assert counts.tolist() == [b.n]
+    assert r1.tobytes() == r2.tobytes() and b1.tobytes() == b2.tobytes()
+
+
+def test_rccl_communicator_of_one_rank(gpu_ctx):
+    """the RCCL path itself on the one GPU of this box: unique id, ncclCommInitRank(world = 1)"""
+    uid = refine.comm_unique_id()
+    assert len(uid) == 128
+    # world == 1 never loads RCCL; a communicator created WITH an id still must work for the gather
+    comm = refine.Comm(gpu_ctx, 0, 1, uid)
+    b = synth.make_batch(16, mode="c2", seed=8)
+    gpu_ctx.set_chromosomes(b.chroms)
+    rb = gpu_ctx.upload(b)
+    rb.run()
+    r, bl, counts = rb.gather(comm, 0)
+    assert r.shape[0] == 16 and counts.tolist() == [16] and int(r["ok"].sum()) >= 14
+    comm.close()
+    rb.free()

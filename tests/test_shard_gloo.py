@@ -94,6 +94,79 @@ def test_two_rank_classifier_jobs_equal_single_process(tmp_path):
     assert merged.tobytes() == whole.tobytes()
 
 
+def _cost_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    whole = synth.make_batch(30, mode="mixed", n_reads=5, seed=13)          # every rank sees the junction list
+    mine = shard.shard_by_cost(whole, rank, world)                          # ... and takes its cost-balanced share
+    sub = synth.subset(whole, mine)
+    res, blob = pyoracle.Oracle("port").refine_batch(sub, want_alignment=False)
+    recs, gblob, counts = shard.gather_results(res, blob, world, dist)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "recs.npy"), recs)
+        np.save(os.path.join(out_dir, "blob.npy"), gblob)
+        np.save(os.path.join(out_dir, "counts.npy"), np.asarray(counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_cost_sharding_and_gather_of_records_and_blob_bytes(tmp_path):
+    """cost-balanced assignment (dellyhip_shard_by_cost) + gather of the records AND the consensus / allele bytes to
+    rank 0 (the torch mirror of dellyhip_gather_results): sorted by svid it is the single-process result, byte for byte"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import shard, synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_cost_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    recs = np.load(os.path.join(str(tmp_path), "recs.npy"))
+    blob = np.load(os.path.join(str(tmp_path), "blob.npy"))
+    counts = np.load(os.path.join(str(tmp_path), "counts.npy"))
+    whole = synth.make_batch(30, mode="mixed", n_reads=5, seed=13)
+    ref, rblob = pyoracle.Oracle("port").refine_batch(whole, want_alignment=False)
+    assert int(counts.sum()) == whole.n and min(counts) > 0
+    order = np.argsort(recs["svid"], kind="stable")
+    recs = recs[order]
+    assert np.array_equal(recs["svid"], ref["svid"])
+    for f in ("ok", "sv_start", "sv_end", "ci_wiggle", "ins_len", "cons_bp", "hom_len", "sr_support", "sr_align_quality",
+              "cons_len", "allele_len"):
+        assert np.array_equal(recs[f], ref[f]), f
+    n_bytes = 0
+    for k in range(whole.n):
+        for w in ("cons", "allele"):
+            a, b = pyoracle.blob_field(recs[k], blob, w), pyoracle.blob_field(ref[k], rblob, w)
+            assert a == b, (k, w)
+            n_bytes += len(a)
+    assert n_bytes > 1000
+
+
+def test_shard_by_cost_balances_and_is_deterministic():
+    from delly_amd import abi, refine, synth
+    # 10x cost spread: a few long-read junctions among short ones
+    b = synth.make_batch(40, mode="c2", n_reads=8, seed=3)
+    cost = (b.junctions["n_seq"].astype(np.float64)) ** 2
+    for world in (1, 2, 3, 8):
+        o1 = refine.shard_by_cost(b.junctions, b.seq_off, world)
+        o2 = refine.shard_by_cost(b.junctions, b.seq_off, world)
+        assert np.array_equal(o1, o2) and o1.min() >= 0 and o1.max() < world
+        loads = np.array([cost[o1 == r].sum() for r in range(world)])
+        assert loads.max() <= loads.mean() * 1.25 + cost.max()
+    lr = synth.make_batch(6, mode="lr", n_reads=5, sub_rate=0.05)
+    mixed_j = np.concatenate([b.junctions[:20], lr.junctions])
+    mixed_j["seq_first"][20:] += b.n_seq
+    off = np.concatenate([b.seq_off, lr.seq_off[1:] + b.seq_off[-1]])
+    own = refine.shard_by_cost(mixed_j, off, 2, abi.params_lr())
+    # the six expensive junctions are split 3 / 3, not left on one rank as a contiguous block would
+    assert sorted(np.bincount(own[20:], minlength=2).tolist()) == [3, 3]
+
+
 def test_shard_range_partitions():
     from delly_amd import shard
     for n in (0, 1, 7, 64, 10001):
