@@ -77,16 +77,47 @@ def cpu_baseline(batch, budget_s=12.0):
                       % (reps, batch.n, nN, okN, threads, sN, n1, s1)}
 
 
+def _profile_file(name):
+    """newest committed copy of a profile artefact (profiles/rNN/<name>)"""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def _measured_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs,
+    (profiles/rNN/pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if not collected."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
     try:
-        with open(path) as f:
+        with open(_profile_file("pmc_traffic.json")) as f:
             return json.load(f)["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+# VALU issue ceiling of one SIMD for the op mix of the DP kernels (v_pk_*_i16, v_max, DPP moves, v_bfi ...), measured with
+# tools/valu_rate.hip at 4-8 resident wavefronts per SIMD, >= 50 ms kernels: profiles/r02/valu_rate.txt (0.51-0.55 G
+# wave-instructions/s; plain v_add / v_and reach 0.73 G).  Nominal figure of MI355X_MICROARCH.md: a wave64 VALU
+# instruction issues over 2 cycles = 1.2 G/s per SIMD at 2.4 GHz (157.3 TFLOP/s fp32).
+VALU_PEAK_MEASURED_PER_SIMD = 0.55e9
+VALU_PEAK_NOMINAL_PER_SIMD = 1.2e9
+N_SIMD = 1024
+
+
+def _valu_instructions(kernel_prefix, n_junctions):
+    """VALU wave-instructions per launch of the dominant kernel from the committed SQ counter pass
+    (profiles/rNN/pmc_sq_summary.txt, SQ_INSTS_VALU, collected at 10 000 C2 junctions), scaled to this launch"""
+    try:
+        for line in open(_profile_file("pmc_sq_summary.txt")):
+            if kernel_prefix in line and "SQ_INSTS_VALU" in line:
+                import ast
+                d = ast.literal_eval(line[line.index("{"):])
+                return d["SQ_INSTS_VALU"] * (n_junctions / 10000.0)
+    except Exception:
+        pass
+    return None
 
 
 def _subbatch(batch, n):
@@ -413,6 +444,17 @@ def main():
         value = total_units / dt
         ach = n * ALG_BYTES_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0
         traffic = _measured_traffic()
+        valu_n = _valu_instructions("split_quad_kernel<5, 3>", n)
+        valu = None
+        if valu_n and ms_dp > 0:
+            rate = valu_n / (ms_dp * 1e-3)
+            valu = {"wave_instructions_per_launch": valu_n, "achieved_G_per_s": rate / 1e9,
+                    "peak_measured_G_per_s": VALU_PEAK_MEASURED_PER_SIMD * N_SIMD / 1e9,
+                    "frac_of_measured_peak": rate / (VALU_PEAK_MEASURED_PER_SIMD * N_SIMD),
+                    "peak_nominal_G_per_s": VALU_PEAK_NOMINAL_PER_SIMD * N_SIMD / 1e9,
+                    "frac_of_nominal_peak": rate / (VALU_PEAK_NOMINAL_PER_SIMD * N_SIMD),
+                    "source": "SQ_INSTS_VALU of profiles/*/pmc_sq_summary.txt / live kernel time; peaks: profiles/r02/valu_rate.txt "
+                              "(tools/valu_rate.hip) and MI355X_MICROARCH.md (wave64 VALU over 2 cycles)"}
         out = {
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,
@@ -437,6 +479,7 @@ def main():
                          "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
                          "gcups": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
+                         "valu": valu, "valu_frac": valu["frac_of_measured_peak"] if valu else None,
                          "note": "path is integer-VALU bound with DP state on chip; HBM fraction is reported because "
                                  "BASELINE asks for it (SURVEY.md 8d)"},
         }

@@ -926,7 +926,8 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       b->wfa_count = (int)wl.size();
       if (b->wfa_count) {
         wfa_layout(b->wfa, maxlen);
-        b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 2));
+        b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 4));
+        b->wfa_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->wfa_blocks, ws_budget_bytes() / std::max<uint64_t>(b->wfa.ws_stride, 1)));
         if ((rc = b->wfa_list.alloc(wl.size())) || (rc = b->wfa_ws.alloc((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
         e = hipMemcpy(b->wfa_list.p, wl.data(), wl.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa list", e));

@@ -178,11 +178,14 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
   if (go) {
     const uint8_t* cons = S.cons;
     const uint8_t* ref = S.ref;
+    // consensus and window made of A, C, G, T only (the usual case): the compare-free bit-vector passes give the same
+    // distances / locations / op strings as plain byte equality (lm_pure_acgt)
+    const int PM = (lm_pure_acgt(cons, 1, m, lane) && lm_pure_acgt(ref, 1, n, lane)) ? (LM_EQ | LM_EQFAST) : 0;
     // --- splitAlign, split.h:483-492
-    const LmRes pre = lm_hw(cons, m, ref, n / 3, 0, true, false, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
+    const LmRes pre = lm_hw(cons, m, ref, n / 3, PM, true, false, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
     const uint32_t csStart = (uint32_t)pre.startLoc;
     const int so = (int)((2ull * (uint64_t)n) / 3ull);
-    const LmRes suf = lm_hw(cons, m, ref + so, n - so, 0, false, false, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
+    const LmRes suf = lm_hw(cons, m, ref + so, n - so, PM, false, false, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
     const uint32_t csEnd = (uint32_t)suf.endLoc;
     if (lane == 0) {
       X.out->score_unsplit = (int32_t)csStart;
@@ -200,14 +203,14 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       } else {
-        const LmRes f = lm_shw(cs, csl, ref, n, 0, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
+        const LmRes f = lm_shw(cs, csl, ref, n, PM, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
         if (f.nops < 0) go = false;
         else lri_edit_distance_vec(opsL, f.nops, distF, lane);
         for (int i = lane; i < csl; i += WAVE) S.rcons[i] = rc_at(cs, csl, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (go) {
-          const LmRes r = lm_shw(S.rcons, csl, S.rref, n, 0, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
+          const LmRes r = lm_shw(S.rcons, csl, S.rref, n, PM, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
           if (r.nops < 0) go = false;
           else lri_edit_distance_vec(opsL, r.nops, distR, lane);
         }
@@ -235,8 +238,8 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
     le.nops = ri.nops = 0;
     uint32_t gaplen = 0, missingStart = 0, missingEnd = 0;
     if (go) {
-      le = lm_hw(cons, m, ref, bestJoin + 1, 0, true, true, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
-      ri = lm_hw(cons, m, ref + bestJoin + 1, n - bestJoin - 1, 0, true, true, bnd, bnd_stride, dirs, R.strip_words, tmp, opsR,
+      le = lm_hw(cons, m, ref, bestJoin + 1, PM, true, true, bnd, bnd_stride, dirs, R.strip_words, tmp, opsL, ops_cap, lane);
+      ri = lm_hw(cons, m, ref + bestJoin + 1, n - bestJoin - 1, PM, true, true, bnd, bnd_stride, dirs, R.strip_words, tmp, opsR,
                  ops_cap, lane);
       if (le.nops < 0 || ri.nops < 0) {
         if (lane == 0) X.out->status = DELLYHIP_E_LIMIT;

@@ -358,6 +358,156 @@ __device__ __noinline__ void lm_last_row_myers(const uint8_t* tp, int tstep, int
   __syncthreads();
 }
 
+// ---- bit-vector flavour of the location passes (edlib HW / SHW: distance + first / last optimal end row) -------------------
+// Same layout and column step as lm_last_row_myers.  HW: E[r][0] = 0 (all vertical deltas 0 at column 0), SHW / NW:
+// E[r][0] = r (all +1); E[0][c] = c either way.  At the last column every lane is frozen; E[r][qlen] = qlen + the
+// prefix sum of the vertical deltas of rows 1..r, which each lane rebuilds for its own rows from Pv / Mv behind a wave
+// prefix sum of the lanes' totals.  Keys as lm_pass: (E << LM_RBITS) | r and (E << LM_RBITS) | (LM_RMASK - r) over rows r0..tlen.
+template <int NWORDS>
+__device__ __noinline__ LmKeys lm_locate_myers(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, bool hw,
+                                               int r0, int lane) {
+  uint32_t* E = lm_eq_lds();
+  const int row0 = lane * 32 * NWORDS;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
+    const int lo = row0 + w * 32;
+    for (int q = 0; q < 32; ++q) {
+      const int r = lo + q;
+      if (r < tlen) {
+        const int x = iupac_index((int)tp[r * tstep]);
+        uint32_t pm = (1u << x) | iupac_partners(x);
+        while (pm) {
+          const int y = __builtin_ctz(pm);
+          pm &= pm - 1;
+          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
+        }
+      }
+    }
+  }
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = hw ? 0u : 0xffffffffu;
+    Mv[w] = 0;
+  }
+  const int lastlane = (tlen - 1) / (32 * NWORDS);
+  const int T = qlen + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 1;
+  int c = -lane;
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    const int y = (ci < qlen) ? iupac_index((int)qp[ci * qstep]) : -1;
+    return ((y < 0) ? 15 : y) * WAVE;
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+      const int newc = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      bs = dpp_from_prev(bs, newc);
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + bs + lane];
+      int hin = dpp_from_prev(hcarry, 1);
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)qlen;
+      uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        uint32_t Eq = EqC[w];
+        const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470
+        const uint32_t Xv = Eq | Mv[w];
+        Eq |= hinNeg;
+        const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+        uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+        uint32_t Mh = Pv[w] & Xh;
+        const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Mh |= hinNeg;
+        Ph |= (hin > 0) ? 1u : 0u;
+        nP[w] = Mh | ~(Xv | Ph);
+        nM[w] = Ph & Xv;
+        hin = hout;
+      }
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        Pv[w] = valid ? nP[w] : Pv[w];
+        Mv[w] = valid ? nM[w] : Mv[w];
+      }
+      hcarry = valid ? hin : hcarry;
+    }
+    chunk = chunk_next;
+  }
+  // column qlen: vertical deltas of this lane's rows (rows beyond tlen do not count)
+  int tot = 0;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, tlen - lo));                       // rows of this word inside the target
+    const uint32_t keep = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? ((1u << nb) - 1u) : 0u);
+    tot += __popc(Pv[w] & keep) - __popc(Mv[w] & keep);
+  }
+  int incl = tot;   // inclusive prefix sum over the lanes
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  int val = qlen + incl - tot;   // E[row0][qlen]: the row just above this lane's first row (row 0 for lane 0)
+  unsigned kf = 0xffffffffu, kl = 0xffffffffu;
+  if (lane == 0 && r0 == 0) {
+    kf = ((unsigned)qlen << LM_RBITS) | 0u;
+    kl = ((unsigned)qlen << LM_RBITS) | (unsigned)LM_RMASK;
+  }
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    const int lo = row0 + w * 32;
+#pragma unroll 1
+    for (int q = 0; q < 32; ++q) {
+      const int r = lo + q + 1;   // 1-based row of bit q
+      if (r <= tlen) {
+        val += (int)((Pv[w] >> q) & 1u) - (int)((Mv[w] >> q) & 1u);
+        if (r >= r0) {
+          kf = min(kf, ((unsigned)val << LM_RBITS) | (unsigned)r);
+          kl = min(kl, ((unsigned)val << LM_RBITS) | (unsigned)(LM_RMASK - r));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    kf = min(kf, (unsigned)__shfl_xor((int)kf, o));
+    kl = min(kl, (unsigned)__shfl_xor((int)kl, o));
+  }
+  LmKeys k;
+  k.kf = (unsigned)rfl((int)kf);
+  k.kl = (unsigned)rfl((int)kl);
+  __syncthreads();
+  return k;
+}
+
+// true when every letter of s[0..n) (stride `step`) is A, C, G, T or '-': among those the extended-IUPAC relation is plain
+// identity, so a plain-equality alignment (splitAlign, the superstring) may run the compare-free bit-vector passes
+__device__ __forceinline__ bool lm_pure_acgt(const uint8_t* sp, int step, int n, int lane) {
+  int bad = 0;
+  for (int i = lane; i < n; i += WAVE) {
+    const int ix = iupac_index((int)sp[i * step]);
+    bad |= (ix < 0 || ix > 4) ? 1 : 0;
+  }
+  return __ballot(bad) == 0ull;
+}
+
 // ---- bit-vector flavour of the traceback-regime path (the base-case rectangles of the Hirschberg split) ----------------
 // edlib's direction rule (INSERT > DELETE > diagonal, edlib.cpp:1018-1125) needs per cell only two bits the Myers
 // step has in hand: INSERT (left: a query letter alone) <=> the horizontal delta D[r][c] - D[r][c-1] is +1 (Ph),
@@ -697,6 +847,17 @@ __device__ __forceinline__ void lm_locate(const uint8_t* tp, int tstep, int tn, 
   const int Q = tn / LRS + 1;
   const int r0 = lm_first_row(qn);
   unsigned kf = 0xffffffffu, kl = 0xffffffffu;
+  if ((mode & LM_EQ) && (mode & LM_EQFAST) && tn >= 1 && qn >= 1 && tn <= MYERS_ROWS) {
+    const bool hw = (mode & LM_HW) != 0;
+    LmKeys k;
+    if (tn <= WAVE * 32) k = lm_locate_myers<1>(tp, tstep, tn, qp, qstep, qn, hw, r0, lane);
+    else if (tn <= WAVE * 64) k = lm_locate_myers<2>(tp, tstep, tn, qp, qstep, qn, hw, r0, lane);
+    else k = lm_locate_myers<3>(tp, tstep, tn, qp, qstep, qn, hw, r0, lane);
+    ed = (int)(k.kf >> LM_RBITS);
+    first = (int)(k.kf & (unsigned)LM_RMASK);
+    last = LM_RMASK - (int)(k.kl & (unsigned)LM_RMASK);
+    return;
+  }
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;

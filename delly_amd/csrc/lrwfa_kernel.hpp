@@ -151,6 +151,12 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       for (int r = 0; r < N; ++r)
         if (L.rlen[r] > A.ncap || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = DELLYHIP_E_LIMIT;
     }
+    // reads made of A, C, G, T only (the usual case): their plain-equality alignments may use the compare-free
+    // bit-vector passes (lm_pure_acgt); the superstring is pure while every read merged into it is
+    unsigned long long pure_reads = 0;
+    if (!status)
+      for (int r = 0; r < N; ++r)
+        if (lm_pure_acgt(blob + L.roff[r], 1, L.rlen[r], lane)) pure_reads |= 1ull << r;
     // reference anchors (src/assemble.h:855-856)
     int pn = 0, sn = 0;
     if (!status) {
@@ -245,6 +251,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       uint8_t* sup = supA;
       uint8_t* sup2 = supB;
       int sl = L.rlen[L.sel[0]];
+      bool sup_pure = ((pure_reads >> L.sel[0]) & 1ull) != 0;
       {
         const uint8_t* r0 = blob + L.roff[L.sel[0]];
         for (int k = lane; k < sl; k += WAVE) sup[k] = r0[k];
@@ -272,6 +279,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         } else if (preJ > preI && postJ > postI) {
           for (int k = lane; k < (int)lenJ; k += WAVE) sup[k] = rd[k];
           sl = (int)lenJ;
+          sup_pure = ((pure_reads >> L.sel[step]) & 1ull) != 0;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         } else {
@@ -279,8 +287,11 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           const uint8_t* sJ = (bd >= 0) ? rd : rd + (-bd);
           if ((int)seqlen > acap - 2 || seqlen == 0) { status = DELLYHIP_E_LIMIT; break; }
           // edlibAlign(seqI, seqJ, NW, PATH): query = seqI (columns), target = seqJ (rows)
-          const int nops = lm_nw_path(sJ, (int)seqlen, sI, (int)seqlen, 0, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+          const bool rd_pure = ((pure_reads >> L.sel[step]) & 1ull) != 0;
+          const int pmode = (sup_pure && rd_pure) ? (LM_EQ | LM_EQFAST) : 0;   // (identity among ACGT: same op string)
+          const int nops = lm_nw_path(sJ, (int)seqlen, sI, (int)seqlen, pmode, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
           if (nops < 0) { status = DELLYHIP_E_LIMIT; break; }
+          sup_pure = sup_pure && rd_pure;
           // buildSuperstring (:90-133)
           const bool f0 = preI > preJ;
           const int plen = f0 ? (int)preI : (int)preJ;
@@ -428,8 +439,10 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
             for (int k = lane; k < pn; k += WAVE) prev[k] = rc_at(pre, pn, k);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const LmRes f = lm_hw(cbuf, Lc, pre, pn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
-            const LmRes r = lm_hw(cbuf, Lc, prev, pn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            // (the consensus holds A, C, G, T only -- consensus_node; anchors without N etc. allow the bit-vector passes)
+            const int amode = (lm_pure_acgt(pre, 1, pn, lane) && lm_pure_acgt(suf, 1, sn, lane) && lm_pure_acgt(cbuf, 1, Lc, lane)) ? (LM_EQ | LM_EQFAST) : 0;
+            const LmRes f = lm_hw(cbuf, Lc, pre, pn, amode, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const LmRes r = lm_hw(cbuf, Lc, prev, pn, amode, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
             if (f.ed > r.ed) {   // reverseComplement(cs), util.h:549-563 semantics
               for (int k = lane; k < Lc; k += WAVE) astr[k] = rc_at(cbuf, Lc, k);
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -438,8 +451,8 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               __syncthreads();
             }
-            const LmRes cp = lm_hw(cbuf, Lc, pre, pn, 0, true, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
-            const LmRes cs2 = lm_hw(cbuf, Lc, suf, sn, 0, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const LmRes cp = lm_hw(cbuf, Lc, pre, pn, amode, true, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+            const LmRes cs2 = lm_hw(cbuf, Lc, suf, sn, amode, false, false, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
             const uint32_t csStart = (uint32_t)cp.startLoc, csEnd = (uint32_t)cs2.endLoc;
             if (csStart < csEnd && csEnd < (uint32_t)Lc) { o = (int)csStart; Lc = (int)(csEnd - csStart); }
           }

@@ -184,9 +184,9 @@ int dellyhip_batch_device_results(dellyhip_ctx* ctx, dellyhip_batch* b, void** d
  * launch stream; also returns the launch count. */
 int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_split,
                              double* ms_msa, int32_t* launches);
-/* Average duration (ms) of the dominant kernel alone -- the packed DP kernel
- * split_pair_kernel -- over the launches covered by the last
- * dellyhip_batch_kernel_ms() call (HIP events on the launch stream). */
+/* Average duration (ms) of the dominant kernel alone -- the packed DP kernel, split_quad_kernel<KQ, KP> (four
+ * junctions per wavefront; split_pair_kernel<K> for consensus sequences of 160 .. 319 bp) -- over the launches
+ * covered by the last dellyhip_batch_kernel_ms() call (HIP events on the launch stream). */
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
 /* ---- multi-GPU: junction sharding + gather of the results to one rank ------------------------ */
@@ -228,11 +228,11 @@ int dellyhip_gather_results_device(dellyhip_ctx* ctx, dellyhip_comm* comm, delly
 /* Long-read flavour of dellyhip_refine_batch: the loop body of src/assemble.h:833-872 for
  * non-insertion junctions -- msaEdlib(c, seqStore[svid], consensus) (src/assemble.h:383-473)
  * followed by alignConsensus(c, hdr, seq, NULL, sv, realign) with the `delly lr` parameters
- * (dellyhip_default_params_lr; realign = bit 0 of params.reserved).  Reads: at most 16 per
- * junction, each <= 24000 bytes and -- for the all-pairs distances -- at least one of every
- * two <= 6144 bytes.  svt 4 junctions take the insertion branch of the loop (:855-860):
- * msaWfa with the reference anchors around svStart, then alignConsensus with realign = false
- * (reads 8 .. 6144 bytes, superstring / alignment <= 8190 columns). */
+ * (dellyhip_default_params_lr; realign = bit 0 of params.reserved).  Reads: at most 32 per
+ * junction (maxReadPerSV, default 15), each <= 32000 bytes; consensus <= 12799.  svt 4 junctions take the
+ * insertion branch of the loop (:855-860): msaWfa with the reference anchors around svStart (<= 4096 bytes
+ * each: minConsWindow), then alignConsensus with realign = false (reads >= 8 bytes; superstring / alignment
+ * <= min(32766, 2 x longest read + 2048) columns). */
 int dellyhip_refine_batch_lr(dellyhip_ctx* ctx, int32_t n_junctions, const dellyhip_junction* junctions,
                              const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq,
                              dellyhip_result* results, char* out_blob, uint64_t out_blob_cap,
@@ -335,8 +335,8 @@ typedef struct dellyhip_nw_job {
   uint32_t target_len;
 } dellyhip_nw_job;
 
-/* distances[i] = editDistance of job i (max(len) if one string is empty, src/edlib.cpp:157-163), or
- * DELLYHIP_E_LIMIT when BOTH strings exceed 6144 bytes.  One job per 64-lane wavefront, Myers bit-vectors. */
+/* distances[i] = editDistance of job i (max(len) if one string is empty, src/edlib.cpp:157-163).  One job per
+ * 64-lane wavefront, Myers bit-vectors; pairs with both strings beyond 6144 bytes run in strips of 6144 rows. */
 int dellyhip_edit_distance_nw_batch(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_nw_job* jobs,
                                     const char* blob, uint64_t blob_len, int32_t* distances);
 /* Device-resident flavour (bench / pipelined callers), as dellyhip_jobs_*. */
@@ -373,7 +373,9 @@ int dellyhip_split_align(dellyhip_ctx* ctx, const char* cons, int32_t m, const c
  * ops receives the EDLIB_EDOP_* alignment of the first location (PATH).
  * Limits of this wrapper: targetLength <= 319, queryLength <= 2048 (the shapes
  * of the short-read insertion path; edlib's Hirschberg regime is not reached);
- * NW + DISTANCE (bit-vector kernel): min(queryLength, targetLength) <= 6144. */
+ * NW + DISTANCE (bit-vector kernel): min(queryLength, targetLength) <= 6144.
+ * (The batched entry points have no such limits: long strings go through dellyhip_refine_batch_lr /
+ * dellyhip_msa_edlib / dellyhip_msa_wfa / dellyhip_edit_distance_nw_batch.) */
 int dellyhip_edlib_align(dellyhip_ctx* ctx, const char* query, int32_t query_len, const char* target,
                          int32_t target_len, int32_t mode, int32_t task, int32_t out[4],
                          unsigned char* ops, int32_t ops_cap, int32_t* ops_len);

@@ -6,7 +6,7 @@
  * Plain-C restatement of the reference's split-read refinement algorithm
  * (dellytools/delly v2.5.1).  Pinned against the reference itself:
  * oracle/_ref/libdelly_ref.so compiles the reference's own headers, and
- * tests/test_oracle_vs_ref.py + tests/golden/ hold every function below to
+ * tests/test_oracle_golden.py + tests/golden/ hold every function below to
  * bit-identical outputs on seeded inputs (the reference ships no tests or
  * golden vectors of its own -- SURVEY.md F8).
  *

@@ -201,6 +201,22 @@ int run(const char* in_path, const char* out_path) {
     torali::_adjustOrientation(d, false, 6);   // translocation 5to5, near side: flipped
     wrs(out, a); wrs(out, b); wrs(out, d);
   }
+  // ---- pass 4: msa() on the host's own container, std::unordered_set<std::string> (src/shortpe.h:68):
+  // duplicates collapse in the set and the reads reach the device in the set's ITERATION order
+  {
+    const int nset = (mode == 1) ? std::min(n, 6) : 0;
+    wr(out, (int32_t)nset);
+    for (int k = 0; k < nset; ++k) {
+      std::unordered_set<std::string> us;
+      for (auto const& r : seqStore[k]) us.insert(r);
+      if (!seqStore[k].empty()) us.insert(seqStore[k][0]);   // a duplicate: no new element
+      std::string cs;
+      const int rows = torali::msa(c, us, cs);
+      wr(out, (int32_t)us.size());
+      wr(out, (int32_t)rows);
+      wrs(out, cs);
+    }
+  }
   out.close();
   return out ? 0 : 2;
 }

@@ -127,6 +127,21 @@ def test_cpp_msa_align_consensus_and_refine_batch_vs_reference(tmp_path, referen
     a, bb, d = rd.s(), rd.s(), rd.s()
     src = b"ACGTNacgtRYKM"
     assert a == reference.reverse_complement(src) and bb == src and d == reference.reverse_complement(src)
+    # std::unordered_set<std::string> as the read container -- duplicates collapse, iteration order is the input order
+    nset = rd.take("i")
+    assert nset == 6
+    order_matters = 0
+    for k in range(nset):
+        reads = b.seqs_of(k)
+        size, rows = rd.take("ii")
+        cs = rd.s()
+        perm = reference.unordered_set_order(reads + [reads[0]])
+        assert size == len(perm) == len(set(reads))
+        ordered = [(reads + [reads[0]])[i] for i in perm]
+        want_rows, want_cs = reference.msa(ordered)
+        assert (rows, cs) == (want_rows, want_cs), k
+        order_matters += reference.msa(reads)[1] != want_cs
+    # (the consensus usually does not depend on the order of six clean reads; the contract is that the device sees the set's order)
 
 
 def test_cpp_long_read_entry_points_vs_reference(tmp_path, reference):

@@ -1,12 +1,31 @@
-// Micro-benchmark: issue rate of the integer VALU ops the DP kernels are made of,
-// per SIMD, at a given number of resident waves per SIMD (gfx950).
-//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// Micro-benchmark (round 2): issue rate of the integer VALU ops the DP kernels are made of, per SIMD, at 1 / 2 / 4 / 8
+// resident wavefronts per SIMD, with INDEPENDENT chains (16 accumulators per lane: the throughput the issue port
+// sustains) and ONE DEPENDENT chain (every instruction reads the previous result: the latency a dependent recurrence
+// sees).  Kernels run >= 50 ms so that clock ramp and launch overhead do not matter.
+//   hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate.bin && tools/valu_rate.bin
+// Reference point (/opt/skills/guides/MI355X_MICROARCH.md): a SIMD issues a wave64 VALU instruction over 2 cycles
+// (32 lanes per cycle), i.e. 1.2 G wave-instructions/s per SIMD at 2.4 GHz (157.3 TFLOP/s fp32 = 1024 x 32 x 2 x 2.4e9).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define REP 16
-template <int OP>
+#define OPS(X)                                                                                         \
+  X(0, "v_add_u32", "v_add_u32 %0, %0, %1")                                                            \
+  X(1, "v_max_i32", "v_max_i32 %0, %0, %1")                                                            \
+  X(2, "v_max3_i32", "v_max3_i32 %0, %0, %1, %1")                                                      \
+  X(3, "v_pk_add_i16", "v_pk_add_i16 %0, %0, %1")                                                      \
+  X(4, "v_pk_max_i16", "v_pk_max_i16 %0, %0, %1")                                                      \
+  X(5, "v_mov_dpp_wave_shr", "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf")             \
+  X(6, "v_and_b32", "v_and_b32 %0, %0, %1")                                                            \
+  X(7, "v_bfi_b32", "v_bfi_b32 %0, %0, %1, %1")                                                        \
+  X(8, "v_lshl_add_u32", "v_lshl_add_u32 %0, %0, 2, %1")                                               \
+  X(9, "v_pk_ashrrev_i16", "v_pk_ashrrev_i16 %0, 15, %0")                                              \
+  X(10, "v_add3_u32", "v_add3_u32 %0, %0, %1, %1")                                                     \
+  X(11, "v_fma_f32", "v_fma_f32 %0, %0, %1, %1")
+
+template <int OP, bool DEP>
 __global__ void k(int* out, int iters, int seed) {
   int v[REP];
 #pragma unroll
@@ -15,26 +34,11 @@ __global__ void k(int* out, int iters, int seed) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < REP; ++i) {
-      if (OP == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 1) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 2) asm volatile("v_max3_i32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 3) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 4) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 5) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]) : "v"(b));
-      if (OP == 6) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(b));
-      if (OP == 7) asm volatile("v_cmp_eq_u32 vcc, %0, %1" ::"v"(v[i]), "v"(b) : "vcc");
-      if (OP == 8) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 9) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(long long*)&v[i & ~1]) : "v"(*(long long*)&v[i & ~1]));
-      if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 11) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(v[i]));
-      if (OP == 12) asm volatile("v_pk_mad_i16 %0, %0, %1, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 13) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 14) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 15) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 16) asm volatile("v_bfi_b32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 17) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(v[i]) : "v"(b));
-      if (OP == 18) asm volatile("v_pk_lshlrev_b16 %0, 2, %0" : "+v"(v[i]));
-      if (OP == 19) asm volatile("v_readlane_b32 s20, %0, 3" ::"v"(v[i]) : "s20");
+      int& x = v[DEP ? 0 : i];
+#define X(ID, NAME, ASM) \
+      if (OP == ID) asm volatile(ASM : "+v"(x) : "v"(b));
+      OPS(X)
+#undef X
     }
   }
   int s = 0;
@@ -43,53 +47,47 @@ __global__ void k(int* out, int iters, int seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int OP>
-void run(const char* name, int wavesPerSimd) {
-  int ncu = 256;
-  int blocks = ncu * 4 * wavesPerSimd;  // 64-thread blocks: one wave each
-  int iters = 4000;
+template <int OP, bool DEP>
+void run(const char* name, int wavesPerSimd, int ncu, FILE* f) {
+  const int blocks = ncu * 4 * wavesPerSimd;  // 64-thread blocks: one wave each
   int* out;
-  hipMalloc(&out, blocks * 64 * 4);
+  hipMalloc(&out, (size_t)blocks * 64 * 4);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  k<OP><<<blocks, 64>>>(out, 10, 1);
+  k<OP, DEP><<<blocks, 64>>>(out, 1000, 1);
   hipDeviceSynchronize();
-  hipEventRecord(a);
-  k<OP><<<blocks, 64>>>(out, iters, 1);
-  hipEventRecord(b);
-  hipEventSynchronize(b);
-  float ms;
-  hipEventElapsedTime(&ms, a, b);
-  double instr = (double)blocks * iters * REP;     // wave-instructions
-  double per_simd_per_s = instr / (ncu * 4) / (ms * 1e-3);
-  printf("%-16s waves/SIMD %d: %.3f ms, %.1f M wave-instr/s/SIMD  => %.2f cycles/instr @2.4GHz\n", name, wavesPerSimd,
-         ms, per_simd_per_s / 1e6, 2.4e9 / per_simd_per_s);
+  // calibrate to ~60 ms
+  int iters = 20000;
+  float ms = 0;
+  for (int round = 0; round < 2; ++round) {
+    hipEventRecord(a);
+    k<OP, DEP><<<blocks, 64>>>(out, iters, 1);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    hipEventElapsedTime(&ms, a, b);
+    if (round == 0) iters = (int)(iters * (60.0 / (ms > 0.01 ? ms : 0.01)));
+  }
+  const double instr = (double)blocks * iters * REP;     // wave-instructions
+  const double per_simd_per_s = instr / (ncu * 4) / (ms * 1e-3);
+  fprintf(f, "%-20s %-11s waves/SIMD %d: %7.2f ms, %7.1f M wave-instr/s/SIMD = %5.2f cycles/instr @2.4GHz\n", name,
+          DEP ? "dependent" : "independent", wavesPerSimd, ms, per_simd_per_s / 1e6, 2.4e9 / per_simd_per_s);
+  fflush(f);
   hipFree(out);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  const int ncu = prop.multiProcessorCount;
+  FILE* f = stdout;
+  fprintf(f, "# %s, %d CUs, clock %d MHz (prop.clockRate)\n", prop.gcnArchName, ncu, prop.clockRate / 1000);
   for (int w : {1, 2, 4, 8}) {
-    run<0>("v_add_u32", w);
-    run<1>("v_max_i32", w);
-    run<2>("v_max3_i32", w);
-    run<13>("v_add3_u32", w);
-    run<10>("v_lshl_add_u32", w);
-    run<11>("v_bfe_u32", w);
-    run<15>("v_xor_b32", w);
-    run<16>("v_bfi_b32", w);
-    run<6>("v_cndmask_b32", w);
-    run<7>("v_cmp_eq_u32", w);
-    run<5>("v_mov_dpp_wshr", w);
-    run<19>("v_readlane", w);
-    run<3>("v_pk_add_i16", w);
-    run<17>("v_pk_sub_i16", w);
-    run<4>("v_pk_max_i16", w);
-    run<14>("v_pk_min_u16", w);
-    run<12>("v_pk_mad_i16", w);
-    run<18>("v_pk_lshlrev_b16", w);
-    run<8>("v_fma_f32", w);
-    run<9>("v_pk_fma_f32", w);
+#define X(ID, NAME, ASM)               \
+    run<ID, false>(NAME, w, ncu, f);   \
+    if (w <= 2) run<ID, true>(NAME, w, ncu, f);
+    OPS(X)
+#undef X
   }
   return 0;
 }
