@@ -11,6 +11,7 @@
 // fetched 16 bytes per lane and load.  Probes of 65 .. 256 bytes (rare) go through the same code
 // with four words per probe in a second, small launch; wavefronts whose probes all fit 32 rows use 32-bit words.
 #pragma once
+#include "myers_kernel.hpp"
 #include "split_kernel.hpp"
 
 namespace dh {
@@ -28,6 +29,8 @@ struct ClsArgs {
   float flank_quality;
   int32_t* wide_list;    // one-word launch: jobs with a probe > 64 bytes are appended here ...
   int32_t* wide_count;   // ... and counted; the wide launch reads both
+  int32_t* big_list;     // wide launch: jobs with a probe > 256 bytes -> classify_big_kernel (one job per wavefront)
+  int32_t* big_count;
 };
 
 template <int NW>
@@ -190,6 +193,9 @@ __global__ __launch_bounds__(WAVE) void classify_kernel(ClsArgs A) {
       if (NW == 1) {   // hand over to the wide launch
         const int slot = atomicAdd(A.wide_count, 1);
         A.wide_list[slot] = (int32_t)idx;
+      } else if (max(m[0], m[1]) <= MYERS_ROWS) {   // ... to the one-job-per-wavefront launch
+        const int slot = atomicAdd(A.big_count, 1);
+        A.big_list[slot] = (int32_t)idx;
       } else {
         limit = true;
       }
@@ -262,6 +268,49 @@ __global__ __launch_bounds__(WAVE) void classify_kernel(ClsArgs A) {
             R.type = 'A';
             R.qual = (uint8_t)min(255, min((int)(scoreAlt * 35), (int)J.qual));
           }
+        }
+      }
+      A.res[idx] = R;
+    }
+  }
+}
+
+// probes of 257 .. 6144 bytes (a consensus-sized homology; practically never): one job per wavefront, the probe's rows cut
+// into 32-row words over the lanes (myers_hw_distance), exact byte comparison
+__global__ __launch_bounds__(WAVE) void classify_big_kernel(ClsArgs A) {
+  const int lane = threadIdx.x;
+  const int n_items = __builtin_amdgcn_readfirstlane(*A.big_count);
+  for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int idx = A.big_list[it];
+    const dellyhip_align_job J = A.jobs[idx];
+    const int m[2] = {(int)J.cons_len, (int)J.ref_len};
+    const int n = (int)J.seq_len;
+    const uint8_t* const probe[2] = {A.blob + J.cons_off, A.blob + J.ref_off};
+    const uint8_t* seq = A.blob + J.seq_off;
+    int best[2];
+    for (int p = 0; p < 2; ++p) {
+      if (m[p] == 0 || n == 0) best[p] = m[p];
+      else if (m[p] <= WAVE * 32) best[p] = myers_hw_distance<1>(probe[p], m[p], seq, n, lane);
+      else if (m[p] <= WAVE * 64) best[p] = myers_hw_distance<2>(probe[p], m[p], seq, n, lane);
+      else best[p] = myers_hw_distance<3>(probe[p], m[p], seq, n, lane);
+    }
+    if (lane == 0) {
+      dellyhip_align_result R{};
+      R.type = 'N';
+      const float fq = A.flank_quality;
+      R.dist_alt = cls_distance(best[0], m[0], n, fq);
+      R.dist_ref = cls_distance(best[1], m[1], n, fq);
+      const double scoreAlt = cls_score(R.dist_alt, m[0], fq);
+      const double scoreRef = cls_score(R.dist_ref, m[1], fq);
+      if (scoreRef > 0.7 || scoreAlt > 0.7) {   // src/coverage.h:424-433
+        R.sv_id = J.sv_id;
+        R.file_index = J.file_index;
+        if (scoreRef > scoreAlt) {
+          R.type = 'R';
+          R.qual = (uint8_t)min(255, min((int)(scoreRef * 35), (int)J.qual));
+        } else {
+          R.type = 'A';
+          R.qual = (uint8_t)min(255, min((int)(scoreAlt * 35), (int)J.qual));
         }
       }
       A.res[idx] = R;

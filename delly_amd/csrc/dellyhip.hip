@@ -867,7 +867,10 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     e = hipMemcpy(b->seq_off.p, seq_off, (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D offsets", e));
   }
-  e = hipMemset(b->res.p, 0, std::max(n, 1) * sizeof(dellyhip_result));
+  // (memsets go onto the context's stream and are waited for: hipMemset on the null stream returns before the fill is done
+  //  and is not ordered with a hipStreamNonBlocking stream -- a kernel launched there could be overwritten by the fill)
+  e = hipMemsetAsync(b->res.p, 0, std::max(n, 1) * sizeof(dellyhip_result), c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset results", e));
   b->h_cons_len.resize(n);
   if (!with_msa) {
@@ -931,7 +934,8 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         if ((rc = b->wfa_list.alloc(wl.size())) || (rc = b->wfa_ws.alloc((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
         e = hipMemcpy(b->wfa_list.p, wl.data(), wl.size() * sizeof(int32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa list", e));
-        e = hipMemset(b->wfa_ws.p, 0, (size_t)b->wfa.ws_stride * b->wfa_blocks);   // k-mer tables start (and are kept) all zero
+        e = hipMemsetAsync(b->wfa_ws.p, 0, (size_t)b->wfa.ws_stride * b->wfa_blocks, c->stream);   // k-mer tables start (and are kept) all zero
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa workspace", e));
         b->wfa.ws = b->wfa_ws.p;
       }
@@ -1448,8 +1452,8 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   HIPCHK(hipMemcpy(dblob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(doff.p, seq_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(dpf.p, pf, sizeof pf, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
-  HIPCHK(hipMemset(dedit.p, 0, dh::LM_NR * dh::LM_NR * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(dres.p, 0, sizeof(dellyhip_result), c->stream));   // (on the launch stream: see batch_upload_impl)
+  HIPCHK(hipMemsetAsync(dedit.p, 0, dh::LM_NR * dh::LM_NR * sizeof(int32_t), c->stream));
   if (pf[1] > 0) {
     dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p, dhb.p, hhalf};
     hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(pf[1]), dim3(dh::WAVE), 0, c->stream, pa);
@@ -1510,8 +1514,8 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
   HIPCHK(hipMemcpy(doff.p, seq_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (prefix_len) HIPCHK(hipMemcpy(dpre.p, prefix, prefix_len, hipMemcpyHostToDevice));
   if (suffix_len) HIPCHK(hipMemcpy(dsuf.p, suffix, suffix_len, hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(dres.p, 0, sizeof(dellyhip_result)));
-  HIPCHK(hipMemset(dws.p, 0, W.ws_stride));
+  HIPCHK(hipMemsetAsync(dres.p, 0, sizeof(dellyhip_result), c->stream));   // (on the launch stream: see batch_upload_impl)
+  HIPCHK(hipMemsetAsync(dws.p, 0, W.ws_stride, c->stream));
   W.junc = dj.p; W.seq_blob = dblob.p; W.seq_off = doff.p; W.p = c->params; W.res = dres.p;
   W.out_blob = dout.p; W.out_stride = W.acap; W.out_cons_cap = W.acap; W.cons_len = dlen.p;
   W.work_list = nullptr; W.n_work = 1; W.use_anchors = 0;
@@ -1561,7 +1565,8 @@ static int direct_pair(dellyhip_ctx* c, int svt, const char* s1, int32_t m, cons
   (void)hipMemcpy(b->ref_blob.p, s2, n, hipMemcpyHostToDevice);
   (void)hipMemcpy(b->ref_off.p, &zero, 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
-  (void)hipMemset(b->res.p, 0, sizeof(dellyhip_result));
+  (void)hipMemsetAsync(b->res.p, 0, sizeof(dellyhip_result), c->stream);
+  (void)hipStreamSynchronize(c->stream);
   if ((rc = build_bins(b, c->params))) return bail(rc);
   rc = dellyhip_batch_run(c, b, nullptr);
   dellyhip_result R;
@@ -1661,6 +1666,7 @@ struct dellyhip_jobs {
   DevBuf<uint8_t> blob;
   DevBuf<dellyhip_align_result> res;
   DevBuf<int32_t> wide;      // [0] = count, [1..] = job indices with a probe > 64 bytes
+  DevBuf<int32_t> big;       // [0] = count, [1..] = job indices with a probe > 256 bytes
   hipStream_t last_stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -1686,7 +1692,7 @@ int dellyhip_jobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_align_
   b->n = n_jobs;
   int rc;
   if ((rc = b->jobs.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->blob.alloc(blob_len + 2 * dh::CLS_PAD)) ||
-      (rc = b->res.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->wide.alloc(n_jobs + 1)))
+      (rc = b->res.alloc(std::max<uint64_t>(n_jobs, 1))) || (rc = b->wide.alloc(n_jobs + 1)) || (rc = b->big.alloc(n_jobs + 1)))
     return rc;
   if (n_jobs) HIPCHK(hipMemcpyAsync(b->jobs.p, jobs, n_jobs * sizeof(dellyhip_align_job), hipMemcpyHostToDevice, c->stream));
   if (blob_len) HIPCHK(hipMemcpyAsync(b->blob.p, blob, blob_len, hipMemcpyHostToDevice, c->stream));
@@ -1706,7 +1712,8 @@ int dellyhip_jobs_run(dellyhip_ctx* c, dellyhip_jobs* b, void* stream_) {
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   HIPCHK(hipMemsetAsync(b->wide.p, 0, sizeof(int32_t), st));
-  dh::ClsArgs a{b->jobs.p, b->blob.p, b->res.p, b->n, c->params.flank_quality, b->wide.p + 1, b->wide.p};
+  HIPCHK(hipMemsetAsync(b->big.p, 0, sizeof(int32_t), st));
+  dh::ClsArgs a{b->jobs.p, b->blob.p, b->res.p, b->n, c->params.flank_quality, b->wide.p + 1, b->wide.p, b->big.p + 1, b->big.p};
   const uint64_t groups = (b->n + dh::WAVE - 1) / dh::WAVE;
   const int grid = (int)std::min<uint64_t>(groups, (uint64_t)std::max(1, c->n_cu) * 64);
   HIPCHK(hipEventRecord(e0, st));
@@ -1714,6 +1721,8 @@ int dellyhip_jobs_run(dellyhip_ctx* c, dellyhip_jobs* b, void* stream_) {
   HIPCHK(hipEventRecord(e1, st));
   // probes of 65 .. 256 bytes (the list is usually empty: the launch then costs a few microseconds)
   hipLaunchKernelGGL(dh::classify_kernel<dh::CLS_MAXW>, dim3(std::max(1, c->n_cu)), dim3(dh::WAVE), 0, st, a);
+  // probes beyond 256 bytes (one job per wavefront; the list is practically always empty)
+  hipLaunchKernelGGL(dh::classify_big_kernel, dim3(std::max(1, c->n_cu)), dim3(dh::WAVE), 0, st, a);
   HIPCHK(hipGetLastError());
   b->pending.emplace_back(e0, e1);
   return 0;

@@ -317,9 +317,10 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_r
   (void)hipMemcpy(dj, &J, sizeof J, hipMemcpyHostToDevice);
   (void)hipMemcpy(dblob, seq_blob, blob_bytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(doff, seq_off, (n_reads + 1) * 8, hipMemcpyHostToDevice);
-  (void)hipMemset(dres, 0, sizeof(dellyhip_result));
-  (void)hipMemset(dcnt, 0, 64);
-  (void)hipMemset(dlen, 0, 4);
+  // (on the launch stream: hipMemset on the null stream is neither host-synchronous nor ordered with a non-blocking stream)
+  (void)hipMemsetAsync(dres, 0, sizeof(dellyhip_result), s);
+  (void)hipMemsetAsync(dcnt, 0, 64, s);
+  (void)hipMemsetAsync(dlen, 0, 4, s);
   MsaArgs A{};
   A.junc = dj; A.seq_blob = dblob; A.seq_off = doff; A.p = P; A.res = dres; A.out_blob = dout; A.out_stride = ccap;
   A.out_cons_cap = ccap;

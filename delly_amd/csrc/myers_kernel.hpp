@@ -153,6 +153,85 @@ __device__ __forceinline__ int myers_nw(const uint8_t* pattern, int pn, const ui
   return myers_nw_distance<3>(pattern, pn, text, tn, lane);
 }
 
+// edlib HW ("infix") DISTANCE of pattern[0..pn) inside text[0..tn): min over all text end columns of the last pattern row
+// with a free start (D[0][j] = 0, src/edlib.cpp:545-700); pn <= 64*32*NWORDS, both > 0.  Same layout as
+// myers_nw_distance; the horizontal delta entering the first row is 0 and the bottom score is tracked per column.
+template <int NWORDS>
+__device__ __noinline__ int myers_hw_distance(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int lane) {
+  MyersWord W[NWORDS];
+  uint32_t Pv[NWORDS], Mv[NWORDS], mk[NWORDS];
+  const int row0 = lane * 32 * NWORDS;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) W[w].eq[k] = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int r = row0 + w * 32 + b;
+      if (r < pn) {
+        const int code = myers_code((int)pattern[r]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (code == k) W[w].eq[k] |= 1u << b;
+      }
+    }
+    Pv[w] = 0xffffffffu;   // D[i][0] = i
+    Mv[w] = 0;
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, lo + 32 - pn));   // rows of this word at or beyond pn
+    mk[w] = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? (~0u << (32 - nb)) : 0u);
+  }
+  int score = row0 + 32 * NWORDS;
+  const int lastlane = (pn - 1) / (32 * NWORDS);
+  const int T = tn + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry = 0;
+  int b = NOMATCH;
+  int c = -lane;
+  int best = pn;           // column 0: D[pn][0] = pn
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int ci = blk * 16 + (lane & 15);
+    const int chunk = (ci < tn) ? (int)text[ci] : NOMATCH;
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      const int newc = __builtin_amdgcn_readlane(chunk, f);
+      b = dpp_from_prev(b, newc);
+      const int hin0 = dpp_from_prev(hcarry, 0);   // row 0 is free: D[0][j] - D[0][j-1] = 0
+      c += 1;
+      if ((unsigned)(c - 1) < (unsigned)tn) {
+        const int code = myers_code(b);
+        int hin = hin0;
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) {
+          uint32_t Eq;
+          if (code >= 0) Eq = code == 0 ? W[w].eq[0] : code == 1 ? W[w].eq[1] : code == 2 ? W[w].eq[2] : code == 3 ? W[w].eq[3] : W[w].eq[4];
+          else Eq = myers_eq_slow(pattern, pn, row0 + w * 32, b);
+          const uint32_t hinNeg = (hin < 0) ? 1u : 0u;
+          const uint32_t Xv = Eq | Mv[w];
+          Eq |= hinNeg;
+          const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+          uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+          uint32_t Mh = Pv[w] & Xh;
+          const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+          Ph <<= 1;
+          Mh <<= 1;
+          Mh |= hinNeg;
+          Ph |= (hin > 0) ? 1u : 0u;
+          Pv[w] = Mh | ~(Xv | Ph);
+          Mv[w] = Ph & Xv;
+          hin = hout;
+        }
+        hcarry = hin;
+        score += hin;
+        int s = score;   // D[pn][c] in the lane that owns row pn
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) s += __popc(Mv[w] & mk[w]) - __popc(Pv[w] & mk[w]);
+        best = min(best, s);
+      }
+    }
+  }
+  return __shfl(best, lastlane);
+}
+
 // any pattern length: strips of MYERS_ROWS rows; hb0 / hb1: two byte arrays of tn + 16 entries (global memory)
 __device__ __forceinline__ int myers_nw_big(const uint8_t* pattern, int pn, const uint8_t* text, int tn, int8_t* hb0, int8_t* hb1,
                                             int lane) {

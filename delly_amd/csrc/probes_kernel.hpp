@@ -9,7 +9,7 @@
 
 namespace dh {
 
-constexpr int PROBE_CAP = 2 * (MMAX + 1);   // bytes per probe slot (probe = 2*minimumFlankSize + homLeft + homRight)
+constexpr int PROBE_CAP = 1024;   // bytes per probe slot: probe = 2*minimumFlankSize + homLeft + homRight <= 2*13 + 2*319 on short-read shapes
 
 struct ProbeArgs {
   SplitArgs a;

@@ -13,15 +13,13 @@ FQ = {"plain": 0.95, "weird": 0.95, "lowq": 0.4}
 
 
 def _same(got, want, jobs):
-    """every field of the record; probes beyond the kernel limit must be flagged, never answered"""
-    big = np.maximum(jobs["cons_len"], jobs["ref_len"]) > 256
-    assert (got["status"][big] == abi.E_LIMIT).all() and (got["type"][big] == ord("N")).all()
-    ok = ~big
-    assert (got["status"][ok] == 0).all()
+    """every field of the record (probes beyond 256 bytes take the one-job-per-wavefront kernel since round 2: no
+    DELLYHIP_E_LIMIT below 6144 bytes)"""
+    assert (got["status"] == 0).all()
     for f in ("file_index", "sv_id", "dist_alt", "dist_ref", "type", "qual"):
-        bad = np.nonzero(got[f][ok] != want[f][ok])[0]
-        assert bad.size == 0, (f, bad[:8], got[f][ok][bad[:8]], want[f][ok][bad[:8]])
-    return int(ok.sum())
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, (f, bad[:8], got[f][bad[:8]], want[f][bad[:8]], jobs[bad[:8]])
+    return int(got.shape[0])
 
 
 def _ctx(fq):
@@ -92,3 +90,40 @@ def test_resident_jobs_large_batch(port):
     sel = np.arange(0, jobs.shape[0], 7)
     want = port.classify_reads(jobs[sel], blob)
     _same(a[sel], want, jobs[sel])
+
+
+def test_classifier_probes_beyond_256_bytes(reference):
+    """probes of 300 .. 900 bytes (long micro-homology): third launch, one job per wavefront"""
+    rng = np.random.default_rng(12)
+    parts, rows, pos = [], [], 0
+
+    def put(a):
+        nonlocal pos
+        parts.append(a)
+        o = pos
+        pos += a.size
+        return o
+    for k in range(12):
+        L = int(rng.integers(260, 900))
+        G = synth.ACGT[rng.integers(0, 4, 2 * L + 400)]
+        alt = np.concatenate([G[:L + 100], G[L + 300:]])
+        cons_probe = alt[100 - 13:100 + L + 13]        # spans the junction of the ALT haplotype
+        ref_probe = G[100 - 13:100 + L + 13]
+        co, ro = put(cons_probe), put(ref_probe)
+        for r in range(6):
+            src = alt if r % 2 == 0 else G
+            a = int(rng.integers(0, 60))
+            read = synth._mutate(rng, src[a:a + L + 200], 0.01)
+            so = put(read)
+            rows.append((co, ro, so, cons_probe.size, ref_probe.size, read.size, 0, k, int(rng.integers(0, 61))))
+    jobs = np.zeros(len(rows), dtype=abi.align_job_dtype())
+    for i, r in enumerate(rows):
+        for f, v in zip(("cons_off", "ref_off", "seq_off", "cons_len", "ref_len", "seq_len", "file_index", "sv_id", "qual"), r):
+            jobs[i][f] = v
+    blob = np.concatenate(parts)
+    want = reference.classify_reads(jobs, blob)
+    ctx = _ctx(0.95)
+    got = ctx.classify_reads(jobs, blob)
+    ctx.close()
+    _same(got, want, jobs)
+    assert len(set(bytes(got["type"]).decode())) >= 2
