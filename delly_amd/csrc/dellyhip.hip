@@ -98,6 +98,8 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int sparse_cost = 40;      // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
+  int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
@@ -393,8 +395,21 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   R.off_trF = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_stack = take((uint64_t)Q * R.strip_words * 4);
+  // sparse longNeedle (sparse_needle.hpp): furthest-reaching tables for up to 256 deficit levels of this batch's
+  // longest shapes (2 int16 per diagonal + 2 int32 per consensus row and level, both matrices) + the run lists
+  R.sparse_bytes = 0;
+  R.off_sparse = o;
+  R.sparse_cost = c->sparse_cost;
+  if (c->use_sparse) {
+    const uint64_t ndp = ((uint64_t)lr_n + lr_m + 2 + 63) & ~63ull;
+    const uint64_t per_level = 2 * ndp * 2 + 2 * (uint64_t)(lr_m + 1) * 4;
+    R.sparse_bytes = 4ull * 4096 * 4 + per_level * 256;
+    R.off_sparse = take(R.sparse_bytes);
+  }
   R.ws_stride = o;
-  b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * 4));
+  // resident wavefronts: the sparse passes are latency-bound on their table loads (L2 / HBM), so as many as the
+  // registers allow (156 VGPRs: 3 per SIMD) -- LDS permitting -- and the workspace budget holds
+  b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * (c->use_sparse ? 5 : 4)));
   b->lr_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lr_blocks, ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1)));
   int rc = b->lr_ws.reserve((size_t)R.ws_stride * b->lr_blocks);
   if (rc) return rc;
@@ -709,6 +724,8 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   c->params = *params;
   c->n_cu = prop.multiProcessorCount;
   if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
+  if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

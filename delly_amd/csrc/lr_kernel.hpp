@@ -22,6 +22,7 @@
 // and visits the strips in reverse order, so M row r = m - rho pops exactly what R pushed.
 #pragma once
 #include "myers_kernel.hpp"
+#include "sparse_needle.hpp"
 #include "split_main.hpp"
 
 namespace dh {
@@ -42,6 +43,9 @@ struct LrArgs {
   uint64_t off_rcons, off_ref, off_rref, off_bnd0, off_bnd1, off_br, off_trF, off_trR, off_stack;  // cons at 0
   uint64_t strip_words;   // code words per strip
   int32_t realign;        // src/split.h:564-572
+  uint64_t off_sparse;    // furthest-reaching tables of the sparse longNeedle (sparse_needle.hpp)
+  uint64_t sparse_bytes;  // 0: dense strip passes only
+  int32_t sparse_cost;    // predicted deficit beyond which the dense strips are taken (SparseWs::pred_cap)
 };
 
 struct StrPtr {           // the four strings of a junction (workspace)
@@ -54,6 +58,19 @@ struct StrPtr {           // the four strings of a junction (workspace)
 struct __attribute__((aligned(16))) PostLR {
   unsigned long long mV[LR_MASKW], mR[LR_MASKW], mE[LR_MASKW];
   int32_t cumV[LR_MASKW + 1], cumR[LR_MASKW + 1];
+};
+// the strip kernel's LDS: the phases of a junction use it one after the other -- orientation test (bit-vector masks),
+// sparse longNeedle (level tiles), column masks of the result
+struct __attribute__((aligned(16))) LrLds {
+  union {
+    PostLR post;
+    SpTile tile;
+    struct {
+      MyersLds<MYERS_NW> myers;
+      uint32_t eqB[MYERS_NW * 6 * WAVE];   // masks of the second pattern of the orientation test (myers_nw_fast2)
+    } o;
+  } u;
+  int16_t reachF[SP_LEVELS_MAX], reachR[SP_LEVELS_MAX];   // sparse longNeedle: furthest row per deficit level
 };
 
 // host + device: words of one strip's code stack
@@ -448,7 +465,9 @@ __device__ __forceinline__ int lr_dir_and_trace(const uint8_t* rowstr, const uin
 }
 
 // ---- one long-read junction per wavefront ------------------------------------------------
-__device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L, MyersLds<MYERS_NW>& ML, uint8_t* ws, int lane) {
+__device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane) {
+  PostLR& L = LL.u.post;
+  MyersLds<MYERS_NW>& ML = LL.u.o.myers;
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
   JCtx X;
@@ -526,7 +545,13 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   go = rfl((int)go) != 0;
+#ifdef DH_LR_TIMING
+  const unsigned long long tq0 = wall_clock64();
+#endif
+  int err_est = -1;   // consensus errors estimated from the orientation test (unknown without it)
   if (go && R.realign && m > 0 && n > 0) {
+    myers_lut_init(ML.lut, lane);   // (the LDS is shared with the later phases of the previous junction)
+    __syncthreads();
     // split.h:564-572: keep the orientation with the smaller NW edit distance to the window
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -537,8 +562,17 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
     int dF, dR;
     if (min(m, n) <= MYERS_ROWS) {
       if (m <= n) {
-        dF = rfl(myers_nw_auto(ML, S.cons, m, S.ref, n, lane));   // (pattern bytes are fetched 32 at a time: the strings sit inside the workspace)
-        dR = rfl(myers_nw_auto(ML, S.rcons, m, S.ref, n, lane));
+        // both orientations in one pass over the window (two patterns in lock-step)
+        bool two;
+        if (m <= WAVE * 32) two = myers_nw_fast2<1>(reinterpret_cast<MyersLds<1>&>(ML), LL.u.o.eqB, S.cons, S.rcons, m, S.ref, n, lane, dF, dR);
+        else if (m <= WAVE * 64) two = myers_nw_fast2<2>(reinterpret_cast<MyersLds<2>&>(ML), LL.u.o.eqB, S.cons, S.rcons, m, S.ref, n, lane, dF, dR);
+        else two = myers_nw_fast2<3>(ML, LL.u.o.eqB, S.cons, S.rcons, m, S.ref, n, lane, dF, dR);
+        if (!two) {   // a consensus byte outside ACGTN: exact-compare passes
+          dF = myers_nw(S.cons, m, S.ref, n, lane);
+          dR = myers_nw(S.rcons, m, S.ref, n, lane);
+        }
+        dF = rfl(dF);
+        dR = rfl(dR);
       } else {
         dF = rfl(myers_nw_auto(ML, S.ref, n, S.cons, m, lane));
         dR = rfl(myers_nw_auto(ML, S.ref, n, S.rcons, m, lane));
@@ -554,6 +588,8 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
         dR = rfl(myers_nw_big(S.ref, n, S.rcons, m, hb0, hb1, lane));
       }
     }
+    // the NW distance of the consensus to its window = the reference letters it skips (|n - m|) + its errors
+    err_est = max(0, min(dF, dR) - abs(n - m));
     if (dR < dF) {   // consensus = revc
       for (int i = lane; i < m; i += WAVE) {
         const uint8_t ch = S.rcons[i];
@@ -572,6 +608,105 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
   }
   X.go = go;
   X.uniformize();
+
+#ifdef DH_LR_TIMING
+  const unsigned long long tq1 = wall_clock64();
+  unsigned long long tq2 = tq1;
+  int spt = 0;
+#endif
+  // ---- longNeedle without the dense matrices (sparse_needle.hpp) when the letters are clean and the deficit budget suffices
+  bool sparse_done = false;
+  int spLtot = 0, spPosC = 0;
+  if (X.go && R.sparse_bytes > 0 && m >= 1 && n >= 1) {
+    int dirty = 0;
+    for (int i = lane; i < m; i += WAVE) dirty |= comp_acgtn(S.cons[i]) ? 0 : 1;   // (case matters: the forward pass compares raw bytes)
+    for (int i = lane; i < n; i += WAVE) dirty |= comp_acgtn(S.ref[i]) ? 0 : 1;
+    if (__ballot(dirty) == 0ull) {
+      SparseWs W;
+      W.ndp = (n + m + 2 + 63) & ~63;
+      const uint64_t per_level = 2ull * W.ndp * 2 + 2ull * (uint64_t)(m + 1) * 4;
+      const uint64_t runs_bytes = 4ull * 4096 * 4;
+      const long long lv = (R.sparse_bytes > runs_bytes) ? (long long)((R.sparse_bytes - runs_bytes) / per_level) : 0;
+      W.smax = (int)min((long long)SP_LEVELS_MAX, lv) - 1;
+      // (the orientation test's NW distance says little about the consensus errors: scattered chance matches inside the
+      //  skipped reference letters absorb them; the give-up rule is the prediction inside sparse_long_needle)
+      (void)err_est;
+      W.pred_cap = R.sparse_cost;
+      uint8_t* sp = ws + R.off_sparse;
+      W.runsF = reinterpret_cast<int32_t*>(sp);
+      W.runsR = W.runsF + 4096;
+      W.listF = W.runsR + 4096;
+      W.listR = W.listF + 4096;
+      W.runs_cap = 4096;
+      sp += runs_bytes;
+      const size_t levels = (size_t)(W.smax + 1);
+      W.frF = reinterpret_cast<int16_t*>(sp);
+      W.frR = W.frF + levels * W.ndp;
+      W.cF = reinterpret_cast<int32_t*>(W.frR + levels * W.ndp);
+      W.cR = W.cF + levels * (m + 1);
+      __syncthreads();
+      const SparseRes sr = sparse_long_needle(S.cons, S.rcons, S.ref, S.rref, m, n, W, LL.u.tile, LL.reachF, LL.reachR, lane);
+      __syncthreads();
+#ifdef DH_LR_TIMING
+      tq2 = wall_clock64();
+      if (sr.resolved && sr.found) {   // sparse phases, units of 50 us: levels | tables | join + refRight | traces
+        auto u8 = [](unsigned long long a, unsigned long long b) { return (int)min(255ull, (b - a) / 5000ull); };
+        spt = u8(tq1, sr.t[0]) | (u8(sr.t[0], sr.t[1]) << 8) | (u8(sr.t[1], sr.t[3]) << 16) | (u8(sr.t[3], sr.t[4]) << 24);
+      }
+#endif
+      if (sr.resolved) {
+        sparse_done = true;
+        if (lane == 0) {
+          X.out->score_unsplit = sr.unsplit;
+          X.out->score_best = sr.best;
+          X.out->cons_left = sr.found ? sr.consLeft : 0;
+          X.out->ref_left = sr.found ? sr.refLeft : 0;
+          X.out->ref_right = sr.found ? sr.refRight : n;   // (no split: the last column of the free-gap row m ties its maximum)
+          X.out->reserved = sr.levels;                     // diagnostic: deficit levels the sparse passes used
+        }
+        X.consLeft = sr.found ? sr.consLeft : 0;
+        X.refLeft = sr.found ? sr.refLeft : 0;
+        X.refRight = sr.found ? sr.refRight : 0;
+        X.consRight = m - X.consLeft;
+        X.go = sr.found != 0;
+        if (sr.found) {
+          const int gapref = (n - sr.refRight) - sr.refLeft;
+          long long total = gapref;
+          for (int i = lane; i < sr.nrunsF; i += WAVE) total += sp_ld32(W.runsF + i) & 0xffffff;
+          for (int i = lane; i < sr.nrunsR; i += WAVE) total += sp_ld32(W.runsR + i) & 0xffffff;
+          long long tsum = total - (lane ? gapref : 0);
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) {
+            const int lo = __shfl_xor((int)(tsum & 0xffffffffll), o), hi = __shfl_xor((int)(tsum >> 32), o);
+            tsum += ((long long)hi << 32) | (unsigned int)lo;
+          }
+          if (tsum > (long long)LR_MASKW * 64) {
+            if (lane == 0) X.out->status = DELLYHIP_E_LIMIT;
+            X.go = false;
+          } else {
+            spLtot = sparse_masks(L, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, LR_MASKW, lane, spPosC,
+                                  [](PostLR& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+            masks_finish(A, X, S, L, spLtot, spPosC, lane);
+          }
+        }
+        X.uniformize();
+      }
+    }
+  }
+  if (sparse_done) {
+#ifdef DH_LR_TIMING
+    const unsigned long long tq3 = wall_clock64();
+#endif
+    split_detect(A, X, S, L, X.go, spLtot, spPosC, lane);
+#ifdef DH_LR_TIMING
+    if (lane == 0) {   // phase times in units of 10 us (wall clock 100 MHz): orientation | sparse | masks | detect
+      const unsigned long long tq4 = wall_clock64();
+      auto u8 = [](unsigned long long a, unsigned long long b) { return (int)min(255ull, (b - a) / 5000ull); };
+      X.out->reserved = spt ? spt : (u8(tq0, tq1) | (u8(tq1, tq2) << 8) | (u8(tq2, tq3) << 16) | (u8(tq3, tq4) << 24));
+    }
+#endif
+    return;
+  }
 
   // ---- longNeedle: R strips, then M strips in reverse order
   const int Q = (m + 1 + LRS - 1) / LRS;
@@ -691,16 +826,13 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, PostLR& L
 }
 
 __global__ __launch_bounds__(WAVE) void lr_kernel(SplitArgs A, LrArgs R) {
-  __shared__ PostLR L;
-  __shared__ MyersLds<MYERS_NW> ML;
+  __shared__ LrLds L;
   const int lane = threadIdx.x;
-  myers_lut_init(ML.lut, lane);
-  __syncthreads();
   uint8_t* ws = R.ws + (size_t)blockIdx.x * R.ws_stride;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;
-    process_lr(A, R, j, L, ML, ws, lane);
+    process_lr(A, R, j, L, ws, lane);
   }
 }
 

@@ -378,6 +378,140 @@ __device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pa
   return __shfl(s, lastlane);
 }
 
+// Two patterns of the same length against one text in lock-step (the orientation test of _alignConsensus: consensus and
+// its reverse complement vs the window, src/split.h:564-572): one pass over the text, twice the independent work per
+// step.  L2: a second mask area for pattern B.  Returns false when a pattern holds bytes outside ACGTN (caller falls back).
+template <int NWORDS>
+__device__ __noinline__ bool myers_nw_fast2(MyersLds<NWORDS>& L, uint32_t* eqB, const uint8_t* patA, const uint8_t* patB, int pn,
+                                            const uint8_t* text, int tn, int lane, int& dA, int& dB) {
+  const int row0 = lane * 32 * NWORDS;
+  bool foreign = false;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const uint8_t* pattern = p ? patB : patA;
+    uint32_t* eqp = p ? eqB : L.eq;
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) {
+      uint32_t* slot = &eqp[w * 6 * WAVE + lane];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) slot[k * WAVE] = 0;
+      const int rbeg = row0 + w * 32;
+      if (rbeg < pn) {
+        uint4 v[2];
+        __builtin_memcpy(&v[0], pattern + rbeg, 16);
+        __builtin_memcpy(&v[1], pattern + rbeg + 16, 16);
+        const uint32_t wd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const int code = (int)L.lut[(wd[q >> 2] >> ((q & 3) * 8)) & 0xff];
+          const bool in = rbeg + q < pn;
+          foreign |= in && code == 5 * WAVE;
+          if (in) slot[code] |= 1u << q;
+        }
+      }
+      slot[5 * WAVE] = 0;
+    }
+  }
+  if (__ballot(foreign)) return false;
+  uint32_t Pv[2][NWORDS], Mv[2][NWORDS];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) {
+      Pv[p][w] = 0xffffffffu;
+      Mv[p][w] = 0;
+    }
+  int score[2] = {row0 + 32 * NWORDS, row0 + 32 * NWORDS};
+  const int lastlane = (pn - 1) / (32 * NWORDS);
+  const int T = tn + lastlane;
+  const int nblk = (T + 15) >> 4;
+  int hcarry[2] = {1, 1};
+  int c = -lane;
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    return (int)L.lut[(ci < tn) ? (int)text[ci] : 0];
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));
+  uint32_t EqN[2][NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    EqN[0][w] = L.eq[w * 6 * WAVE + bs + lane];
+    EqN[1][w] = eqB[w * 6 * WAVE + bs + lane];
+  }
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[2][NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        EqC[0][w] = EqN[0][w];
+        EqC[1][w] = EqN[1][w];
+      }
+      const int newc = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      bs = dpp_from_prev(bs, newc);
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        EqN[0][w] = L.eq[w * 6 * WAVE + bs + lane];
+        EqN[1][w] = eqB[w * 6 * WAVE + bs + lane];
+      }
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)tn;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        int hin = dpp_from_prev(hcarry[p], 1);
+        uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) {
+          uint32_t Eq = EqC[p][w];
+          const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470 (Hyyro's block step), 32-bit words
+          const uint32_t Xv = Eq | Mv[p][w];
+          Eq |= hinNeg;
+          const uint32_t Xh = (((Eq & Pv[p][w]) + Pv[p][w]) ^ Pv[p][w]) | Eq;
+          uint32_t Ph = Mv[p][w] | ~(Xh | Pv[p][w]);
+          uint32_t Mh = Pv[p][w] & Xh;
+          const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+          Ph <<= 1;
+          Mh <<= 1;
+          Mh |= hinNeg;
+          Ph |= (hin > 0) ? 1u : 0u;
+          nP[w] = Mh | ~(Xv | Ph);
+          nM[w] = Ph & Xv;
+          hin = hout;
+        }
+#pragma unroll
+        for (int w = 0; w < NWORDS; ++w) {
+          Pv[p][w] = valid ? nP[w] : Pv[p][w];
+          Mv[p][w] = valid ? nM[w] : Mv[p][w];
+        }
+        hcarry[p] = valid ? hin : hcarry[p];
+        score[p] += valid ? hin : 0;
+      }
+    }
+    chunk = chunk_next;
+  }
+  int out[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int s = score[p];
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) {
+      const int lo = row0 + w * 32;
+      const int nb = min(32, max(0, lo + 32 - pn));
+      if (nb > 0) {
+        const uint32_t mk = (nb >= 32) ? 0xffffffffu : (~0u << (32 - nb));
+        s -= __popc(Pv[p][w] & mk);
+        s += __popc(Mv[p][w] & mk);
+      }
+    }
+    out[p] = __shfl(s, lastlane);
+  }
+  dA = out[0];
+  dB = out[1];
+  return true;
+}
+
 // fast variant with the exact-compare fallback; L: one MyersLds<MYERS_NW> per wavefront, lut initialised
 __device__ __forceinline__ int myers_nw_auto(MyersLds<MYERS_NW>& L, const uint8_t* pattern, int pn, const uint8_t* text, int tn,
                                              int lane) {

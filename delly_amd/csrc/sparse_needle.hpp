@@ -1,0 +1,653 @@
+// sparse_needle.hpp -- gfx950 device code: longNeedle (src/needle.h:45-222) WITHOUT its dense matrices.
+//
+// The reference fills two (m+1) x (n+1) score matrices (forward, reverse complement), their row prefix maxima, scans
+// every cell for the best join and walks two tracebacks.  Everything it derives -- bestScore, (consLeft, refLeft),
+// refRight, the two paths -- only involves cells whose DEFICIT D[r][c] = r - mat[r][c] (0 on a perfect prefix match;
+// +2 per mismatch or consensus-only move, +1 per reference-only move) is at most s = m - bestScore:
+//   * a split path through forward cell (r, c) scores at most mat[r][c] + (m - r), so cells with D > s cannot carry it;
+//   * cells the tracebacks compare against SUCCESSFULLY lie on optimal paths too (a failed comparison stays failed when
+//     the neighbour's value is only known to be "worse than s");
+//   * the join winner, its first-row-major tie-break and refRight are decided among cells with D_F + D_R = s.
+// Cells of bounded deficit are described completely by furthest-reaching tables (Landau-Vishkin / WFA style):
+//   FR[d][k] = last row r on diagonal k = c - r whose deficit is <= d   (D is non-decreasing along a diagonal),
+// computed level by level from FR[d-1][k-1] (reference-only move), FR[d-2][k] + 1 (mismatch), FR[d-2][k+1] + 1
+// (consensus-only move), the free first row (D[0][c] = 0) and the first column (D[r][0] = 2r), each followed by a match
+// extension.  Work: (s+1) x (n+m+1) table entries per matrix instead of (m+1) x (n+1) cells -- ~25x fewer at the
+// long-read shapes (2 kb x 7 kb, s ~ 60), and the tracebacks need no direction matrices at all.
+// Row m (free trailing gap in the reference) is handled as the reference's prefix maximum: mat[m][c] = max over c' <= c of
+// the interior-rule value, so "first column with deficit <= d" is the same query as in every other row.
+//
+// Exactness: the CPU prototype tools/proto/sparse_needle.py restates this procedure and is bit-compared with a dense
+// restatement of the reference (itself checked against oracle/) on thousands of random and adversarial inputs (repeats,
+// low complexity, no-split, junk); the kernel is bit-compared with oracle/_ref by the -m gpu tests.  The procedure needs
+// clean letters (A, C, G, T, N, upper case: then reverseComplement is an involution and mat[m][n] == rev[m][n] always);
+// other inputs, and junctions not resolved at the deficit budget the workspace allows, take the dense strip passes.
+#pragma once
+#include "split_kernel.hpp"
+
+namespace dh {
+
+constexpr int SP_NEG = -30000;                 // "no cell of this cost on this diagonal" (int16 tables)
+constexpr int SP_INF = 0x3fffffff;
+constexpr int SP_LEVELS_MAX = 512;             // deficit levels 0 .. 511
+constexpr int SP_UNKNOWN = -(1 << 30);         // score_unsplit when mat[m][n] lies below the deficit budget (not needed for the result)
+
+struct SparseWs {
+  int16_t* frF;      // [level][ndp]
+  int16_t* frR;
+  int32_t* cF;       // [level][m + 1]: first column whose prefix-min deficit is <= level (SP_INF: none)
+  int32_t* cR;
+  int32_t* runsF;    // traceback runs, push order: (op << 24) | length, op 0 's', 1 'v', 2 'h'
+  int32_t* runsR;
+  int32_t* listF;    // diagonals deep enough to meet the other side (runs_cap entries each)
+  int32_t* listR;
+  int32_t ndp;       // level stride of frF / frR (>= n + m + 2)
+  int32_t smax;      // levels the workspace holds minus one
+  int32_t pred_cap;  // give up (dense passes) when the deficit predicted after the first level block exceeds this
+  int32_t runs_cap;
+};
+
+struct SparseRes {
+  int resolved;      // 0: deficit budget exhausted -> dense passes
+  int found;
+  int unsplit;       // mat[m][n] or SP_UNKNOWN
+  int best, consLeft, refLeft, refRight;
+  int nrunsF, nrunsR;
+  int levels;        // deficit levels used (diagnostic)
+  unsigned long long t[5];   // DH_LR_TIMING: wall clock after the levels, the first-column tables, the join, refRight, the traces
+};
+
+// The tables live in the wavefront's workspace, which it re-writes for every junction: table reads bypass the vector L1
+// (like ld_scratch, split_kernel.hpp), two int16 entries per aligned 32-bit load.
+__device__ __forceinline__ int sp_ld16(const int16_t* p) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+  const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t*>(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (int)(int16_t)((u & 2) ? (v >> 16) : (v & 0xffffu));
+}
+__device__ __forceinline__ int sp_ld32(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t sp_load8(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+// candidate row of diagonal q at level d from the two previous levels (before the match extension)
+__device__ __forceinline__ int sp_candidate(int d, int q, int k, int m, int n, int ND, int v1, int v1l, int v2, int v2r) {
+  int best = SP_NEG;
+  if (d == 0) {
+    if (k >= 0) best = 0;                                   // row 0, column k
+  } else {
+    best = v1;
+    if (q >= 1 && v1l >= 0 && v1l + k >= 1 && v1l + k <= n) best = max(best, v1l);            // reference-only move (r, c-1) -> (r, c)
+    if (d >= 2) {
+      if (v2 >= 0 && v2 + 1 <= m && v2 + 1 + k <= n && v2 + k >= 0) best = max(best, v2 + 1);  // mismatch (r, c) -> (r+1, c+1)
+      if (q + 1 < ND && v2r >= 0 && v2r + 1 <= m && v2r + 1 + k >= 0) best = max(best, v2r + 1);   // consensus-only move from diagonal k+1
+    }
+    if (k < 0 && 2 * (-k) <= d) best = max(best, -k);       // first column: D[r][0] = 2r
+  }
+  return best;
+}
+
+// match extension from row r on diagonal k, 8 letters per compare
+__device__ __forceinline__ int sp_extend(const uint8_t* a, const uint8_t* b, int m, int n, int r, int k) {
+  const int c = r + k;
+  const int lim = min(m - r, n - c);
+  int adv = 0;
+  while (adv < lim) {
+    const uint64_t z = sp_load8(a + r + adv) ^ sp_load8(b + c + adv);
+    if (z) {
+      adv += (int)(__builtin_ctzll(z) >> 3);
+      break;
+    }
+    adv += 8;
+  }
+  return r + min(adv, lim);
+}
+
+// one deficit level of BOTH matrices (forward: a = consensus, b = window; reverse: their reverse complements), two
+// chunks of 64 diagonals per iteration: four independent load / extend streams per wavefront.  reach[0] / reach[1] =
+// the furthest row reached on any diagonal of the forward / reverse matrix.
+__device__ __noinline__ void sp_level2(const uint8_t* __restrict__ aF, const uint8_t* __restrict__ bF, const uint8_t* __restrict__ aR,
+                                       const uint8_t* __restrict__ bR, int m, int n, int d, int16_t* __restrict__ FRf,
+                                       int16_t* __restrict__ FRr, int ndp, int lane, int (&reach)[2]) {
+  const int ND = n + m + 1;
+  int16_t* __restrict__ curF = FRf + (size_t)d * ndp;
+  int16_t* __restrict__ curR = FRr + (size_t)d * ndp;
+  const int16_t* __restrict__ p1F = FRf + (size_t)max(d - 1, 0) * ndp;
+  const int16_t* __restrict__ p2F = FRf + (size_t)max(d - 2, 0) * ndp;
+  const int16_t* __restrict__ p1R = FRr + (size_t)max(d - 1, 0) * ndp;
+  const int16_t* __restrict__ p2R = FRr + (size_t)max(d - 2, 0) * ndp;
+  int rf = SP_NEG, rr = SP_NEG;
+  for (int q0 = 0; q0 < ND; q0 += 2 * WAVE) {
+    int q[2], k[2], cf[2], cr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      q[u] = q0 + u * WAVE + lane;
+      k[u] = q[u] - m;
+      const bool in = q[u] < ND;
+      // (the level rows are padded to ndp >= ND + 1 entries; q - 1 = -1 is never used: guarded in sp_candidate)
+      const int qq = in ? q[u] : 0;
+      const int v1 = (d >= 1) ? (int)p1F[qq] : SP_NEG, v1l = (d >= 1 && qq >= 1) ? (int)p1F[qq - 1] : SP_NEG;
+      const int v2 = (d >= 2) ? (int)p2F[qq] : SP_NEG, v2r = (d >= 2) ? (int)p2F[qq + 1] : SP_NEG;
+      const int w1 = (d >= 1) ? (int)p1R[qq] : SP_NEG, w1l = (d >= 1 && qq >= 1) ? (int)p1R[qq - 1] : SP_NEG;
+      const int w2 = (d >= 2) ? (int)p2R[qq] : SP_NEG, w2r = (d >= 2) ? (int)p2R[qq + 1] : SP_NEG;
+      cf[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, v1, v1l, v2, v2r) : SP_NEG;
+      cr[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, w1, w1l, w2, w2r) : SP_NEG;
+    }
+    // match extension: the first 8 letters of all four streams in one batch of loads (a random diagonal mismatches
+    // within them: one load latency per iteration instead of four); only the rare long runs enter the loop
+    uint64_t zf[2], zr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rf0 = max(cf[u], 0), rr0 = max(cr[u], 0);
+      const int kk = (q[u] < ND) ? k[u] : 0;
+      // (addresses stay inside the padded strings: r <= m, c = r + k clamped into [0, n])
+      const int cfc = min(max(rf0 + kk, 0), n), crc = min(max(rr0 + kk, 0), n);
+      zf[u] = sp_load8(aF + rf0) ^ sp_load8(bF + cfc);
+      zr[u] = sp_load8(aR + rr0) ^ sp_load8(bR + crc);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (cf[u] >= 0) {
+        const int lim = min(m - cf[u], n - (cf[u] + k[u]));
+        const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
+        if (adv < 8 || lim <= 8) cf[u] += min(adv, lim);
+        else cf[u] = sp_extend(aF, bF, m, n, cf[u] + 8, k[u]);
+      }
+      if (cr[u] >= 0) {
+        const int lim = min(m - cr[u], n - (cr[u] + k[u]));
+        const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
+        if (adv < 8 || lim <= 8) cr[u] += min(adv, lim);
+        else cr[u] = sp_extend(aR, bR, m, n, cr[u] + 8, k[u]);
+      }
+      if (q[u] < ND) {
+        curF[q[u]] = (int16_t)cf[u];
+        curR[q[u]] = (int16_t)cr[u];
+      }
+      rf = max(rf, cf[u]);
+      rr = max(rr, cr[u]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    rf = max(rf, __shfl_xor(rf, o));
+    rr = max(rr, __shfl_xor(rr, o));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  reach[0] = rfl(rf);
+  reach[1] = rfl(rr);
+}
+
+// ---- level blocks in LDS -------------------------------------------------------------------------------------------
+// A level of diagonal q only needs the two previous levels of q-1 .. q+1, so a TILE of diagonals can be carried through a
+// BLOCK of SP_LB levels entirely in LDS when a halo of SP_LB diagonals on either side is recomputed (the valid region
+// shrinks by one diagonal per level and side: 2 x 16 / 960 = 3 % redundant work).  The table rows then cost LDS latency
+// instead of an L2 / HBM round trip per level; the global tables are only written (streaming) and read back once per
+// block.  The letters a tile can touch -- the whole consensus, window columns [k_lo, k_hi + m] -- are staged in LDS too
+// when they fit.
+constexpr int SP_LB = 16;                            // levels per block
+constexpr int SP_TW = 960;                           // valid diagonals per tile
+constexpr int SP_ROW = SP_TW + 2 * SP_LB + 64;       // LDS row: halo + slack for the second chunk of an iteration
+constexpr int SP_STR_CAP = 12288;                    // staged letters (both matrices)
+
+struct __attribute__((aligned(16))) SpTile {
+  int16_t row[2][3][SP_ROW];                         // [matrix][level % 3][diagonal - base]
+  uint8_t str[SP_STR_CAP];
+};
+
+// 8 letters at an arbitrary LDS byte offset: two aligned 8-byte reads + a funnel shift
+__device__ __forceinline__ uint64_t sp_lds8(const uint8_t* p) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(u & ~(uintptr_t)7);
+  const uint64_t lo = q[0], hi = q[1];
+  const int sh = (int)(u & 7) * 8;
+  return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+}
+
+// letters of one matrix for the extension: global strings (off = 0) or their staged copies (row letters at la, window
+// columns [c0, ...) at lb)
+struct SpStr {
+  const uint8_t* a;
+  const uint8_t* b;
+  int c0;            // window column of b[0]
+  bool lds;
+};
+__device__ __forceinline__ uint64_t sp_pair8(const SpStr& s, int r, int c) {
+  if (s.lds) return sp_lds8(s.a + r) ^ sp_lds8(s.b + (c - s.c0));
+  return sp_load8(s.a + r) ^ sp_load8(s.b + c);
+}
+__device__ __forceinline__ int sp_extend_s(const SpStr& s, int m, int n, int r, int k) {
+  const int c = r + k;
+  const int lim = min(m - r, n - c);
+  int adv = 0;
+  while (adv < lim) {
+    const uint64_t z = sp_pair8(s, r + adv, c + adv);
+    if (z) {
+      adv += (int)(__builtin_ctzll(z) >> 3);
+      break;
+    }
+    adv += 8;
+  }
+  return r + min(adv, lim);
+}
+
+// levels d0 .. d1 (at most SP_LB of them) of both matrices, tile by tile.  reachF / reachR (LDS) receive the furthest
+// row per level.  Levels d0 - 1 and d0 - 2 are read from the global tables.
+__device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+                                            int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, SpTile& T,
+                                            int16_t* reachF, int16_t* reachR, int lane) {
+  const int ND = n + m + 1;
+  const int nl = d1 - d0 + 1;
+  for (int d = d0 + lane; d <= d1; d += WAVE) { reachF[d] = (int16_t)SP_NEG; reachR[d] = (int16_t)SP_NEG; }
+  __syncthreads();
+  const bool stage = 2 * (2 * m + SP_TW + 2 * SP_LB + 64) <= SP_STR_CAP;
+  for (int tlo = 0; tlo < ND; tlo += SP_TW) {
+    const int thi = min(tlo + SP_TW, ND);
+    const int base = tlo - SP_LB - 1;                      // diagonal of LDS index 0
+    const int len = thi + SP_LB + 1 - base;                // <= SP_TW + 2 SP_LB + 2
+    // previous two levels of the tile + halo
+    for (int i = lane; i < len; i += WAVE) {
+      const int q = base + i;
+      const bool in = q >= 0 && q < ND;
+      T.row[0][(d0 + 2) % 3][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRf + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[1][(d0 + 2) % 3][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRr + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[0][(d0 + 1) % 3][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRf + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+      T.row[1][(d0 + 1) % 3][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRr + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+    }
+    // letters this tile can touch: rows 0 .. m, columns c = r + k, k in [tlo - SP_LB - m, thi + SP_LB - m)
+    SpStr sF{consF, refF, 0, false}, sR{consR, refR, 0, false};
+    if (stage) {
+      const int c0 = max(0, tlo - SP_LB - m) & ~7, c1 = min(n, thi + SP_LB);
+      const int wl = max(c1 - c0, 0);
+      const int am = (m + 16 + 7) & ~7, bw = (wl + 16 + 7) & ~7;
+      uint8_t* la0 = T.str;
+      uint8_t* lb0 = la0 + am;
+      uint8_t* la1 = lb0 + bw;
+      uint8_t* lb1 = la1 + am;
+      for (int i = lane; i < am; i += WAVE) { la0[i] = (i < m) ? consF[i] : (uint8_t)1; la1[i] = (i < m) ? consR[i] : (uint8_t)1; }
+      for (int i = lane; i < bw; i += WAVE) { lb0[i] = (i < wl) ? refF[c0 + i] : (uint8_t)2; lb1[i] = (i < wl) ? refR[c0 + i] : (uint8_t)2; }
+      sF = SpStr{la0, lb0, c0, true};
+      sR = SpStr{la1, lb1, c0, true};
+    }
+    __syncthreads();
+    for (int j = 0; j < nl; ++j) {
+      const int d = d0 + j;
+      const int halo = nl - 1 - j;
+      const int qa = max(tlo - halo, 0), qb = min(thi + halo, ND);
+      int16_t* curF = T.row[0][d % 3];
+      int16_t* curR = T.row[1][d % 3];
+      const int16_t* p1F = T.row[0][(d + 2) % 3];
+      const int16_t* p2F = T.row[0][(d + 1) % 3];
+      const int16_t* p1R = T.row[1][(d + 2) % 3];
+      const int16_t* p2R = T.row[1][(d + 1) % 3];
+      int16_t* gF = FRf + (size_t)d * ndp;
+      int16_t* gR = FRr + (size_t)d * ndp;
+      int rf = SP_NEG, rr = SP_NEG;
+      for (int q0 = qa; q0 < qb; q0 += 2 * WAVE) {
+        int q[2], k[2], cf[2], cr[2];
+        uint64_t zf[2], zr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          q[u] = q0 + u * WAVE + lane;
+          k[u] = q[u] - m;
+          const bool in = q[u] < qb;
+          const int i = (in ? q[u] : qa) - base;
+          const int v1 = (d >= 1) ? (int)p1F[i] : SP_NEG, v1l = (d >= 1) ? (int)p1F[i - 1] : SP_NEG;
+          const int v2 = (d >= 2) ? (int)p2F[i] : SP_NEG, v2r = (d >= 2) ? (int)p2F[i + 1] : SP_NEG;
+          const int w1 = (d >= 1) ? (int)p1R[i] : SP_NEG, w1l = (d >= 1) ? (int)p1R[i - 1] : SP_NEG;
+          const int w2 = (d >= 2) ? (int)p2R[i] : SP_NEG, w2r = (d >= 2) ? (int)p2R[i + 1] : SP_NEG;
+          cf[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, v1, v1l, v2, v2r) : SP_NEG;
+          cr[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, w1, w1l, w2, w2r) : SP_NEG;
+          const int rf0 = max(cf[u], 0), rr0 = max(cr[u], 0);
+          const int kk = in ? k[u] : 0;
+          const int cfc = min(max(rf0 + kk, sF.c0), n), crc = min(max(rr0 + kk, sR.c0), n);
+          zf[u] = sp_pair8(sF, rf0, cfc);
+          zr[u] = sp_pair8(sR, rr0, crc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (cf[u] >= 0) {
+            const int lim = min(m - cf[u], n - (cf[u] + k[u]));
+            const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
+            if (adv < 8 || lim <= 8) cf[u] += min(adv, lim);
+            else cf[u] = sp_extend_s(sF, m, n, cf[u] + 8, k[u]);
+          }
+          if (cr[u] >= 0) {
+            const int lim = min(m - cr[u], n - (cr[u] + k[u]));
+            const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
+            if (adv < 8 || lim <= 8) cr[u] += min(adv, lim);
+            else cr[u] = sp_extend_s(sR, m, n, cr[u] + 8, k[u]);
+          }
+          if (q[u] < qb) {
+            curF[q[u] - base] = (int16_t)cf[u];
+            curR[q[u] - base] = (int16_t)cr[u];
+            if (q[u] >= tlo && q[u] < thi) {
+              gF[q[u]] = (int16_t)cf[u];
+              gR[q[u]] = (int16_t)cr[u];
+              rf = max(rf, cf[u]);
+              rr = max(rr, cr[u]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        rf = max(rf, __shfl_xor(rf, o));
+        rr = max(rr, __shfl_xor(rr, o));
+      }
+      if (lane == 0) {
+        reachF[d] = (int16_t)max((int)reachF[d], rf);
+        reachR[d] = (int16_t)max((int)reachR[d], rr);
+      }
+      __syncthreads();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// cT[d][r] = min over diagonals k with FR[d][k] >= r (and r on the diagonal) of r + k, for rows rlo .. rhi, levels 0 .. S
+__device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
+  const int ND = n + m + 1;
+  const int rows = rhi - rlo + 1;
+  for (int d = 0; d <= S; ++d)
+    for (int i = lane; i < rows; i += WAVE) cT[(size_t)d * (m + 1) + rlo + i] = SP_INF;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int d = 0; d <= S; ++d) {
+    const int16_t* lv = FR + (size_t)d * ndp;
+    int32_t* row = cT + (size_t)d * (m + 1);
+    for (int q0 = 0; q0 < ND; q0 += WAVE) {
+      const int q = q0 + lane;
+      if (q < ND) {
+        const int v = sp_ld16(lv + q);
+        const int k = q - m;
+        const int lo = max(rlo, max(0, -k));
+        const int hi = min(v, rhi);
+        for (int r = lo; r <= hi; ++r) atomicMin(&row[r], r + k);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// the diagonals that reach row rlo at level S (FR is non-decreasing in the level: no other diagonal can reach it at a lower
+// one), compacted into list[]; returns their number or -1 when the list overflows
+__device__ __noinline__ int sp_deep_list(const int16_t* FR, int ndp, int m, int n, int S, int rlo, int32_t* list, int cap, int lane) {
+  const int ND = n + m + 1;
+  const int16_t* lv = FR + (size_t)S * ndp;
+  int cnt = 0;
+  for (int q0 = 0; q0 < ND; q0 += WAVE) {
+    const int q = q0 + lane;
+    const bool hit = (q < ND) && (sp_ld16(lv + min(q, ND - 1)) >= rlo);
+    const unsigned long long bm = __ballot(hit);
+    if (bm) {
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int pos = cnt + __popcll(bm & below);
+      if (hit && pos < cap) list[pos] = q;
+      cnt += __popcll(bm);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return (cnt <= cap) ? cnt : -1;
+}
+
+// sp_first_columns restricted to the listed diagonals
+__device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, int m, int S, int rlo, int rhi, const int32_t* list,
+                                                   int cnt, int32_t* cT, int lane) {
+  const int rows = rhi - rlo + 1;
+  for (int d = 0; d <= S; ++d)
+    for (int i = lane; i < rows; i += WAVE) cT[(size_t)d * (m + 1) + rlo + i] = SP_INF;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // work items = (level, listed diagonal), 64 at a time
+  const int items = (S + 1) * cnt;
+  for (int i0 = 0; i0 < items; i0 += WAVE) {
+    const int it = i0 + lane;
+    if (it < items) {
+      const int d = it / cnt, q = sp_ld32(list + (it - d * cnt));
+      const int v = sp_ld16(FR + (size_t)d * ndp + q);
+      const int k = q - m;
+      const int lo = max(rlo, max(0, -k));
+      const int hi = min(v, rhi);
+      int32_t* row = cT + (size_t)d * (m + 1);
+      for (int r = lo; r <= hi; ++r) atomicMin(&row[r], r + k);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// traceback from (r, c) with deficit D: the reference's rule (vertical, then horizontal, then diagonal; src/needle.h:154-192)
+// decided on the tables; runs in push order.  Returns the number of runs or -1 on overflow.  Wave-uniform.
+__device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane) {
+  const int ND = n + m + 1;
+  auto fr = [&](int d, int q) -> int { return (d < 0 || q < 0 || q >= ND) ? SP_NEG : sp_ld16(FR + (size_t)d * ndp + q); };
+  int nruns = 0, last_op = -1, last_len = 0;
+  auto emit = [&](int op, int len) {
+    if (len <= 0) return;
+    if (op == last_op) { last_len += len; return; }
+    if (last_op >= 0) {
+      if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
+      ++nruns;
+    }
+    last_op = op;
+    last_len = len;
+  };
+  r = rfl(r); c = rfl(c); D = rfl(D);
+  while (r > 0 || c > 0) {
+    if (r == 0) { emit(2, c); c = 0; break; }
+    if (c == 0) { emit(1, r); r = 0; break; }
+    const int k = c - r, q = k + m;
+    if (D >= 2 && rfl(fr(D - 2, q + 1)) >= r - 1) { emit(1, 1); --r; D -= 2; continue; }
+    if (D >= 1 && rfl(fr(D - 1, q - 1)) >= r) { emit(2, 1); --c; D -= 1; continue; }
+    // diagonal run at cost D: rows >= lowD of this diagonal cost D; a test passes at rows <= T
+    const int lowD = (D >= 1) ? max(rfl(fr(D - 1, q)) + 1, 0) : 0;
+    int T = SP_NEG;
+    if (D >= 2) T = max(T, rfl(fr(D - 2, q + 1)) + 1);
+    if (D >= 1) T = max(T, rfl(fr(D - 1, q - 1)));
+    const int start = max(0, -k);                       // first row of the diagonal (c = 0 or r = 0 there)
+    const int y = max(max(lowD, T + 1), start + 1);     // the lowest row the run still leaves diagonally
+    const int cnt = r - y + 1;                          // >= 1: the tests failed at row r
+    emit(0, cnt);
+    r -= cnt;
+    c -= cnt;
+    if (r < lowD) {                                     // crossed a mismatch: the cost of the cell we stand on now
+      int e = D - 1;
+      while (e >= 1 && rfl(fr(e - 1, q)) >= r) --e;
+      D = (rfl(fr(e, q)) >= r) ? e : D;                 // (e >= 0 always holds a cell here; defensive)
+    }
+  }
+  if (last_op >= 0) {
+    if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
+    ++nruns;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return (nruns <= cap) ? nruns : -1;
+}
+
+// The whole procedure for one junction (one wavefront).  cons / ref: clean letters; rcons / rref: their reverse
+// complements.  reach arrays in LDS (SP_LEVELS_MAX int16 each).
+__device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const uint8_t* rcons, const uint8_t* ref, const uint8_t* rref,
+                                                    int m, int n, const SparseWs& W, SpTile& T, int16_t* reachF, int16_t* reachR, int lane) {
+  SparseRes O;
+  O.resolved = 0; O.found = 0; O.unsplit = SP_UNKNOWN; O.best = 0; O.consLeft = O.refLeft = O.refRight = 0; O.nrunsF = O.nrunsR = 0; O.levels = 0;
+  const int ND = n + m + 1;
+  if (ND + 1 > W.ndp || m < 1 || n < 1 || W.smax < 4) return O;
+  int done = -1;           // levels 0 .. done are computed
+  int S = min(W.smax, 8);
+  for (;;) {
+    for (int d = done + 1; d <= S; d += SP_LB)
+      sp_level_block(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
+    __syncthreads();
+#ifdef DH_LR_TIMING
+    O.t[0] = wall_clock64();
+#endif
+    done = S;
+    // deficit of the unsplit (semi-global) alignment: first level that reaches row m
+    int du = -1;
+    for (int d0 = 0; d0 <= S && du < 0; d0 += WAVE) {
+      const int d = d0 + lane;
+      const unsigned long long hit = __ballot(d <= S && reachF[d] >= m);
+      if (hit) du = d0 + __builtin_ctzll(hit);
+    }
+    // rows where both sides have cells: forward reaches row r, reverse reaches row m - r
+    const int rhi = min(m, (int)reachF[S]), rlo = max(0, m - (int)reachR[S]);
+    long long key = 0x7fffffffffffffffll;      // (total deficit << 40) | (row << 20) | column
+    int dsel = 0;
+    int nlistR = -1;
+    if (rlo <= rhi) {
+      const int nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
+      nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
+      if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, lane);
+      else sp_first_columns(W.frF, W.ndp, m, n, S, rlo, rhi, W.cF, lane);
+      if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, S, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+      else sp_first_columns(W.frR, W.ndp, m, n, S, m - rhi, m - rlo, W.cR, lane);
+#ifdef DH_LR_TIMING
+      O.t[1] = wall_clock64();
+#endif
+      int dbest = 0;
+      for (int r0 = rlo; r0 <= rhi; r0 += WAVE) {
+        const int r = r0 + lane;
+        if (r <= rhi) {
+          // two pointers: minimal e for every d (first columns shrink with d, last allowed columns grow with e)
+          int e = S + 1;
+          long long kb = 0x7fffffffffffffffll;
+          int db = 0;
+          const int32_t* cf = W.cF + r;
+          const int32_t* cr = W.cR + (m - r);
+          for (int d = 0; d <= S; ++d) {
+            const int lo = sp_ld32(cf + (size_t)d * (m + 1));
+            if (lo > n) continue;
+            while (e >= 1) {
+              const int c2 = sp_ld32(cr + (size_t)(e - 1) * (m + 1));
+              if (c2 <= n && lo <= n - c2) --e;
+              else break;
+            }
+            if (e <= S && d + e <= S) {
+              const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
+              if (kk <= kb) { kb = kk; db = d; }   // ties in d + e: the larger d has the smaller (or equal) column
+            }
+          }
+          if (kb < key) { key = kb; dbest = db; }
+        }
+      }
+      // wave minimum of (key, d)
+      long long kmin = key;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const int lo = __shfl_xor((int)(kmin & 0xffffffffll), o), hi = __shfl_xor((int)(kmin >> 32), o);
+        const long long w = ((long long)hi << 32) | (unsigned int)lo;
+        kmin = w < kmin ? w : kmin;
+      }
+      const unsigned long long who = __ballot(key == kmin && key != 0x7fffffffffffffffll);
+      dsel = who ? __shfl(dbest, __builtin_ctzll(who)) : 0;
+      key = kmin;
+    }
+#ifdef DH_LR_TIMING
+    O.t[2] = wall_clock64();
+#endif
+    const bool have = key != 0x7fffffffffffffffll;
+    const int bestD = have ? (int)(key >> 40) : -1;
+    if (du >= 0 || have) {
+      O.resolved = 1;
+      O.levels = S;
+      O.unsplit = (du >= 0) ? m - du : SP_UNKNOWN;
+      if (!have || (du >= 0 && bestD >= du)) {     // no improving split (needle.h:152)
+        O.found = 0;
+        O.best = m - du;
+        return O;
+      }
+      O.found = 1;
+      O.best = m - bestD;
+      O.consLeft = (int)((key >> 20) & 0xfffff);
+      O.refLeft = (int)(key & 0xfffff);
+      const int cr_ = m - O.consLeft;
+      const int eR = bestD - dsel;
+      // refRight: last t <= n - refLeft with rev[consRight][t] at deficit eR (needle.h:119-123)
+      int rright = 0;
+      const int16_t* lv = W.frR + (size_t)eR * W.ndp;
+      if (nlistR >= 0) {   // (row consRight >= m - rhi: every diagonal that reaches it is listed)
+        for (int i0 = 0; i0 < nlistR; i0 += WAVE) {
+          const int i = i0 + lane;
+          if (i < nlistR) {
+            const int q = sp_ld32(W.listR + i), k = q - m, t = cr_ + k;
+            if (t >= 0 && t <= n - O.refLeft && sp_ld16(lv + q) >= cr_) rright = max(rright, t);
+          }
+        }
+      } else {
+        for (int q0 = 0; q0 < ND; q0 += WAVE) {
+          const int q = q0 + lane;
+          if (q < ND) {
+            const int k = q - m, t = cr_ + k;
+            if (t >= 0 && t <= n - O.refLeft && sp_ld16(lv + q) >= cr_) rright = max(rright, t);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) rright = max(rright, __shfl_xor(rright, o));
+      O.refRight = rfl(rright);
+#ifdef DH_LR_TIMING
+      O.t[3] = wall_clock64();
+#endif
+      O.nrunsF = sp_trace(W.frF, W.ndp, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane);
+      O.nrunsR = sp_trace(W.frR, W.ndp, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane);
+#ifdef DH_LR_TIMING
+      O.t[4] = wall_clock64();
+#endif
+      if (O.nrunsF < 0 || O.nrunsR < 0) O.resolved = 0;   // run list overflow: dense passes
+      return O;
+    }
+    if (S >= W.smax) return O;       // budget exhausted
+    // Not resolved at S: the deficit the junction will need, from how far S levels carried the two sides -- errors are
+    // roughly evenly spread, so covering all m consensus rows takes about S * m / (rows covered per side) levels.  Beyond
+    // pred_cap the dense strips are cheaper than more levels.
+    {
+      const long long covered = max(1, (int)reachF[S] + (int)reachR[S]);
+      const long long pred = (2ll * S * m) / covered;
+      if (pred > W.pred_cap) return O;
+    }
+    S = min(W.smax, S * 2);
+  }
+}
+
+// column masks of the glued alignment (needle.h:196-219) from the two run lists: forward trace reversed, the reference
+// gap, the reverse trace in push order.  PL / append as needle_masks (split_main.hpp).  Returns the number of columns.
+template <typename PL, typename APPEND>
+__device__ __forceinline__ int sparse_masks(PL& L, const int32_t* runsF, int nF, const int32_t* runsR, int nR, int gapref, int maskw,
+                                            int lane, int& posC, APPEND append) {
+  for (int w = lane; w < maskw; w += WAVE) {
+    L.mV[w] = 0;
+    L.mR[w] = 0;
+    L.mE[w] = 0;
+  }
+  __syncthreads();
+  int pos = 0;
+  auto put = [&](int op, int len) {
+    const unsigned long long v = (op != 2) ? ~0ull : 0ull, r = (op != 1) ? ~0ull : 0ull;
+    for (int k = 0; k < len; k += 64) {
+      append(L, pos, min(64, len - k), v, r, lane);
+      pos += min(64, len - k);
+    }
+  };
+  for (int i = nF - 1; i >= 0; --i) {
+    const int x = rfl(sp_ld32(runsF + i));
+    put(x >> 24, x & 0xffffff);
+  }
+  put(2, gapref);
+  posC = pos;
+  for (int i = 0; i < nR; ++i) {
+    const int x = rfl(sp_ld32(runsR + i));
+    put(x >> 24, x & 0xffffff);
+  }
+  return pos;
+}
+
+}  // namespace dh
