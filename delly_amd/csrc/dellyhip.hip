@@ -17,6 +17,7 @@
 #include "split_main.hpp"
 #include "split_pk.hpp"
 #include "split_quad.hpp"
+#include "split_sparse.hpp"
 #include "ins_kernel.hpp"
 #include "lr_kernel.hpp"
 #include "lrmsa_kernel.hpp"
@@ -98,6 +99,7 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
   int sparse_cost = 40;      // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
@@ -127,6 +129,8 @@ struct dellyhip_batch {
   DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
+  int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
+  int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
   std::vector<int32_t> qbin_first, qbin_count, qbin_pairs;   // per KQ: offset, quad items, pair items behind them
   int use_quad = 1, quad_mix = 0;
@@ -195,6 +199,7 @@ int ensure_scratch(dellyhip_ctx* c) {
   if (c->scratch.p) return 0;
   const uint64_t nblk = (dh::NMAX + 63 + 15) / 16 + 1;
   c->scratch_words = nblk * 2 * dh::KMAX * dh::WAVE;  // packed pair stack: 2 dwords per 16 steps per slot
+  c->scratch_words = std::max<uint64_t>(c->scratch_words, dh::sps_scratch_bytes() / 4 + 64);   // tables of split_sparse_kernel
   c->scratch_blocks = c->n_cu * 20;  // 5 waves per SIMD resident
   int rc = c->scratch.alloc((size_t)c->scratch_words * c->scratch_blocks);
   if (rc) return rc;
@@ -267,6 +272,13 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.ref_base = b->ref_blob.p;
     a.ref_off = b->ref_off.p;
     a.ref_len = b->ref_len.p;
+  }
+  if (b->sps_count > 0 && !direct) {   // sparse longNeedle first: the dense kernels below skip what it finishes
+    a.work_list = b->work.p + b->sps_first;
+    a.n_work = b->sps_count;
+    a.work_counter = c->counters.p + 30;
+    hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min(b->sps_count, c->scratch_blocks)), dim3(dh::WAVE), 0, s, a);
+    HIPCHK(hipGetLastError());
   }
   bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
@@ -514,7 +526,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->qbin_first.assign(7, 0);
   b->qbin_count.assign(7, 0);
   b->qbin_pairs.assign(7, 0);
-  std::vector<int32_t> ins, lrv, lriv;
+  std::vector<int32_t> ins, lrv, lriv, sparse;
   const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
@@ -536,6 +548,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     long span = (long)J.sv_end - (long)J.sv_start;
     int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
     if (!b->h_win_len.empty()) approx = b->h_win_len[i];
+    if (b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx + m + 1 <= dh::SPS_ND) sparse.push_back(i);
     if (b->use_quad && !direct && m + 1 <= dh::HALF * 5 && approx <= dh::QNMAX) {
       const int kq = std::max(1, (m + 1 + dh::HALF - 1) / dh::HALF);
       qbins[kq].push_back(std::make_pair(approx, i));
@@ -611,7 +624,10 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->lri_first = (int)work.size();
   b->lri_count = (int)lriv.size();
   work.insert(work.end(), lriv.begin(), lriv.end());
-  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)2 * b->n + 2 * dh::KMAX + 64));
+  b->sps_first = (int)work.size();
+  b->sps_count = (int)sparse.size();
+  work.insert(work.end(), sparse.begin(), sparse.end());
+  int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)3 * b->n + 2 * dh::KMAX + 64));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return 0;
@@ -725,6 +741,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   c->n_cu = prop.multiProcessorCount;
   if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
@@ -813,6 +830,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->want_alignment = want_alignment;
   b->use_quad = c->use_quad;
   b->quad_mix = c->quad_mix;
+  b->sr_sparse = c->sr_sparse;
   b->n_simd = c->n_cu * 4;
   b->h_junc.assign(junc, junc + n);
   int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;

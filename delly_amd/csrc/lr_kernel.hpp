@@ -645,7 +645,7 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL
       W.cF = reinterpret_cast<int32_t*>(W.frR + levels * W.ndp);
       W.cR = W.cF + levels * (m + 1);
       __syncthreads();
-      const SparseRes sr = sparse_long_needle(S.cons, S.rcons, S.ref, S.rref, m, n, W, LL.u.tile, LL.reachF, LL.reachR, lane);
+      const SparseRes sr = sparse_long_needle<SpTile, false>(S.cons, S.rcons, S.ref, S.rref, m, n, W, LL.u.tile, LL.reachF, LL.reachR, 8, lane);
       __syncthreads();
 #ifdef DH_LR_TIMING
       tq2 = wall_clock64();

@@ -190,14 +190,21 @@ __device__ __noinline__ void sp_level2(const uint8_t* __restrict__ aF, const uin
 // block.  The letters a tile can touch -- the whole consensus, window columns [k_lo, k_hi + m] -- are staged in LDS too
 // when they fit.
 constexpr int SP_LB = 16;                            // levels per block
-constexpr int SP_TW = 960;                           // valid diagonals per tile
-constexpr int SP_ROW = SP_TW + 2 * SP_LB + 64;       // LDS row: halo + slack for the second chunk of an iteration
-constexpr int SP_STR_CAP = 12288;                    // staged letters (both matrices)
-
-struct __attribute__((aligned(16))) SpTile {
-  int16_t row[2][3][SP_ROW];                         // [matrix][level % 3][diagonal - base]
-  uint8_t str[SP_STR_CAP];
+// TW = valid diagonals per tile, STRCAP = bytes for staged letters (both matrices; 0: the caller's strings are in LDS already),
+// ELEM = int16_t (rows as they are; "none" = SP_NEG) or uint8_t (row + 1, 0 = "none": consensus rows <= 254, half the LDS)
+template <int TW, int STRCAP, typename ELEM = int16_t>
+struct __attribute__((aligned(16))) SpTileT {
+  typedef ELEM elem_t;
+  static constexpr int tw = TW;
+  static constexpr int row_len = TW + 2 * SP_LB + 64;   // halo + slack for the second chunk of an iteration
+  static constexpr int str_cap = STRCAP;
+  static constexpr bool narrow = sizeof(ELEM) == 1;
+  ELEM row[2][3][TW + 2 * SP_LB + 64];                  // [matrix][level % 3][diagonal - base]
+  uint8_t str[STRCAP > 0 ? STRCAP : 8];
+  static __device__ __forceinline__ int dec(ELEM e) { return narrow ? (int)e - 1 : (int)e; }
+  static __device__ __forceinline__ ELEM enc(int v) { return narrow ? (ELEM)(max(v, -1) + 1) : (ELEM)v; }
 };
+typedef SpTileT<960, 12288> SpTile;                  // long reads: 3 % halo overhead, letters staged per tile
 
 // 8 letters at an arbitrary LDS byte offset: two aligned 8-byte reads + a funnel shift
 __device__ __forceinline__ uint64_t sp_lds8(const uint8_t* p) {
@@ -216,16 +223,19 @@ struct SpStr {
   int c0;            // window column of b[0]
   bool lds;
 };
+template <bool ALWAYS_LDS = false>
 __device__ __forceinline__ uint64_t sp_pair8(const SpStr& s, int r, int c) {
+  if (ALWAYS_LDS) return sp_lds8(s.a + r) ^ sp_lds8(s.b + c);
   if (s.lds) return sp_lds8(s.a + r) ^ sp_lds8(s.b + (c - s.c0));
   return sp_load8(s.a + r) ^ sp_load8(s.b + c);
 }
+template <bool ALWAYS_LDS = false>
 __device__ __forceinline__ int sp_extend_s(const SpStr& s, int m, int n, int r, int k) {
   const int c = r + k;
   const int lim = min(m - r, n - c);
   int adv = 0;
   while (adv < lim) {
-    const uint64_t z = sp_pair8(s, r + adv, c + adv);
+    const uint64_t z = sp_pair8<ALWAYS_LDS>(s, r + adv, c + adv);
     if (z) {
       adv += (int)(__builtin_ctzll(z) >> 3);
       break;
@@ -237,29 +247,36 @@ __device__ __forceinline__ int sp_extend_s(const SpStr& s, int m, int n, int r, 
 
 // levels d0 .. d1 (at most SP_LB of them) of both matrices, tile by tile.  reachF / reachR (LDS) receive the furthest
 // row per level.  Levels d0 - 1 and d0 - 2 are read from the global tables.
+// LDSSTR: the four strings are LDS arrays already (short-read kernel) -- no staging.  resume: the tile still holds levels
+// d0 - 1 and d0 - 2 of ALL diagonals from the previous call (single tile, LDS untouched since): no reload.
+template <typename TILE, bool LDSSTR>
 __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
-                                            int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, SpTile& T,
-                                            int16_t* reachF, int16_t* reachR, int lane) {
+                                            int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T,
+                                            int16_t* reachF, int16_t* reachR, bool resume, int lane) {
+  typedef typename TILE::elem_t elem_t;
+  constexpr bool lds_strings = LDSSTR;
+  constexpr int SP_TW = TILE::tw;
+  constexpr int SP_STR_CAP = TILE::str_cap;
   const int ND = n + m + 1;
   const int nl = d1 - d0 + 1;
   for (int d = d0 + lane; d <= d1; d += WAVE) { reachF[d] = (int16_t)SP_NEG; reachR[d] = (int16_t)SP_NEG; }
   __syncthreads();
-  const bool stage = 2 * (2 * m + SP_TW + 2 * SP_LB + 64) <= SP_STR_CAP;
+  const bool stage = !lds_strings && 2 * (2 * m + SP_TW + 2 * SP_LB + 64) <= SP_STR_CAP;
   for (int tlo = 0; tlo < ND; tlo += SP_TW) {
     const int thi = min(tlo + SP_TW, ND);
     const int base = tlo - SP_LB - 1;                      // diagonal of LDS index 0
     const int len = thi + SP_LB + 1 - base;                // <= SP_TW + 2 SP_LB + 2
     // previous two levels of the tile + halo
-    for (int i = lane; i < len; i += WAVE) {
+    for (int i = lane; i < len && !resume; i += WAVE) {
       const int q = base + i;
       const bool in = q >= 0 && q < ND;
-      T.row[0][(d0 + 2) % 3][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRf + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
-      T.row[1][(d0 + 2) % 3][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRr + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
-      T.row[0][(d0 + 1) % 3][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRf + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
-      T.row[1][(d0 + 1) % 3][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRr + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+      T.row[0][(d0 + 2) % 3][i] = TILE::enc((d0 >= 1 && in) ? sp_ld16(FRf + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[1][(d0 + 2) % 3][i] = TILE::enc((d0 >= 1 && in) ? sp_ld16(FRr + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[0][(d0 + 1) % 3][i] = TILE::enc((d0 >= 2 && in) ? sp_ld16(FRf + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+      T.row[1][(d0 + 1) % 3][i] = TILE::enc((d0 >= 2 && in) ? sp_ld16(FRr + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
     }
     // letters this tile can touch: rows 0 .. m, columns c = r + k, k in [tlo - SP_LB - m, thi + SP_LB - m)
-    SpStr sF{consF, refF, 0, false}, sR{consR, refR, 0, false};
+    SpStr sF{consF, refF, 0, lds_strings}, sR{consR, refR, 0, lds_strings};
     if (stage) {
       const int c0 = max(0, tlo - SP_LB - m) & ~7, c1 = min(n, thi + SP_LB);
       const int wl = max(c1 - c0, 0);
@@ -278,12 +295,12 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
       const int d = d0 + j;
       const int halo = nl - 1 - j;
       const int qa = max(tlo - halo, 0), qb = min(thi + halo, ND);
-      int16_t* curF = T.row[0][d % 3];
-      int16_t* curR = T.row[1][d % 3];
-      const int16_t* p1F = T.row[0][(d + 2) % 3];
-      const int16_t* p2F = T.row[0][(d + 1) % 3];
-      const int16_t* p1R = T.row[1][(d + 2) % 3];
-      const int16_t* p2R = T.row[1][(d + 1) % 3];
+      elem_t* curF = T.row[0][d % 3];
+      elem_t* curR = T.row[1][d % 3];
+      const elem_t* p1F = T.row[0][(d + 2) % 3];
+      const elem_t* p2F = T.row[0][(d + 1) % 3];
+      const elem_t* p1R = T.row[1][(d + 2) % 3];
+      const elem_t* p2R = T.row[1][(d + 1) % 3];
       int16_t* gF = FRf + (size_t)d * ndp;
       int16_t* gR = FRr + (size_t)d * ndp;
       int rf = SP_NEG, rr = SP_NEG;
@@ -296,17 +313,17 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
           k[u] = q[u] - m;
           const bool in = q[u] < qb;
           const int i = (in ? q[u] : qa) - base;
-          const int v1 = (d >= 1) ? (int)p1F[i] : SP_NEG, v1l = (d >= 1) ? (int)p1F[i - 1] : SP_NEG;
-          const int v2 = (d >= 2) ? (int)p2F[i] : SP_NEG, v2r = (d >= 2) ? (int)p2F[i + 1] : SP_NEG;
-          const int w1 = (d >= 1) ? (int)p1R[i] : SP_NEG, w1l = (d >= 1) ? (int)p1R[i - 1] : SP_NEG;
-          const int w2 = (d >= 2) ? (int)p2R[i] : SP_NEG, w2r = (d >= 2) ? (int)p2R[i + 1] : SP_NEG;
+          const int v1 = (d >= 1) ? TILE::dec(p1F[i]) : SP_NEG, v1l = (d >= 1) ? TILE::dec(p1F[i - 1]) : SP_NEG;
+          const int v2 = (d >= 2) ? TILE::dec(p2F[i]) : SP_NEG, v2r = (d >= 2) ? TILE::dec(p2F[i + 1]) : SP_NEG;
+          const int w1 = (d >= 1) ? TILE::dec(p1R[i]) : SP_NEG, w1l = (d >= 1) ? TILE::dec(p1R[i - 1]) : SP_NEG;
+          const int w2 = (d >= 2) ? TILE::dec(p2R[i]) : SP_NEG, w2r = (d >= 2) ? TILE::dec(p2R[i + 1]) : SP_NEG;
           cf[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, v1, v1l, v2, v2r) : SP_NEG;
           cr[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, w1, w1l, w2, w2r) : SP_NEG;
           const int rf0 = max(cf[u], 0), rr0 = max(cr[u], 0);
           const int kk = in ? k[u] : 0;
           const int cfc = min(max(rf0 + kk, sF.c0), n), crc = min(max(rr0 + kk, sR.c0), n);
-          zf[u] = sp_pair8(sF, rf0, cfc);
-          zr[u] = sp_pair8(sR, rr0, crc);
+          zf[u] = sp_pair8<LDSSTR>(sF, rf0, cfc);
+          zr[u] = sp_pair8<LDSSTR>(sR, rr0, crc);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -314,17 +331,17 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
             const int lim = min(m - cf[u], n - (cf[u] + k[u]));
             const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
             if (adv < 8 || lim <= 8) cf[u] += min(adv, lim);
-            else cf[u] = sp_extend_s(sF, m, n, cf[u] + 8, k[u]);
+            else cf[u] = sp_extend_s<LDSSTR>(sF, m, n, cf[u] + 8, k[u]);
           }
           if (cr[u] >= 0) {
             const int lim = min(m - cr[u], n - (cr[u] + k[u]));
             const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
             if (adv < 8 || lim <= 8) cr[u] += min(adv, lim);
-            else cr[u] = sp_extend_s(sR, m, n, cr[u] + 8, k[u]);
+            else cr[u] = sp_extend_s<LDSSTR>(sR, m, n, cr[u] + 8, k[u]);
           }
           if (q[u] < qb) {
-            curF[q[u] - base] = (int16_t)cf[u];
-            curR[q[u] - base] = (int16_t)cr[u];
+            curF[q[u] - base] = TILE::enc(cf[u]);
+            curR[q[u] - base] = TILE::enc(cr[u]);
             if (q[u] >= tlo && q[u] < thi) {
               gF[q[u]] = (int16_t)cf[u];
               gR[q[u]] = (int16_t)cr[u];
@@ -350,6 +367,46 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
   __syncthreads();
 }
 
+// First columns of one level without same-address atomics.  Diagonals k >= 0 come in ascending order and all start at
+// row 0, so diagonal k answers exactly the rows above everything the earlier ones reached: a running maximum (pm, uniform)
+// plus a prefix maximum over the 64 lanes of a chunk gives every lane its own, disjoint row range.
+__device__ __forceinline__ void sp_offer_chunk(int32_t* row, int rlo, int rhi, int k, int v, int& pm, int lane) {
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl = max(incl, t);
+  }
+  int excl = __shfl_up(incl, 1);
+  if (lane == 0) excl = SP_NEG;
+  const int from = max(max(excl, pm) + 1, rlo), to = min(v, rhi);
+  const int hs = min(to, from + 7);
+  for (int r = from; r <= hs; ++r) atomicMin(&row[r], r + k);
+  unsigned long long todo = __ballot(to > from + 7);     // (the few diagonals the alignment runs along: whole wavefront)
+  while (todo) {
+    const int src = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int f2 = __shfl(from, src) + 8, t2 = __shfl(to, src), k2 = __shfl(k, src);
+    for (int r = f2 + lane; r <= t2; r += WAVE) atomicMin(&row[r], r + k2);
+  }
+  pm = max(pm, __shfl(incl, WAVE - 1));
+}
+// Diagonals below the main one start at (row -k, column 0), a cell of deficit 2 |k|: at level d only the d / 2 diagonals
+// next to the main one hold cells.  Each offers its rows with the whole wavefront.
+__device__ __forceinline__ void sp_offer_negative(const int16_t* lv, int32_t* row, int m, int d, int rlo, int rhi, int lane) {
+  const int nneg = min(d / 2, m);
+  for (int i0 = 0; i0 < nneg; i0 += WAVE) {
+    const int i = i0 + lane;
+    const int v = (i < nneg) ? sp_ld16(lv + (m - 1 - i)) : SP_NEG;
+    const int cnt = min(WAVE, nneg - i0);
+    for (int t = 0; t < cnt; ++t) {
+      const int vt = __shfl(v, t), kt = -(i0 + t + 1);
+      const int lo = max(rlo, -kt), hi = min(vt, rhi);
+      for (int r = lo + lane; r <= hi; r += WAVE) atomicMin(&row[r], r + kt);
+    }
+  }
+}
+
 // cT[d][r] = min over diagonals k with FR[d][k] >= r (and r on the diagonal) of r + k, for rows rlo .. rhi, levels 0 .. S
 __device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
   const int ND = n + m + 1;
@@ -361,15 +418,12 @@ __device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m,
   for (int d = 0; d <= S; ++d) {
     const int16_t* lv = FR + (size_t)d * ndp;
     int32_t* row = cT + (size_t)d * (m + 1);
-    for (int q0 = 0; q0 < ND; q0 += WAVE) {
+    sp_offer_negative(lv, row, m, d, rlo, rhi, lane);
+    int pm = rlo - 1;
+    for (int q0 = m; q0 < ND && pm < rhi; q0 += WAVE) {
       const int q = q0 + lane;
-      if (q < ND) {
-        const int v = sp_ld16(lv + q);
-        const int k = q - m;
-        const int lo = max(rlo, max(0, -k));
-        const int hi = min(v, rhi);
-        for (int r = lo; r <= hi; ++r) atomicMin(&row[r], r + k);
-      }
+      const int v = (q < ND) ? sp_ld16(lv + q) : SP_NEG;
+      sp_offer_chunk(row, rlo, rhi, q - m, v, pm, lane);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -398,7 +452,7 @@ __device__ __noinline__ int sp_deep_list(const int16_t* FR, int ndp, int m, int 
   return (cnt <= cap) ? cnt : -1;
 }
 
-// sp_first_columns restricted to the listed diagonals
+// sp_first_columns restricted to the listed diagonals (ascending)
 __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, int m, int S, int rlo, int rhi, const int32_t* list,
                                                    int cnt, int32_t* cT, int lane) {
   const int rows = rhi - rlo + 1;
@@ -406,20 +460,33 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
     for (int i = lane; i < rows; i += WAVE) cT[(size_t)d * (m + 1) + rlo + i] = SP_INF;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // work items = (level, listed diagonal), 64 at a time
-  const int items = (S + 1) * cnt;
-  for (int i0 = 0; i0 < items; i0 += WAVE) {
-    const int it = i0 + lane;
-    if (it < items) {
-      const int d = it / cnt, q = sp_ld32(list + (it - d * cnt));
-      const int v = sp_ld16(FR + (size_t)d * ndp + q);
-      const int k = q - m;
-      const int lo = max(rlo, max(0, -k));
-      const int hi = min(v, rhi);
-      int32_t* row = cT + (size_t)d * (m + 1);
-      for (int r = lo; r <= hi; ++r) atomicMin(&row[r], r + k);
+  if (cnt <= WAVE) {       // the usual case: one chunk, its entries stay in registers, four levels' loads in flight
+    const int q = (lane < cnt) ? sp_ld32(list + lane) : -1;
+    const bool use = q >= m;                     // (diagonals below the main one: sp_offer_negative)
+    for (int d0 = 0; d0 <= S; d0 += 4) {
+      int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (use && d0 + u <= S) ? sp_ld16(FR + (size_t)(d0 + u) * ndp + q) : SP_NEG;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (d0 + u <= S) {
+          int pm = rlo - 1;
+          sp_offer_chunk(cT + (size_t)(d0 + u) * (m + 1), rlo, rhi, q - m, v[u], pm, lane);
+        }
+      }
+    }
+  } else {
+    for (int d = 0; d <= S; ++d) {
+      int pm = rlo - 1;
+      for (int i0 = 0; i0 < cnt && pm < rhi; i0 += WAVE) {
+        const int i = i0 + lane;
+        const int q = (i < cnt) ? sp_ld32(list + i) : -1;
+        const int v = (q >= m) ? sp_ld16(FR + (size_t)d * ndp + q) : SP_NEG;
+        sp_offer_chunk(cT + (size_t)d * (m + 1), rlo, rhi, q - m, v, pm, lane);
+      }
     }
   }
+  for (int d = 2; d <= S; ++d) sp_offer_negative(FR + (size_t)d * ndp, cT + (size_t)d * (m + 1), m, d, rlo, rhi, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
@@ -475,17 +542,20 @@ __device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, i
 
 // The whole procedure for one junction (one wavefront).  cons / ref: clean letters; rcons / rref: their reverse
 // complements.  reach arrays in LDS (SP_LEVELS_MAX int16 each).
+template <typename TILE, bool LDSSTR>
 __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const uint8_t* rcons, const uint8_t* ref, const uint8_t* rref,
-                                                    int m, int n, const SparseWs& W, SpTile& T, int16_t* reachF, int16_t* reachR, int lane) {
+                                                    int m, int n, const SparseWs& W, TILE& T, int16_t* reachF, int16_t* reachR,
+                                                    int s_first, int lane) {
   SparseRes O;
   O.resolved = 0; O.found = 0; O.unsplit = SP_UNKNOWN; O.best = 0; O.consLeft = O.refLeft = O.refRight = 0; O.nrunsF = O.nrunsR = 0; O.levels = 0;
   const int ND = n + m + 1;
   if (ND + 1 > W.ndp || m < 1 || n < 1 || W.smax < 4) return O;
   int done = -1;           // levels 0 .. done are computed
-  int S = min(W.smax, 8);
+  int S = min(W.smax, s_first);
   for (;;) {
-    for (int d = done + 1; d <= S; d += SP_LB)
-      sp_level_block(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
+    for (int d = done + 1; d <= S; d += SP_LB)   // (LDSSTR callers keep the tile to themselves between rounds: a single tile resumes)
+      sp_level_block<TILE, LDSSTR>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR,
+                                   LDSSTR && d > 0 && ND <= TILE::tw, lane);
     __syncthreads();
 #ifdef DH_LR_TIMING
     O.t[0] = wall_clock64();

@@ -70,6 +70,7 @@ struct SplitArgs {
 };
 
 constexpr int DH_DEFERRED = 1;  // transient result.status: not representable in the packed kernel
+constexpr int SPS_DONE = 2;     // transient result.reserved: finished by split_sparse_kernel (the dense kernels skip the junction)
 
 constexpr int OUT_CONS_CAP = MMAX + 1;
 constexpr int OUT_ALLELE_CAP = NMAX + MMAX + 8;

@@ -362,7 +362,11 @@ __global__ __launch_bounds__(WAVE, DH_PAIR_WAVES) void split_pair_kernel(SplitAr
     if (lane == 0) w = atomicAdd(A.work_counter, 1);
     w = rfl(w);
       if (w >= A.n_work) break;
-    process_pair<K>(A, A.work_list[2 * w], A.work_list[2 * w + 1], L, scratch, lane);
+    int ja = A.work_list[2 * w], jb = A.work_list[2 * w + 1];   // (junctions finished by the sparse kernel: empty seats)
+    if (ja >= 0 && rfl(A.res[ja].reserved) == SPS_DONE) ja = -1;
+    if (jb >= 0 && rfl(A.res[jb].reserved) == SPS_DONE) jb = -1;
+    if (ja < 0) { ja = jb; jb = -1; }
+    if (ja >= 0) process_pair<K>(A, ja, jb, L, scratch, lane);
     }
 }
 

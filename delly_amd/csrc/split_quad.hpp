@@ -358,11 +358,28 @@ __global__ __launch_bounds__(WAVE, DH_QUAD_WAVES) void split_quad_kernel(SplitAr
     w = rfl(w);
     if (w >= A.n_work) break;
     if (w < n_quads) {
-      const int jq[4] = {A.work_list[4 * w], A.work_list[4 * w + 1], A.work_list[4 * w + 2], A.work_list[4 * w + 3]};
-      process_quad<KQ>(A, jq, L.q, scratch, lane);
+      // seats whose junction the sparse kernel already finished are empty; live junctions move to the front
+      int jq[4] = {-1, -1, -1, -1};
+      int nlive = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = A.work_list[4 * w + q];
+        if (j >= 0 && rfl(A.res[j].reserved) != SPS_DONE) {
+          if (nlive == 0) jq[0] = j;
+          else if (nlive == 1) jq[1] = j;
+          else if (nlive == 2) jq[2] = j;
+          else jq[3] = j;
+          ++nlive;
+        }
+      }
+      if (nlive > 0) process_quad<KQ>(A, jq, L.q, scratch, lane);
     } else {
       const int32_t* pl = A.work_list + 4 * n_quads + 2 * (w - n_quads);
-      process_pair<KP>(A, pl[0], pl[1], L.p, scratch, lane);
+      int ja = pl[0], jb = pl[1];
+      if (ja >= 0 && rfl(A.res[ja].reserved) == SPS_DONE) ja = -1;
+      if (jb >= 0 && rfl(A.res[jb].reserved) == SPS_DONE) jb = -1;
+      if (ja < 0) { ja = jb; jb = -1; }
+      if (ja >= 0) process_pair<KP>(A, ja, jb, L.p, scratch, lane);
     }
     __syncthreads();
   }

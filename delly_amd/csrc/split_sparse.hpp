@@ -1,0 +1,151 @@
+// split_sparse.hpp -- short-read alignConsensus (svt != 4) through the SPARSE longNeedle of sparse_needle.hpp: one
+// junction per wavefront, furthest-reaching tables instead of the packed dense DP of split_quad.hpp / split_pk.hpp.
+//
+// A 150 bp consensus against a 1 kb window has 151 x 1001 cells per matrix, but a junction whose consensus carries
+// e errors is decided by the cells of deficit <= ~2.5 e: (levels) x (1151 diagonals) table entries.  BASELINE's C2
+// consensus sequences (0.5 % substitutions) need 1 .. 9 levels (47 % none, 83 % <= 2, 99.9 % <= 8), so the kernel
+// raises the level count per junction (2, 4, 8, 16, 32) and stops as soon as the junction is resolved; what is not
+// resolved at 32 levels -- or has letters outside A, C, G, T, N, a consensus beyond 254 bp or a window beyond
+// SPS_ND diagonals -- is left to the dense kernels, which skip every junction this kernel finished
+// (result.reserved == SPS_DONE).  Everything after the alignment (column masks, _findSplit, _percentIdentity,
+// homology, coordinates, alleles) is the shared split_detect stage.
+#pragma once
+#include "sparse_needle.hpp"
+#include "split_main.hpp"
+
+namespace dh {
+
+constexpr int SPS_MMAX = 254;                 // consensus rows the short-read sparse path takes
+constexpr int SPS_ND = 1408;                  // diagonals (n + m + 1): one tile, no halo
+constexpr int SPS_SMAX = 32;                  // deficit levels before the dense kernels take over
+constexpr int SPS_LIST = 1024;                // run / deep-diagonal list capacity
+typedef SpTileT<SPS_ND, 0, uint8_t> SpsTile;  // rows <= 254 fit a byte: 9 KB for the three rolling levels of both matrices
+
+// the junction's strings and the post stage's masks, sized for this kernel's shapes (12.5 KB of LDS per wavefront with
+// the tile: 12 wavefronts per CU)
+struct __attribute__((aligned(16))) StrLdsS {
+  static constexpr bool has_rc = true;
+  static constexpr int ref_cap = SPS_ND;
+  static constexpr int cons_cap = SPS_MMAX + 2;
+  uint8_t cons[SPS_MMAX + 2];
+  uint8_t rcons[SPS_MMAX + 2];
+  uint8_t ref[SPS_ND];
+  uint8_t rref[SPS_ND];
+};
+struct __attribute__((aligned(16))) PostLdsS {
+  unsigned long long mV[MASKW], mR[MASKW], mE[MASKW];
+  int32_t cumV[MASKW + 1], cumR[MASKW + 1];
+};
+struct __attribute__((aligned(16))) SpsLds {
+  StrLdsS s;
+  union {
+    PostLdsS p;
+    SpsTile t;
+  } u;
+  int16_t reachF[SPS_SMAX + 2], reachR[SPS_SMAX + 2];
+};
+
+// bytes of per-wavefront global scratch the kernel needs
+__host__ __device__ inline uint64_t sps_scratch_bytes() {
+  const uint64_t ndp = (SPS_ND + 2 + 63) & ~63;
+  return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp * 2 + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
+}
+
+__device__ void process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
+#ifdef DH_LR_TIMING
+  const unsigned long long tq0 = wall_clock64();
+#endif
+  JCtx X;
+  junction_setup<KMAX, true, StrLdsS>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
+  if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
+    if (lane == 0 && X.out->status == 0) X.out->reserved = SPS_DONE;
+    return;
+  }
+  const int m = X.m, n = X.n;
+  if (m < 1 || n < 1 || m > SPS_MMAX || n + m + 1 > SPS_ND) return;   // dense kernels
+  int dirty = 0;
+  for (int i = lane; i < m; i += WAVE) dirty |= comp_acgtn(L.s.cons[i]) ? 0 : 1;   // (case matters: the forward pass compares raw bytes)
+  for (int i = lane; i < n; i += WAVE) dirty |= comp_acgtn(L.s.ref[i]) ? 0 : 1;
+  if (__ballot(dirty) != 0ull) return;
+  SparseWs W;
+  W.ndp = (n + m + 2 + 63) & ~63;
+  W.smax = SPS_SMAX;
+  W.pred_cap = 1 << 20;     // (never give up early: an unresolved junction costs a whole dense wavefront of ~1 ms)
+  W.runs_cap = SPS_LIST;
+  uint8_t* sp = reinterpret_cast<uint8_t*>(scratch);
+  W.runsF = reinterpret_cast<int32_t*>(sp);
+  W.runsR = W.runsF + SPS_LIST;
+  W.listF = W.runsR + SPS_LIST;
+  W.listR = W.listF + SPS_LIST;
+  sp += 4ull * SPS_LIST * 4;
+  W.frF = reinterpret_cast<int16_t*>(sp);
+  W.frR = W.frF + (size_t)(SPS_SMAX + 1) * W.ndp;
+  W.cF = reinterpret_cast<int32_t*>(W.frR + (size_t)(SPS_SMAX + 1) * W.ndp);
+  W.cR = W.cF + (size_t)(SPS_SMAX + 1) * (m + 1);
+  __syncthreads();
+#ifdef DH_LR_TIMING
+  const unsigned long long tq1 = wall_clock64();
+#endif
+  const SparseRes sr = sparse_long_needle<SpsTile, true>(L.s.cons, L.s.rcons, L.s.ref, L.s.rref, m, n, W, L.u.t, L.reachF, L.reachR, 2, lane);
+  __syncthreads();
+#ifdef DH_LR_TIMING
+  const unsigned long long tq2 = wall_clock64();
+#endif
+  if (!sr.resolved) return;   // dense kernels
+  if (lane == 0) {
+    X.out->score_unsplit = sr.unsplit;
+    X.out->score_best = sr.best;
+    X.out->cons_left = sr.found ? sr.consLeft : 0;
+    X.out->ref_left = sr.found ? sr.refLeft : 0;
+    X.out->ref_right = sr.found ? sr.refRight : n;
+  }
+  X.consLeft = sr.found ? sr.consLeft : 0;
+  X.refLeft = sr.found ? sr.refLeft : 0;
+  X.refRight = sr.found ? sr.refRight : 0;
+  X.consRight = m - X.consLeft;
+  X.go = sr.found != 0;
+  int Ltot = 0, posC = 0;
+  if (sr.found) {
+    const int gapref = (n - sr.refRight) - sr.refLeft;
+    Ltot = sparse_masks(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC,
+                        [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+    masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
+  }
+  X.uniformize();
+#ifdef DH_LR_TIMING
+  const unsigned long long tq3 = wall_clock64();
+#endif
+  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane);
+#ifdef DH_LR_TIMING
+  if (lane == 0) {   // debug build: phase times in microseconds overwrite diagnostic slots of the record
+    const unsigned long long tq4 = wall_clock64();
+    X.out->c_start = (int)(tq0 & 0x3fffffffull);                 // start, 10 ns ticks
+    X.out->c_end = (int)(tq4 & 0x3fffffffull);                   // end
+    X.out->r_start = (int)((sr.t[0] - tq1) / 100);               // levels (+ earlier evaluation rounds), us
+    X.out->r_end = (int)((tq2 - sr.t[0]) / 100);                 // last evaluation + traces
+    X.out->hom_left = (int)((tq4 - tq2) / 100);                  // masks + split detection
+    X.out->hom_right = sr.levels;
+  }
+#endif
+  if (lane == 0) X.out->reserved = SPS_DONE;
+}
+
+#ifndef DH_SPARSE_WAVES
+#define DH_SPARSE_WAVES 3
+#endif
+__global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(SplitArgs A) {
+  __shared__ SpsLds L;
+  const int lane = threadIdx.x;
+  uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  for (;;) {
+    int w = 0;
+    if (lane == 0) w = atomicAdd(A.work_counter, 1);
+    w = rfl(w);
+    if (w >= A.n_work) break;
+    const int j = A.work_list[w];
+    if (j >= 0) process_sparse(A, j, L, scratch, lane);
+    __syncthreads();
+  }
+}
+
+}  // namespace dh
