@@ -129,6 +129,7 @@ struct dellyhip_batch {
   DevBuf<int32_t> work;              // K-binned pair lists, concatenated
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
+  bool sps_all = false;              // every junction of the dense bins is in the sparse list too
   int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
   int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
@@ -277,8 +278,10 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.work_list = b->work.p + b->sps_first;
     a.n_work = b->sps_count;
     a.work_counter = c->counters.p + 30;
+    a.sps_left = c->counters.p + 31;
     hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min(b->sps_count, c->scratch_blocks)), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
+    if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to the sparse kernel
   }
   bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
@@ -310,6 +313,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     HIPCHK(hipGetLastError());
   }
   if (!any_bin && b->mid) HIPCHK(hipEventRecord(b->mid, s));  // keeps the per-launch event quartet complete
+  a.sps_left = nullptr;
   if (b->ins_count > 0) {   // (direct mode: dellyhip_split_align)
     a.work_list = b->work.p + b->ins_first;
     a.n_work = b->ins_count;
@@ -626,6 +630,13 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   work.insert(work.end(), lriv.begin(), lriv.end());
   b->sps_first = (int)work.size();
   b->sps_count = (int)sparse.size();
+  {
+    size_t dense = 0;
+    for (auto& v : bins) dense += v.size();
+    for (auto& v : qbins) dense += v.size();
+    for (auto& v : qextra) dense += v.size();
+    b->sps_all = !sparse.empty() && sparse.size() == dense;
+  }
   work.insert(work.end(), sparse.begin(), sparse.end());
   int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)3 * b->n + 2 * dh::KMAX + 64));
   if (rc) return rc;

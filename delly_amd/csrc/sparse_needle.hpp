@@ -367,6 +367,132 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
   __syncthreads();
 }
 
+// The level loop again for the short-read kernel: ONE tile that holds every diagonal (no halo to recompute, nothing to
+// reload between calls), byte rows (row + 1, 0 = none), the four strings in LDS.  All guards of sp_candidate that a
+// "none" entry or a bound already implies are gone (cells of diagonal k have rows >= -k, so the lower column bounds hold
+// for every valid entry; a same-diagonal step past the last row or column can only start from the bound itself, which
+// level d - 1 already holds): about a third of the instructions of sp_level_block.  The tile's three rows of both
+// matrices must be zero when d0 == 0 (done here); index = diagonal + SP_LB + 1.
+__device__ __forceinline__ uint64_t sp_lds8u(const uint8_t* p) {   // (gfx950 reads unaligned LDS quadwords in one instruction)
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+template <typename TILE>
+__device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+                                             int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
+                                             int16_t* reachR, int lane) {
+  static_assert(TILE::narrow, "byte rows");
+  constexpr int OFF = SP_LB + 1;
+  const int ND = n + m + 1;
+  if (d0 == 0) {
+    uint32_t* z = reinterpret_cast<uint32_t*>(&T.row[0][0][0]);
+    for (int i = lane; i < (int)(sizeof(T.row) / 4); i += WAVE) z[i] = 0u;
+  }
+  __syncthreads();
+  for (int d = d0; d <= d1; ++d) {
+    uint8_t* curF = T.row[0][d % 3] + OFF;
+    uint8_t* curR = T.row[1][d % 3] + OFF;
+    const uint8_t* p1F = T.row[0][(d + 2) % 3] + OFF;
+    const uint8_t* p2F = T.row[0][(d + 1) % 3] + OFF;
+    const uint8_t* p1R = T.row[1][(d + 2) % 3] + OFF;
+    const uint8_t* p2R = T.row[1][(d + 1) % 3] + OFF;
+    int16_t* gF = FRf + (size_t)d * ndp;
+    int16_t* gR = FRr + (size_t)d * ndp;
+    const int seed = (d == 0) ? 0 : -1;        // level 0: row 0 of every diagonal k >= 0
+    int rf = -1, rr = -1;
+    for (int q0 = 0; q0 < ND; q0 += 2 * WAVE) {
+      int bf[2], br[2], kk[2];
+      uint64_t zf[2], zr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = min(q0 + u * WAVE + lane, ND - 1);
+        const int k = q - m;
+        kk[u] = k;
+        const int nk = n - k, rmax = min(m, nk);
+        const int first = (k < 0 && -2 * k <= d) ? -k : ((k >= 0) ? seed : -1);
+        {
+          const int e1 = p1F[q], e1l = p1F[q - 1], e2 = p2F[q], e2r = p2F[q + 1];
+          int b = max(e1 - 1, first);
+          if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);      // reference-only move from diagonal k - 1
+          if (e2 >= 1) b = max(b, min(e2, rmax));                            // mismatch on this diagonal
+          if (e2r >= 1 && e2r <= m) b = max(b, e2r);                         // consensus-only move from diagonal k + 1
+          bf[u] = b;
+        }
+        {
+          const int e1 = p1R[q], e1l = p1R[q - 1], e2 = p2R[q], e2r = p2R[q + 1];
+          int b = max(e1 - 1, first);
+          if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);
+          if (e2 >= 1) b = max(b, min(e2, rmax));
+          if (e2r >= 1 && e2r <= m) b = max(b, e2r);
+          br[u] = b;
+        }
+        const int r0 = max(bf[u], 0), r1 = max(br[u], 0);
+        zf[u] = sp_lds8u(consF + r0) ^ sp_lds8u(refF + max(r0 + k, 0));
+        zr[u] = sp_lds8u(consR + r1) ^ sp_lds8u(refR + max(r1 + k, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = q0 + u * WAVE + lane, k = kk[u];
+        if (bf[u] >= 0) {
+          const int lim = min(m - bf[u], n - (bf[u] + k));
+          const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
+          int r = bf[u] + min(adv, lim);
+          if (adv >= 8 && lim > 8) {
+            const int rl = bf[u] + lim;
+            r = bf[u] + 8;
+            for (;;) {
+              const uint64_t z = sp_lds8u(consF + r) ^ sp_lds8u(refF + r + k);
+              if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
+              r += 8;
+              if (r >= rl) break;
+            }
+            r = min(r, rl);
+          }
+          bf[u] = r;
+        }
+        if (br[u] >= 0) {
+          const int lim = min(m - br[u], n - (br[u] + k));
+          const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
+          int r = br[u] + min(adv, lim);
+          if (adv >= 8 && lim > 8) {
+            const int rl = br[u] + lim;
+            r = br[u] + 8;
+            for (;;) {
+              const uint64_t z = sp_lds8u(consR + r) ^ sp_lds8u(refR + r + k);
+              if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
+              r += 8;
+              if (r >= rl) break;
+            }
+            r = min(r, rl);
+          }
+          br[u] = r;
+        }
+        if (q < ND) {
+          curF[q] = (uint8_t)(bf[u] + 1);
+          curR[q] = (uint8_t)(br[u] + 1);
+          gF[q] = (int16_t)bf[u];
+          gR[q] = (int16_t)br[u];
+          rf = max(rf, bf[u]);
+          rr = max(rr, br[u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      rf = max(rf, __shfl_xor(rf, o));
+      rr = max(rr, __shfl_xor(rr, o));
+    }
+    if (lane == 0) {
+      reachF[d] = (int16_t)(rf < 0 ? SP_NEG : rf);
+      reachR[d] = (int16_t)(rr < 0 ? SP_NEG : rr);
+    }
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // First columns of one level without same-address atomics.  Diagonals k >= 0 come in ascending order and all start at
 // row 0, so diagonal k answers exactly the rows above everything the earlier ones reached: a running maximum (pm, uniform)
 // plus a prefix maximum over the 64 lanes of a chunk gives every lane its own, disjoint row range.
@@ -439,6 +565,25 @@ __device__ __noinline__ int sp_deep_list(const int16_t* FR, int ndp, int m, int 
   for (int q0 = 0; q0 < ND; q0 += WAVE) {
     const int q = q0 + lane;
     const bool hit = (q < ND) && (sp_ld16(lv + min(q, ND - 1)) >= rlo);
+    const unsigned long long bm = __ballot(hit);
+    if (bm) {
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int pos = cnt + __popcll(bm & below);
+      if (hit && pos < cap) list[pos] = q;
+      cnt += __popcll(bm);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return (cnt <= cap) ? cnt : -1;
+}
+
+// sp_deep_list on the byte row of level S the short-read tile still holds (row + 1, 0 = none; lv = row + SP_LB + 1)
+__device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo, int32_t* list, int cap, int lane) {
+  int cnt = 0;
+  for (int q0 = 0; q0 < ND; q0 += WAVE) {
+    const int q = q0 + lane;
+    const bool hit = (q < ND) && ((int)lv[min(q, ND - 1)] - 1 >= rlo);
     const unsigned long long bm = __ballot(hit);
     if (bm) {
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -553,9 +698,13 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
   int done = -1;           // levels 0 .. done are computed
   int S = min(W.smax, s_first);
   for (;;) {
-    for (int d = done + 1; d <= S; d += SP_LB)   // (LDSSTR callers keep the tile to themselves between rounds: a single tile resumes)
-      sp_level_block<TILE, LDSSTR>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR,
-                                   LDSSTR && d > 0 && ND <= TILE::tw, lane);
+    if constexpr (LDSSTR && TILE::narrow) {        // short-read kernel: one tile, kept between the rounds
+      sps_level_block(cons, ref, rcons, rref, m, n, done + 1, S, W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
+    } else {
+      for (int d = done + 1; d <= S; d += SP_LB)
+        sp_level_block<TILE, LDSSTR>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR,
+                                     false, lane);
+    }
     __syncthreads();
 #ifdef DH_LR_TIMING
     O.t[0] = wall_clock64();
@@ -574,8 +723,14 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
     int dsel = 0;
     int nlistR = -1;
     if (rlo <= rhi) {
-      const int nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
-      nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
+      int nlistF;
+      if constexpr (LDSSTR && TILE::narrow) {
+        nlistF = sps_deep_list(T.row[0][S % 3] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sps_deep_list(T.row[1][S % 3] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+      } else {
+        nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
+      }
       if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, lane);
       else sp_first_columns(W.frF, W.ndp, m, n, S, rlo, rhi, W.cF, lane);
       if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, S, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);

@@ -64,6 +64,7 @@ struct SplitArgs {
   const int32_t* work_list;     // junction indices for this launch (one K bin)
   int32_t n_work;
   int32_t* work_counter;        // zeroed before launch (the atomic of shortpe.h:181)
+  int32_t* sps_left;            // junctions split_sparse_kernel left to the dense kernels (nullptr: they run regardless)
   int32_t want_alignment;
   int32_t out_cons_cap, out_allele_cap;  // layout of a junction's out_blob slot: [cons][allele][aln rows]
   int32_t pair_mode;            // 1: split_align_kernel runs behind the packed kernel (deferred junctions only)

@@ -700,6 +700,7 @@ __global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A) {
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
   if (A.pair_mode && *A.work_counter == 0) return;  // nothing was deferred by the packed kernel
+  if (A.sps_left && *A.sps_left == 0) return;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;
@@ -720,6 +721,7 @@ __global__ __launch_bounds__(WAVE) void split_post_kernel(SplitArgs A) {
   __shared__ WaveLds L;
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  if (A.sps_left && *A.sps_left == 0) return;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;

@@ -357,6 +357,7 @@ __global__ __launch_bounds__(WAVE, DH_PAIR_WAVES) void split_pair_kernel(SplitAr
   __shared__ PairLds L;
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  if (A.sps_left && *A.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
   for (;;) {
     int w = 0;
     if (lane == 0) w = atomicAdd(A.work_counter, 1);

@@ -352,6 +352,7 @@ __global__ __launch_bounds__(WAVE, DH_QUAD_WAVES) void split_quad_kernel(SplitAr
   } L;
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  if (A.sps_left && *A.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
   for (;;) {
     int w = 0;
     if (lane == 0) w = atomicAdd(A.work_counter, 1);

@@ -51,22 +51,23 @@ __host__ __device__ inline uint64_t sps_scratch_bytes() {
   return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp * 2 + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
 }
 
-__device__ void process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
+__device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
 #ifdef DH_LR_TIMING
   const unsigned long long tq0 = wall_clock64();
 #endif
   JCtx X;
   junction_setup<KMAX, true, StrLdsS>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
   if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
-    if (lane == 0 && X.out->status == 0) X.out->reserved = SPS_DONE;
-    return;
+    const bool final = X.out->status == 0;
+    if (lane == 0 && final) X.out->reserved = SPS_DONE;
+    return final;
   }
   const int m = X.m, n = X.n;
-  if (m < 1 || n < 1 || m > SPS_MMAX || n + m + 1 > SPS_ND) return;   // dense kernels
+  if (m < 1 || n < 1 || m > SPS_MMAX || n + m + 1 > SPS_ND) return false;   // dense kernels
   int dirty = 0;
   for (int i = lane; i < m; i += WAVE) dirty |= comp_acgtn(L.s.cons[i]) ? 0 : 1;   // (case matters: the forward pass compares raw bytes)
   for (int i = lane; i < n; i += WAVE) dirty |= comp_acgtn(L.s.ref[i]) ? 0 : 1;
-  if (__ballot(dirty) != 0ull) return;
+  if (__ballot(dirty) != 0ull) return false;
   SparseWs W;
   W.ndp = (n + m + 2 + 63) & ~63;
   W.smax = SPS_SMAX;
@@ -91,7 +92,7 @@ __device__ void process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
 #ifdef DH_LR_TIMING
   const unsigned long long tq2 = wall_clock64();
 #endif
-  if (!sr.resolved) return;   // dense kernels
+  if (!sr.resolved) return false;   // dense kernels
   if (lane == 0) {
     X.out->score_unsplit = sr.unsplit;
     X.out->score_best = sr.best;
@@ -128,6 +129,7 @@ __device__ void process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   }
 #endif
   if (lane == 0) X.out->reserved = SPS_DONE;
+  return true;
 }
 
 #ifndef DH_SPARSE_WAVES
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
     w = rfl(w);
     if (w >= A.n_work) break;
     const int j = A.work_list[w];
-    if (j >= 0) process_sparse(A, j, L, scratch, lane);
+    if (j >= 0 && !process_sparse(A, j, L, scratch, lane) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
     __syncthreads();
   }
 }
