@@ -192,14 +192,14 @@ __device__ __noinline__ void sp_level2(const uint8_t* __restrict__ aF, const uin
 constexpr int SP_LB = 16;                            // levels per block
 // TW = valid diagonals per tile, STRCAP = bytes for staged letters (both matrices; 0: the caller's strings are in LDS already),
 // ELEM = int16_t (rows as they are; "none" = SP_NEG) or uint8_t (row + 1, 0 = "none": consensus rows <= 254, half the LDS)
-template <int TW, int STRCAP, typename ELEM = int16_t>
+template <int TW, int STRCAP, typename ELEM = int16_t, int NROWS = 3>
 struct __attribute__((aligned(16))) SpTileT {
   typedef ELEM elem_t;
   static constexpr int tw = TW;
   static constexpr int row_len = TW + 2 * SP_LB + 64;   // halo + slack for the second chunk of an iteration
   static constexpr int str_cap = STRCAP;
   static constexpr bool narrow = sizeof(ELEM) == 1;
-  ELEM row[2][3][TW + 2 * SP_LB + 64];                  // [matrix][level % 3][diagonal - base]
+  ELEM row[2][NROWS][TW + 2 * SP_LB + 64];              // [matrix][level % NROWS][diagonal - base]
   uint8_t str[STRCAP > 0 ? STRCAP : 8];
   static __device__ __forceinline__ int dec(ELEM e) { return narrow ? (int)e - 1 : (int)e; }
   static __device__ __forceinline__ ELEM enc(int v) { return narrow ? (ELEM)(max(v, -1) + 1) : (ELEM)v; }
@@ -371,8 +371,10 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
 // reload between calls), byte rows (row + 1, 0 = none), the four strings in LDS.  All guards of sp_candidate that a
 // "none" entry or a bound already implies are gone (cells of diagonal k have rows >= -k, so the lower column bounds hold
 // for every valid entry; a same-diagonal step past the last row or column can only start from the bound itself, which
-// level d - 1 already holds): about a third of the instructions of sp_level_block.  The tile's three rows of both
-// matrices must be zero when d0 == 0 (done here); index = diagonal + SP_LB + 1.
+// level d - 1 already holds): about a third of the instructions of sp_level_block.  TWO rows per matrix: level d is
+// written over level d - 2 in place -- diagonal q reads entries q and q + 1 of that row, chunks go in ascending order and
+// every chunk reads before it writes, so nothing is overwritten early.  The rows must be zero when d0 == 0 (done here);
+// index = diagonal + SP_LB + 1.
 __device__ __forceinline__ uint64_t sp_lds8u(const uint8_t* p) {   // (gfx950 reads unaligned LDS quadwords in one instruction)
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
@@ -391,12 +393,12 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
   }
   __syncthreads();
   for (int d = d0; d <= d1; ++d) {
-    uint8_t* curF = T.row[0][d % 3] + OFF;
-    uint8_t* curR = T.row[1][d % 3] + OFF;
-    const uint8_t* p1F = T.row[0][(d + 2) % 3] + OFF;
-    const uint8_t* p2F = T.row[0][(d + 1) % 3] + OFF;
-    const uint8_t* p1R = T.row[1][(d + 2) % 3] + OFF;
-    const uint8_t* p2R = T.row[1][(d + 1) % 3] + OFF;
+    uint8_t* curF = T.row[0][d & 1] + OFF;
+    uint8_t* curR = T.row[1][d & 1] + OFF;
+    const uint8_t* p1F = T.row[0][(d + 1) & 1] + OFF;
+    const uint8_t* p2F = curF;
+    const uint8_t* p1R = T.row[1][(d + 1) & 1] + OFF;
+    const uint8_t* p2R = curR;
     int16_t* gF = FRf + (size_t)d * ndp;
     int16_t* gR = FRr + (size_t)d * ndp;
     const int seed = (d == 0) ? 0 : -1;        // level 0: row 0 of every diagonal k >= 0
@@ -411,62 +413,79 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
         kk[u] = k;
         const int nk = n - k, rmax = min(m, nk);
         const int first = (k < 0 && -2 * k <= d) ? -k : ((k >= 0) ? seed : -1);
-        {
-          const int e1 = p1F[q], e1l = p1F[q - 1], e2 = p2F[q], e2r = p2F[q + 1];
-          int b = max(e1 - 1, first);
-          if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);      // reference-only move from diagonal k - 1
-          if (e2 >= 1) b = max(b, min(e2, rmax));                            // mismatch on this diagonal
-          if (e2r >= 1 && e2r <= m) b = max(b, e2r);                         // consensus-only move from diagonal k + 1
-          bf[u] = b;
-        }
-        {
-          const int e1 = p1R[q], e1l = p1R[q - 1], e2 = p2R[q], e2r = p2R[q + 1];
-          int b = max(e1 - 1, first);
-          if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);
-          if (e2 >= 1) b = max(b, min(e2, rmax));
-          if (e2r >= 1 && e2r <= m) b = max(b, e2r);
-          br[u] = b;
+        bf[u] = br[u] = first;
+        if (d > 0) {     // (level 0 has no predecessors: row 0 of the diagonals k >= 0)
+          {
+            const int e1 = p1F[q], e1l = p1F[q - 1], e2 = p2F[q], e2r = p2F[q + 1];
+            int b = max(e1 - 1, first);
+            if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);      // reference-only move from diagonal k - 1
+            if (e2 >= 1) b = max(b, min(e2, rmax));                            // mismatch on this diagonal
+            if (e2r >= 1 && e2r <= m) b = max(b, e2r);                         // consensus-only move from diagonal k + 1
+            bf[u] = b;
+          }
+          {
+            const int e1 = p1R[q], e1l = p1R[q - 1], e2 = p2R[q], e2r = p2R[q + 1];
+            int b = max(e1 - 1, first);
+            if ((unsigned)(e1l - 1) <= (unsigned)nk) b = max(b, e1l - 1);
+            if (e2 >= 1) b = max(b, min(e2, rmax));
+            if (e2r >= 1 && e2r <= m) b = max(b, e2r);
+            br[u] = b;
+          }
         }
         const int r0 = max(bf[u], 0), r1 = max(br[u], 0);
         zf[u] = sp_lds8u(consF + r0) ^ sp_lds8u(refF + max(r0 + k, 0));
         zr[u] = sp_lds8u(consR + r1) ^ sp_lds8u(refR + max(r1 + k, 0));
       }
+      // straight-line first compare of the four streams (a "none" entry compares row 0 and is discarded); only a run of
+      // 8 or more matches -- the few diagonals an alignment follows -- enters the loop below
+      int endF[2], endR[2];
+      bool moreF[2], moreR[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = kk[u];
+        {
+          const int b0 = max(bf[u], 0);
+          const int lim = min(m - b0, n - b0 - k);
+          const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
+          endF[u] = b0 + lim;
+          moreF[u] = bf[u] >= 0 && adv >= 8 && lim > 8;
+          bf[u] = (bf[u] < 0) ? -1 : b0 + min(adv, lim);
+        }
+        {
+          const int b0 = max(br[u], 0);
+          const int lim = min(m - b0, n - b0 - k);
+          const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
+          endR[u] = b0 + lim;
+          moreR[u] = br[u] >= 0 && adv >= 8 && lim > 8;
+          br[u] = (br[u] < 0) ? -1 : b0 + min(adv, lim);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int q = q0 + u * WAVE + lane, k = kk[u];
-        if (bf[u] >= 0) {
-          const int lim = min(m - bf[u], n - (bf[u] + k));
-          const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
-          int r = bf[u] + min(adv, lim);
-          if (adv >= 8 && lim > 8) {
-            const int rl = bf[u] + lim;
-            r = bf[u] + 8;
+        if (__ballot(moreF[u])) {
+          if (moreF[u]) {
+            int r = bf[u];
             for (;;) {
               const uint64_t z = sp_lds8u(consF + r) ^ sp_lds8u(refF + r + k);
               if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
               r += 8;
-              if (r >= rl) break;
+              if (r >= endF[u]) break;
             }
-            r = min(r, rl);
+            bf[u] = min(r, endF[u]);
           }
-          bf[u] = r;
         }
-        if (br[u] >= 0) {
-          const int lim = min(m - br[u], n - (br[u] + k));
-          const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
-          int r = br[u] + min(adv, lim);
-          if (adv >= 8 && lim > 8) {
-            const int rl = br[u] + lim;
-            r = br[u] + 8;
+        if (__ballot(moreR[u])) {
+          if (moreR[u]) {
+            int r = br[u];
             for (;;) {
               const uint64_t z = sp_lds8u(consR + r) ^ sp_lds8u(refR + r + k);
               if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
               r += 8;
-              if (r >= rl) break;
+              if (r >= endR[u]) break;
             }
-            r = min(r, rl);
+            br[u] = min(r, endR[u]);
           }
-          br[u] = r;
         }
         if (q < ND) {
           curF[q] = (uint8_t)(bf[u] + 1);
@@ -725,8 +744,8 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
     if (rlo <= rhi) {
       int nlistF;
       if constexpr (LDSSTR && TILE::narrow) {
-        nlistF = sps_deep_list(T.row[0][S % 3] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
-        nlistR = sps_deep_list(T.row[1][S % 3] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+        nlistF = sps_deep_list(T.row[0][S & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sps_deep_list(T.row[1][S & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
       } else {
         nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
         nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
@@ -839,7 +858,7 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       const long long pred = (2ll * S * m) / covered;
       if (pred > W.pred_cap) return O;
     }
-    S = min(W.smax, S * 2);
+    S = min(W.smax, (S < 8) ? S + 2 : S * 2);   // (even totals dominate: a substitution costs 2)
   }
 }
 

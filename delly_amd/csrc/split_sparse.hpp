@@ -4,7 +4,7 @@
 // A 150 bp consensus against a 1 kb window has 151 x 1001 cells per matrix, but a junction whose consensus carries
 // e errors is decided by the cells of deficit <= ~2.5 e: (levels) x (1151 diagonals) table entries.  BASELINE's C2
 // consensus sequences (0.5 % substitutions) need 1 .. 9 levels (47 % none, 83 % <= 2, 99.9 % <= 8), so the kernel
-// raises the level count per junction (2, 4, 8, 16, 32) and stops as soon as the junction is resolved; what is not
+// raises the level count per junction (0, 2, 4, 6, 8, 16, 32) and stops as soon as the junction is resolved; what is not
 // resolved at 32 levels -- or has letters outside A, C, G, T, N, a consensus beyond 254 bp or a window beyond
 // SPS_ND diagonals -- is left to the dense kernels, which skip every junction this kernel finished
 // (result.reserved == SPS_DONE).  Everything after the alignment (column masks, _findSplit, _percentIdentity,
@@ -19,10 +19,10 @@ constexpr int SPS_MMAX = 254;                 // consensus rows the short-read s
 constexpr int SPS_ND = 1408;                  // diagonals (n + m + 1): one tile, no halo
 constexpr int SPS_SMAX = 32;                  // deficit levels before the dense kernels take over
 constexpr int SPS_LIST = 1024;                // run / deep-diagonal list capacity
-typedef SpTileT<SPS_ND, 0, uint8_t> SpsTile;  // rows <= 254 fit a byte: 9 KB for the three rolling levels of both matrices
+typedef SpTileT<SPS_ND, 0, uint8_t, 2> SpsTile;  // rows <= 254 fit a byte, level d overwrites level d - 2: 6 KB for both matrices
 
-// the junction's strings and the post stage's masks, sized for this kernel's shapes (12.5 KB of LDS per wavefront with
-// the tile: 12 wavefronts per CU)
+// the junction's strings and the post stage's masks, sized for this kernel's shapes (9.5 KB of LDS per wavefront with
+// the tile: 16 wavefronts per CU)
 struct __attribute__((aligned(16))) StrLdsS {
   static constexpr bool has_rc = true;
   static constexpr int ref_cap = SPS_ND;
@@ -87,7 +87,7 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
 #ifdef DH_LR_TIMING
   const unsigned long long tq1 = wall_clock64();
 #endif
-  const SparseRes sr = sparse_long_needle<SpsTile, true>(L.s.cons, L.s.rcons, L.s.ref, L.s.rref, m, n, W, L.u.t, L.reachF, L.reachR, 2, lane);
+  const SparseRes sr = sparse_long_needle<SpsTile, true>(L.s.cons, L.s.rcons, L.s.ref, L.s.rref, m, n, W, L.u.t, L.reachF, L.reachR, 0, lane);
   __syncthreads();
 #ifdef DH_LR_TIMING
   const unsigned long long tq2 = wall_clock64();
@@ -133,7 +133,7 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
 }
 
 #ifndef DH_SPARSE_WAVES
-#define DH_SPARSE_WAVES 3
+#define DH_SPARSE_WAVES 4
 #endif
 __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(SplitArgs A) {
   __shared__ SpsLds L;
