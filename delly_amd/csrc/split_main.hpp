@@ -23,6 +23,62 @@ __device__ __forceinline__ long long wave_max64(long long v) {
   return v;
 }
 
+// ---- eight letters per lane (split_sparse_kernel's setup) ----
+__device__ __forceinline__ uint64_t ld8u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void st8u(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+// upc() on eight bytes
+__device__ __forceinline__ uint64_t upc8(uint64_t x) {
+  const uint64_t t = x & 0x7f7f7f7f7f7f7f7full;
+  const uint64_t a = t + 0x1f1f1f1f1f1f1f1full;      // bit 7 of a byte: t >= 'a'
+  const uint64_t b = t + 0x0505050505050505ull;      // bit 7: t > 'z'
+  return x - ((a & ~b & ~x & 0x8080808080808080ull) >> 2);
+}
+// bit 7 of every byte that is NOT one of A, C, G, T, N (0 = all eight are)
+__device__ __forceinline__ uint64_t not_acgtn8(uint64_t x) {
+  uint64_t any = 0;
+  const uint64_t pat[5] = {0x4141414141414141ull, 0x4343434343434343ull, 0x4747474747474747ull, 0x5454545454545454ull, 0x4e4e4e4e4e4e4e4eull};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const uint64_t z = x ^ pat[i];
+    any |= ~((((z & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | z)) & 0x8080808080808080ull;   // byte of z is zero
+  }
+  return any ^ 0x8080808080808080ull;
+}
+// comp_acgtn() on eight bytes that are all in A, C, G, T, N: A <-> T is x ^ 0x15, C <-> G is x ^ 0x04; bit 1 is set
+// for C, G, N only and bit 3 for N only
+__device__ __forceinline__ uint64_t comp8(uint64_t x) {
+  const uint64_t one = 0x0101010101010101ull;
+  const uint64_t b1 = (x >> 1) & one, b3 = (x >> 3) & one;
+  const uint64_t cg = b1 & ~b3, at = ~b1 & one;
+  return x ^ (cg << 2) ^ (at | (at << 2) | (at << 4));
+}
+// dst[0 .. len) = upc(src[0 .. len)), quadwords + a bytewise tail (no read or write beyond len); returns nonzero when a
+// letter outside A, C, G, T, N was copied (RAW = no upper-casing: the consensus is compared as it is)
+template <bool RAW>
+__device__ __forceinline__ int copy_letters8(uint8_t* dst, const uint8_t* src, int len, int lane) {
+  uint64_t bad = 0;
+  const int full = len & ~7;
+  for (int i = lane * 8; i < full; i += WAVE * 8) {
+    uint64_t v = ld8u(src + i);
+    if (!RAW) v = upc8(v);
+    bad |= not_acgtn8(v);
+    st8u(dst + i, v);
+  }
+  if (lane < len - full) {
+    uint8_t c = src[full + lane];
+    if (!RAW) c = upc(c);
+    bad |= comp_acgtn(c) ? 0ull : 1ull;
+    dst[full + lane] = c;
+  }
+  return bad != 0ull;
+}
+// dst = reverse complement of src[0 .. len) (letters in A, C, G, T, N), LDS to LDS
+__device__ __forceinline__ void revcomp8(uint8_t* dst, const uint8_t* src, int len, int lane) {
+  const int full = len & ~7;
+  for (int i = lane * 8; i < full; i += WAVE * 8) st8u(dst + i, comp8(__builtin_bswap64(ld8u(src + len - 8 - i))));
+  if (lane < len - full) dst[full + lane] = comp_acgtn(src[len - 1 - full - lane]);
+}
+
 // fills dst[0..len) of the window string from one segment (parallel over lanes)
 __device__ __forceinline__ void fill_segment(uint8_t* dst, const Seg& sg, int lane) {
   for (int i = lane; i < sg.len; i += WAVE) {
@@ -51,6 +107,7 @@ struct JCtx {
   int svt, svS, svE;
   int sBeg, sEnd, eBeg, eEnd;
   bool go, direct;
+  int dirty;          // FAST setup only: a letter outside A, C, G, T, N (or lower case in the consensus) was seen
   uint8_t* ob;
   uint64_t ob_off;
   dellyhip_result* out;
@@ -59,6 +116,7 @@ struct JCtx {
     j = rfl(j); m = rfl(m); n = rfl(n); svt = rfl(svt); svS = rfl(svS); svE = rfl(svE);
     sBeg = rfl(sBeg); sEnd = rfl(sEnd); eBeg = rfl(eBeg); eEnd = rfl(eEnd);
     go = rfl((int)go) != 0; direct = rfl((int)direct) != 0;
+    dirty = rfl(dirty);
     ob = reinterpret_cast<uint8_t*>(rfl64(reinterpret_cast<uint64_t>(ob)));
     ob_off = rfl64(ob_off);
     out = reinterpret_cast<dellyhip_result*>(rfl64(reinterpret_cast<uint64_t>(out)));
@@ -142,7 +200,9 @@ __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyh
 // ---- stage 1 ---------------------------------------------------------------------
 // INS: the caller is the insertion kernel (svt 4, splitAlign path); every other kernel flags
 // svt 4 junctions, which the host never routes to them, with DELLYHIP_E_LIMIT.
-template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds, bool INS = false>
+// FAST (split_sparse_kernel): quadword copies; the reverse complements assume clean letters, X.dirty tells the caller
+// when they are not (it then leaves the junction to a kernel with the exact byte-wise semantics).
+template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds, bool INS = false, bool FAST = false>
 __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
@@ -157,6 +217,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
   X.svE = J.sv_end;
   X.sBeg = X.sEnd = X.eBeg = X.eEnd = 0;
   X.direct = (A.ref_base != nullptr);
+  X.dirty = 0;
   X.consLeft = X.refLeft = X.refRight = X.consRight = 0;
   const int m = X.m;
   const uint8_t* cons_g = A.cons_base + A.cons_off[j];
@@ -176,7 +237,15 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     mlimit = true;
     go = false;
   }
-  if (go) {
+  int dirty = 0;
+  if (go && FAST) {
+    dirty |= copy_letters8<true>(S.cons, cons_g, m, lane);
+    if (WRITE_DEFAULTS && A.cons_base != A.out_blob) {
+      const int full = m & ~7;
+      for (int i = lane * 8; i < full; i += WAVE * 8) st8u(X.ob + i, ld8u(cons_g + i));
+      if (lane < m - full) X.ob[full + lane] = cons_g[full + lane];
+    }
+  } else if (go) {
     for (int i = lane; i < m; i += WAVE) {
       uint8_t ch = cons_g[i];
       S.cons[i] = ch;
@@ -211,13 +280,21 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     if (go) {
       int o = 0;
       for (int q = 0; q < nseg; ++q) {
-        fill_segment(S.ref + o, seg[q], lane);
+        if (FAST && !seg[q].rc) dirty |= copy_letters8<false>(S.ref + o, seg[q].base + seg[q].beg, seg[q].len, lane);
+        else {
+          fill_segment(S.ref + o, seg[q], lane);
+          if (FAST) {    // (a reverse-complemented piece keeps letters outside A, C, G, T, N: check what was written)
+            __syncthreads();
+            for (int i = lane; i < seg[q].len; i += WAVE) dirty |= comp_acgtn(S.ref[o + i]) ? 0 : 1;
+          }
+        }
         o += seg[q].len;
       }
     }
   }
   X.n = n;
   X.go = go;
+  X.dirty = FAST ? (__ballot(dirty != 0) != 0ull) : 0;
   // result defaults (everything a later stage does not overwrite)
   if (WRITE_DEFAULTS && lane == 0) {
     dellyhip_result R;
@@ -239,7 +316,12 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
   }
   __syncthreads();
   if constexpr (STR::has_rc) {
-    if (go) {
+    if (go && FAST) {
+      if (!X.dirty) {
+        revcomp8(S.rcons, S.cons, m, lane);
+        revcomp8(S.rref, S.ref, n, lane);
+      }
+    } else if (go) {
       // reverseComplement(s1), reverseComplement(s2): util.h:549-563
       for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
       for (int i = lane; i < n; i += WAVE) S.rref[i] = rc_at(S.ref, n, i);

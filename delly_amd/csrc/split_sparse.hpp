@@ -56,7 +56,7 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   const unsigned long long tq0 = wall_clock64();
 #endif
   JCtx X;
-  junction_setup<KMAX, true, StrLdsS>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
+  junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
   if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
     const bool final = X.out->status == 0;
     if (lane == 0 && final) X.out->reserved = SPS_DONE;
@@ -64,10 +64,7 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   }
   const int m = X.m, n = X.n;
   if (m < 1 || n < 1 || m > SPS_MMAX || n + m + 1 > SPS_ND) return false;   // dense kernels
-  int dirty = 0;
-  for (int i = lane; i < m; i += WAVE) dirty |= comp_acgtn(L.s.cons[i]) ? 0 : 1;   // (case matters: the forward pass compares raw bytes)
-  for (int i = lane; i < n; i += WAVE) dirty |= comp_acgtn(L.s.ref[i]) ? 0 : 1;
-  if (__ballot(dirty) != 0ull) return false;
+  if (X.dirty) return false;   // letters outside A, C, G, T, N (case matters: the forward pass compares raw bytes): dense kernels
   SparseWs W;
   W.ndp = (n + m + 2 + 63) & ~63;
   W.smax = SPS_SMAX;
