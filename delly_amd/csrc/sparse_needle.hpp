@@ -54,6 +54,8 @@ struct SparseRes {
   int best, consLeft, refLeft, refRight;
   int nrunsF, nrunsR;
   int levels;        // deficit levels used (diagnostic)
+  int mmF, mmR;      // mismatch columns on the two traced paths (from the deficits: a path of deficit D with V consensus-only
+                     // and H paid reference-only moves crosses (D - 2 V - H) / 2 mismatches)
   unsigned long long t[5];   // DH_LR_TIMING: wall clock after the levels, the first-column tables, the join, refRight, the traces
 };
 
@@ -657,8 +659,11 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
 
 // traceback from (r, c) with deficit D: the reference's rule (vertical, then horizontal, then diagonal; src/needle.h:154-192)
 // decided on the tables; runs in push order.  Returns the number of runs or -1 on overflow.  Wave-uniform.
-__device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane) {
+__device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
+                                     int* mismatches = nullptr) {
   const int ND = n + m + 1;
+  const int D0 = rfl(D);
+  int nv = 0, nh = 0;
   auto fr = [&](int d, int q) -> int { return (d < 0 || q < 0 || q >= ND) ? SP_NEG : sp_ld16(FR + (size_t)d * ndp + q); };
   int nruns = 0, last_op = -1, last_len = 0;
   auto emit = [&](int op, int len) {
@@ -673,11 +678,11 @@ __device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, i
   };
   r = rfl(r); c = rfl(c); D = rfl(D);
   while (r > 0 || c > 0) {
-    if (r == 0) { emit(2, c); c = 0; break; }
-    if (c == 0) { emit(1, r); r = 0; break; }
+    if (r == 0) { emit(2, c); c = 0; break; }            // (leading reference letters: free)
+    if (c == 0) { emit(1, r); nv += r; r = 0; break; }
     const int k = c - r, q = k + m;
-    if (D >= 2 && rfl(fr(D - 2, q + 1)) >= r - 1) { emit(1, 1); --r; D -= 2; continue; }
-    if (D >= 1 && rfl(fr(D - 1, q - 1)) >= r) { emit(2, 1); --c; D -= 1; continue; }
+    if (D >= 2 && rfl(fr(D - 2, q + 1)) >= r - 1) { emit(1, 1); ++nv; --r; D -= 2; continue; }
+    if (D >= 1 && rfl(fr(D - 1, q - 1)) >= r) { emit(2, 1); ++nh; --c; D -= 1; continue; }
     // diagonal run at cost D: rows >= lowD of this diagonal cost D; a test passes at rows <= T
     const int lowD = (D >= 1) ? max(rfl(fr(D - 1, q)) + 1, 0) : 0;
     int T = SP_NEG;
@@ -699,6 +704,7 @@ __device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, i
     if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
     ++nruns;
   }
+  if (mismatches) *mismatches = (D0 - 2 * nv - nh) / 2;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   return (nruns <= cap) ? nruns : -1;
@@ -711,7 +717,7 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
                                                     int m, int n, const SparseWs& W, TILE& T, int16_t* reachF, int16_t* reachR,
                                                     int s_first, int lane) {
   SparseRes O;
-  O.resolved = 0; O.found = 0; O.unsplit = SP_UNKNOWN; O.best = 0; O.consLeft = O.refLeft = O.refRight = 0; O.nrunsF = O.nrunsR = 0; O.levels = 0;
+  O.resolved = 0; O.found = 0; O.unsplit = SP_UNKNOWN; O.best = 0; O.consLeft = O.refLeft = O.refRight = 0; O.nrunsF = O.nrunsR = 0; O.levels = 0; O.mmF = O.mmR = 0;
   const int ND = n + m + 1;
   if (ND + 1 > W.ndp || m < 1 || n < 1 || W.smax < 4) return O;
   int done = -1;           // levels 0 .. done are computed
@@ -841,8 +847,8 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
 #ifdef DH_LR_TIMING
       O.t[3] = wall_clock64();
 #endif
-      O.nrunsF = sp_trace(W.frF, W.ndp, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane);
-      O.nrunsR = sp_trace(W.frR, W.ndp, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane);
+      O.nrunsF = sp_trace(W.frF, W.ndp, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF);
+      O.nrunsR = sp_trace(W.frR, W.ndp, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR);
 #ifdef DH_LR_TIMING
       O.t[4] = wall_clock64();
 #endif
@@ -891,6 +897,71 @@ __device__ __forceinline__ int sparse_masks(PL& L, const int32_t* runsF, int nF,
     const int x = rfl(sp_ld32(runsR + i));
     put(x >> 24, x & 0xffffff);
   }
+  return pos;
+}
+
+// sparse_masks with every run written by the whole wavefront (one word per lane), the cumulative counts by a prefix sum
+// over the lanes, and no letter pass: returns the number of columns, both = columns with a letter in both rows.
+// (The equality mask mE is NOT produced: the caller has the match / mismatch counts from the traces.)
+template <typename PL>
+__device__ __forceinline__ int sparse_masks_counts(PL& L, const int32_t* runsF, int nF, const int32_t* runsR, int nR, int gapref, int maskw,
+                                                   int lane, int& posC, int& both) {
+  for (int w = lane; w < maskw; w += WAVE) {
+    L.mV[w] = 0;
+    L.mR[w] = 0;
+  }
+  __syncthreads();
+  int pos = 0;
+  auto put = [&](int op, int len) {
+    if (len <= 0) return;
+    const int w0 = pos >> 6, w1 = (pos + len - 1) >> 6;
+    for (int w = w0 + lane; w <= w1; w += WAVE) {
+      const int lo = max(pos - w * 64, 0), hi = min(pos + len - w * 64, 64);
+      const unsigned long long mk = ((hi >= 64) ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+      if (op != 2) L.mV[w] |= mk;
+      if (op != 1) L.mR[w] |= mk;
+    }
+    pos += len;
+  };
+  // (run words are independent loads: fetch up to 64 of each list at once)
+  const int xF = (lane < nF) ? sp_ld32(runsF + (nF - 1 - lane)) : 0;
+  const int xR = (lane < nR) ? sp_ld32(runsR + lane) : 0;
+  for (int i = 0; i < nF; ++i) {
+    const int x = (i < WAVE) ? __shfl(xF, i) : rfl(sp_ld32(runsF + (nF - 1 - i)));
+    put(x >> 24, x & 0xffffff);
+  }
+  put(2, gapref);
+  posC = pos;
+  for (int i = 0; i < nR; ++i) {
+    const int x = (i < WAVE) ? __shfl(xR, i) : rfl(sp_ld32(runsR + i));
+    put(x >> 24, x & 0xffffff);
+  }
+  __syncthreads();
+  // cumulative letter counts per mask word
+  const int nw = (pos + 63) >> 6;
+  int b = 0;
+  for (int w0 = 0, cv = 0, cr = 0; w0 <= nw; w0 += WAVE) {
+    const int w = w0 + lane;
+    const unsigned long long mv = (w < nw) ? L.mV[w] : 0ull, mr = (w < nw) ? L.mR[w] : 0ull;
+    int pv = __popcll(mv), pr = __popcll(mr);
+    b += __popcll(mv & mr);
+    int sv = pv, sr = pr;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const int tv = __shfl_up(sv, o), tr = __shfl_up(sr, o);
+      if (lane >= o) { sv += tv; sr += tr; }
+    }
+    if (w <= nw) {
+      L.cumV[w] = cv + sv - pv;
+      L.cumR[w] = cr + sr - pr;
+    }
+    cv += __shfl(sv, WAVE - 1);
+    cr += __shfl(sr, WAVE - 1);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) b += __shfl_xor(b, o);
+  both = b;
+  __syncthreads();
   return pos;
 }
 

@@ -486,8 +486,9 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
 // _findSplit / _percentIdentity / _findHomology / _coordTransform / exact alleles on the column
 // masks (split.h:166-375, 596-637); writes the result record.
 template <typename STRS, typename PL>
+// pre_ma / pre_mm >= 0: the match / mismatch column counts are known (L.mE is not read).
 __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PL& L, bool go, int Ltot,
-                                             int posC, int lane) {
+                                             int posC, int lane, int pre_ma = -1, int pre_mm = -1) {
   const dellyhip_params& P = A.p;
   const int m = X.m, n = X.n;
   uint8_t* ob = X.ob;
@@ -536,10 +537,15 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
     float percId = 0.f;
     if (ok) {
       // _percentIdentity split.h:282-316
-      for (int w = 0; w < ((Ltot + 63) >> 6); ++w) {
-        unsigned long long both = L.mV[w] & L.mR[w];
-        ma += __popcll(both & L.mE[w]);
-        mm += __popcll(both & ~L.mE[w]);
+      if (pre_ma >= 0) {
+        ma = pre_ma;
+        mm = pre_mm;
+      } else {
+        for (int w = 0; w < ((Ltot + 63) >> 6); ++w) {
+          unsigned long long both = L.mV[w] & L.mR[w];
+          ma += __popcll(both & L.mE[w]);
+          mm += __popcll(both & ~L.mE[w]);
+        }
       }
       mm += closedLen - chosenLen;
       percId = (float)(uint32_t)ma / (float)(uint32_t)(ma + mm);

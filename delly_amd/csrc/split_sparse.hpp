@@ -102,18 +102,25 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   X.refRight = sr.found ? sr.refRight : 0;
   X.consRight = m - X.consLeft;
   X.go = sr.found != 0;
-  int Ltot = 0, posC = 0;
+  int Ltot = 0, posC = 0, pre_ma = -1, pre_mm = -1;
   if (sr.found) {
     const int gapref = (n - sr.refRight) - sr.refLeft;
-    Ltot = sparse_masks(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC,
-                        [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
-    masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
+    if (A.want_alignment) {   // the alignment rows need every column's letters
+      Ltot = sparse_masks(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC,
+                          [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+      masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
+    } else {
+      int both = 0;
+      Ltot = sparse_masks_counts(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC, both);
+      pre_mm = rfl(sr.mmF + sr.mmR);
+      pre_ma = rfl(both) - pre_mm;
+    }
   }
   X.uniformize();
 #ifdef DH_LR_TIMING
   const unsigned long long tq3 = wall_clock64();
 #endif
-  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane);
+  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm);
 #ifdef DH_LR_TIMING
   if (lane == 0) {   // debug build: phase times in microseconds overwrite diagnostic slots of the record
     const unsigned long long tq4 = wall_clock64();
