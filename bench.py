@@ -444,7 +444,7 @@ def main():
         value = total_units / dt
         ach = n * ALG_BYTES_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0
         traffic = _measured_traffic()
-        valu_n = _valu_instructions("split_quad_kernel<5, 3>", n)
+        valu_n = _valu_instructions("split_sparse_kernel", n)
         valu = None
         if valu_n and ms_dp > 0:
             rate = valu_n / (ms_dp * 1e-3)
@@ -475,10 +475,10 @@ def main():
                        "ms_per_step_per_rank": per_rank_ms, "kernels_ms_per_step_rank0": ms_split},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "split_quad_kernel<5,3> (packed int16 longNeedle DP, 4 junctions per wavefront)",
+                         "kernel": "split_sparse_kernel (sparse longNeedle: furthest-reaching tables per deficit level, one junction per wavefront, alignment + split detection fused)",
                          "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
-                         "gcups": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
+                         "gcups_dense_equivalent": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
                          "valu": valu, "valu_frac": valu["frac_of_measured_peak"] if valu else None,
                          "note": "path is integer-VALU bound with DP state on chip; HBM fraction is reported because "
                                  "BASELINE asks for it (SURVEY.md 8d)"},

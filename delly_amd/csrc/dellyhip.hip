@@ -99,6 +99,7 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int sps_waves = 16;        // wavefronts of split_sparse_kernel per CU (env DELLYHIP_SPS_WAVES; 16 = what LDS and registers allow)
   int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
   int sparse_cost = 40;      // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
@@ -274,14 +275,16 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.ref_off = b->ref_off.p;
     a.ref_len = b->ref_len.p;
   }
+  bool mid_done = false;
   if (b->sps_count > 0 && !direct) {   // sparse longNeedle first: the dense kernels below skip what it finishes
     a.work_list = b->work.p + b->sps_first;
     a.n_work = b->sps_count;
     a.work_counter = c->counters.p + 30;
     a.sps_left = c->counters.p + 31;
-    hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min(b->sps_count, c->scratch_blocks)), dim3(dh::WAVE), 0, s, a);
+    hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->sps_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
     if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to the sparse kernel
+    else if (b->mid) { HIPCHK(hipEventRecord(b->mid, s)); mid_done = true; }   // dp_kernel_ms = the sparse kernel (the dominant one)
   }
   bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
@@ -290,11 +293,11 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     any_bin = true;
     a.work_list = b->work.p + 2 * b->bin_first[K];
     switch (K) {
-      case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 2: launch_split<2>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 1: launch_split<1>(a, cnt, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 2: launch_split<2>(a, cnt, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 3: launch_split<3>(a, cnt, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 4: launch_split<4>(a, cnt, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      default: launch_split<5>(a, cnt, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
     }
     HIPCHK(hipGetLastError());
   }
@@ -304,15 +307,15 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     any_bin = true;
     a.work_list = b->work.p + b->qbin_first[KQ];
     switch (KQ) {
-      case 1: launch_quad<1, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 2: launch_quad<2, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 3: launch_quad<3, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      case 4: launch_quad<4, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
-      default: launch_quad<5, 3>(a, cnt, np, c->scratch_blocks, c->counters.p, s, b->mid); break;
+      case 1: launch_quad<1, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 2: launch_quad<2, 1>(a, cnt, np, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 3: launch_quad<3, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      case 4: launch_quad<4, 2>(a, cnt, np, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
+      default: launch_quad<5, 3>(a, cnt, np, c->scratch_blocks, c->counters.p, s, mid_done ? nullptr : b->mid); break;
     }
     HIPCHK(hipGetLastError());
   }
-  if (!any_bin && b->mid) HIPCHK(hipEventRecord(b->mid, s));  // keeps the per-launch event quartet complete
+  if (!any_bin && b->mid && !mid_done) HIPCHK(hipEventRecord(b->mid, s));  // keeps the per-launch event quartet complete
   a.sps_left = nullptr;
   if (b->ins_count > 0) {   // (direct mode: dellyhip_split_align)
     a.work_list = b->work.p + b->ins_first;
@@ -753,6 +756,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_SPS_WAVES")) c->sps_waves = std::max(1, std::min(20, atoi(t)));
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob

@@ -347,7 +347,8 @@ class ResidentBatch:
         return a.value, b.value, l.value
 
     def dp_kernel_ms(self):
-        """Average ms of split_pair_kernel alone over the launches of the last kernel_ms() window."""
+        """Average ms of the dominant alignment kernel alone (split_sparse_kernel, or the packed dense DP kernels when the
+        sparse path does not cover the batch) over the launches of the last kernel_ms() window."""
         a = C.c_double(0)
         self.ctx._check(self.ctx.lib.dellyhip_batch_dp_kernel_ms(self.ctx._ctx, self._b, C.byref(a)))
         return a.value
