@@ -101,7 +101,7 @@ struct dellyhip_ctx {
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
   int sps_waves = 16;        // wavefronts of split_sparse_kernel per CU (env DELLYHIP_SPS_WAVES; 16 = what LDS and registers allow)
   int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
-  int sparse_cost = 40;      // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
+  int sparse_cost = 160;     // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items

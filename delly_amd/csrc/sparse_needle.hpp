@@ -76,6 +76,12 @@ __device__ __forceinline__ uint64_t sp_load8(const uint8_t* p) {
   return v;
 }
 
+__device__ __forceinline__ uint64_t sp_lds8u(const uint8_t* p) {   // (gfx950 reads unaligned LDS quadwords in one instruction)
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
 // candidate row of diagonal q at level d from the two previous levels (before the match extension)
 __device__ __forceinline__ int sp_candidate(int d, int q, int k, int m, int n, int ND, int v1, int v1l, int v2, int v2r) {
   int best = SP_NEG;
@@ -206,7 +212,7 @@ struct __attribute__((aligned(16))) SpTileT {
   static __device__ __forceinline__ int dec(ELEM e) { return narrow ? (int)e - 1 : (int)e; }
   static __device__ __forceinline__ ELEM enc(int v) { return narrow ? (ELEM)(max(v, -1) + 1) : (ELEM)v; }
 };
-typedef SpTileT<960, 12288> SpTile;                  // long reads: 3 % halo overhead, letters staged per tile
+typedef SpTileT<960, 12288, int16_t, 2> SpTile;      // long reads: 3 % halo overhead, letters staged per tile, two rolling rows
 
 // 8 letters at an arbitrary LDS byte offset: two aligned 8-byte reads + a funnel shift
 __device__ __forceinline__ uint64_t sp_lds8(const uint8_t* p) {
@@ -369,6 +375,185 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
   __syncthreads();
 }
 
+// The level block of the strip (long-read) kernel: tiles of TILE::tw diagonals with a halo of SP_LB, int16 rows, TWO rows
+// per matrix (level d overwrites level d - 2 in place: diagonal q reads entries q and q + 1 of that row, chunks ascend,
+// every chunk reads before it writes; the shrinking halo only ever reads entries the level two below computed), the
+// lean candidate step of sps_level_block.  STAGED: the letters a tile can touch sit in T.str.
+template <typename TILE, bool STAGED>
+__device__ __forceinline__ void sp_tile_levels(const uint8_t* aF, const uint8_t* bF, const uint8_t* aR, const uint8_t* bR, int c0, int m, int n,
+                                               int d0, int nl, int tlo, int thi, int16_t* FRf, int16_t* FRr, int ndp, TILE& T,
+                                               int16_t* reachF, int16_t* reachR, int lane) {
+  constexpr int OFF = SP_LB + 1;
+  const int ND = n + m + 1;
+  const int base = tlo - OFF;
+  auto ld8 = [&](const uint8_t* p) -> uint64_t { return STAGED ? sp_lds8u(p) : sp_load8(p); };
+  for (int j = 0; j < nl; ++j) {
+    const int d = d0 + j;
+    const int halo = nl - 1 - j;
+    const int qa = max(tlo - halo, 0), qb = min(thi + halo, ND);
+    int16_t* curF = T.row[0][d & 1] - base;
+    int16_t* curR = T.row[1][d & 1] - base;
+    const int16_t* p1F = T.row[0][(d + 1) & 1] - base;
+    const int16_t* p1R = T.row[1][(d + 1) & 1] - base;
+    const int16_t* p2F = curF;
+    const int16_t* p2R = curR;
+    int16_t* gF = FRf + (size_t)d * ndp;
+    int16_t* gR = FRr + (size_t)d * ndp;
+    const int seed = (d == 0) ? 0 : -1;
+    int rf = -1, rr = -1;
+    for (int q0 = qa; q0 < qb; q0 += 2 * WAVE) {
+      int bf[2], br[2], kk[2];
+      uint64_t zf[2], zr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = min(q0 + u * WAVE + lane, qb - 1);
+        const int k = q - m;
+        kk[u] = k;
+        const int nk = n - k, rmax = min(m, nk);
+        const int first = (k < 0 && -2 * k <= d) ? -k : ((k >= 0) ? seed : -1);
+        bf[u] = br[u] = first;
+        if (d > 0) {
+          {
+            const int v1 = p1F[q], v1l = p1F[q - 1], v2 = p2F[q], v2r = p2F[q + 1];
+            int b = max(v1, first);
+            if ((unsigned)v1l <= (unsigned)nk) b = max(b, v1l);          // reference-only move from diagonal k - 1
+            if (v2 >= 0) b = max(b, min(v2 + 1, rmax));                   // mismatch on this diagonal
+            if (v2r >= 0 && v2r < m) b = max(b, v2r + 1);                 // consensus-only move from diagonal k + 1
+            bf[u] = b;
+          }
+          {
+            const int v1 = p1R[q], v1l = p1R[q - 1], v2 = p2R[q], v2r = p2R[q + 1];
+            int b = max(v1, first);
+            if ((unsigned)v1l <= (unsigned)nk) b = max(b, v1l);
+            if (v2 >= 0) b = max(b, min(v2 + 1, rmax));
+            if (v2r >= 0 && v2r < m) b = max(b, v2r + 1);
+            br[u] = b;
+          }
+        }
+        const int r0 = max(bf[u], 0), r1 = max(br[u], 0);
+        zf[u] = ld8(aF + r0) ^ ld8(bF + (max(r0 + k, c0) - c0));
+        zr[u] = ld8(aR + r1) ^ ld8(bR + (max(r1 + k, c0) - c0));
+      }
+      int endF[2], endR[2];
+      bool moreF[2], moreR[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = kk[u];
+        {
+          const int b0 = max(bf[u], 0);
+          const int lim = min(m - b0, n - b0 - k);
+          const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
+          endF[u] = b0 + lim;
+          moreF[u] = bf[u] >= 0 && adv >= 8 && lim > 8;
+          bf[u] = (bf[u] < 0) ? -1 : b0 + min(adv, lim);
+        }
+        {
+          const int b0 = max(br[u], 0);
+          const int lim = min(m - b0, n - b0 - k);
+          const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
+          endR[u] = b0 + lim;
+          moreR[u] = br[u] >= 0 && adv >= 8 && lim > 8;
+          br[u] = (br[u] < 0) ? -1 : b0 + min(adv, lim);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q = q0 + u * WAVE + lane, k = kk[u];
+        if (__ballot(moreF[u])) {
+          if (moreF[u]) {
+            int r = bf[u];
+            for (;;) {
+              const uint64_t z = ld8(aF + r) ^ ld8(bF + (r + k - c0));
+              if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
+              r += 8;
+              if (r >= endF[u]) break;
+            }
+            bf[u] = min(r, endF[u]);
+          }
+        }
+        if (__ballot(moreR[u])) {
+          if (moreR[u]) {
+            int r = br[u];
+            for (;;) {
+              const uint64_t z = ld8(aR + r) ^ ld8(bR + (r + k - c0));
+              if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
+              r += 8;
+              if (r >= endR[u]) break;
+            }
+            br[u] = min(r, endR[u]);
+          }
+        }
+        if (q < qb) {
+          curF[q] = (int16_t)bf[u];
+          curR[q] = (int16_t)br[u];
+          if (q >= tlo && q < thi) {
+            gF[q] = (int16_t)bf[u];
+            gR[q] = (int16_t)br[u];
+            rf = max(rf, bf[u]);
+            rr = max(rr, br[u]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      rf = max(rf, __shfl_xor(rf, o));
+      rr = max(rr, __shfl_xor(rr, o));
+    }
+    if (lane == 0) {
+      reachF[d] = (int16_t)max((int)reachF[d], rf < 0 ? SP_NEG : rf);
+      reachR[d] = (int16_t)max((int)reachR[d], rr < 0 ? SP_NEG : rr);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TILE>
+__device__ __noinline__ void sp_level_block2(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+                                             int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
+                                             int16_t* reachR, int lane) {
+  constexpr int SP_TW = TILE::tw;
+  constexpr int SP_STR_CAP = TILE::str_cap;
+  constexpr int OFF = SP_LB + 1;
+  const int ND = n + m + 1;
+  const int nl = d1 - d0 + 1;
+  for (int d = d0 + lane; d <= d1; d += WAVE) { reachF[d] = (int16_t)SP_NEG; reachR[d] = (int16_t)SP_NEG; }
+  __syncthreads();
+  const bool stage = 2 * (2 * m + SP_TW + 2 * SP_LB + 64) <= SP_STR_CAP;
+  for (int tlo = 0; tlo < ND; tlo += SP_TW) {
+    const int thi = min(tlo + SP_TW, ND);
+    const int base = tlo - OFF;
+    const int len = thi + OFF - base;
+    for (int i = lane; i < len; i += WAVE) {     // levels d0 - 1 and d0 - 2 of the tile + halo (level d lives in row d & 1)
+      const int q = base + i;
+      const bool in = q >= 0 && q < ND;
+      T.row[0][(d0 + 1) & 1][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRf + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[1][(d0 + 1) & 1][i] = (int16_t)((d0 >= 1 && in) ? sp_ld16(FRr + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
+      T.row[0][d0 & 1][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRf + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+      T.row[1][d0 & 1][i] = (int16_t)((d0 >= 2 && in) ? sp_ld16(FRr + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
+    }
+    if (stage) {
+      // letters this tile can touch: rows 0 .. m, columns c = r + k, k in [tlo - SP_LB - m, thi + SP_LB - m)
+      const int c0 = max(0, tlo - SP_LB - m) & ~7, c1 = min(n, thi + SP_LB);
+      const int wl = max(c1 - c0, 0);
+      const int am = (m + 16 + 7) & ~7, bw = (wl + 16 + 7) & ~7;
+      uint8_t* la0 = T.str;
+      uint8_t* lb0 = la0 + am;
+      uint8_t* la1 = lb0 + bw;
+      uint8_t* lb1 = la1 + am;
+      for (int i = lane; i < am; i += WAVE) { la0[i] = (i < m) ? consF[i] : (uint8_t)1; la1[i] = (i < m) ? consR[i] : (uint8_t)1; }
+      for (int i = lane; i < bw; i += WAVE) { lb0[i] = (i < wl) ? refF[c0 + i] : (uint8_t)2; lb1[i] = (i < wl) ? refR[c0 + i] : (uint8_t)2; }
+      __syncthreads();
+      sp_tile_levels<TILE, true>(la0, lb0, la1, lb1, c0, m, n, d0, nl, tlo, thi, FRf, FRr, ndp, T, reachF, reachR, lane);
+    } else {
+      __syncthreads();
+      sp_tile_levels<TILE, false>(consF, refF, consR, refR, 0, m, n, d0, nl, tlo, thi, FRf, FRr, ndp, T, reachF, reachR, lane);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // The level loop again for the short-read kernel: ONE tile that holds every diagonal (no halo to recompute, nothing to
 // reload between calls), byte rows (row + 1, 0 = none), the four strings in LDS.  All guards of sp_candidate that a
 // "none" entry or a bound already implies are gone (cells of diagonal k have rows >= -k, so the lower column bounds hold
@@ -377,11 +562,6 @@ __device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t*
 // written over level d - 2 in place -- diagonal q reads entries q and q + 1 of that row, chunks go in ascending order and
 // every chunk reads before it writes, so nothing is overwritten early.  The rows must be zero when d0 == 0 (done here);
 // index = diagonal + SP_LB + 1.
-__device__ __forceinline__ uint64_t sp_lds8u(const uint8_t* p) {   // (gfx950 reads unaligned LDS quadwords in one instruction)
-  uint64_t v;
-  __builtin_memcpy(&v, p, 8);
-  return v;
-}
 template <typename TILE>
 __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
                                              int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
@@ -727,8 +907,7 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       sps_level_block(cons, ref, rcons, rref, m, n, done + 1, S, W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
     } else {
       for (int d = done + 1; d <= S; d += SP_LB)
-        sp_level_block<TILE, LDSSTR>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR,
-                                     false, lane);
+        sp_level_block2<TILE>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
     }
     __syncthreads();
 #ifdef DH_LR_TIMING
@@ -747,7 +926,14 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
     long long key = 0x7fffffffffffffffll;      // (total deficit << 40) | (row << 20) | column
     int dsel = 0;
     int nlistR = -1;
-    if (rlo <= rhi) {
+    // A split of total deficit <= S needs levels d + e <= S whose furthest rows meet (reach is non-decreasing in the
+    // level): without one the tables cannot resolve the junction and are not built.
+    bool feasible = false;
+    for (int d0 = 0; d0 <= S && !feasible; d0 += WAVE) {
+      const int d = d0 + lane;
+      feasible = __ballot(d <= S && reachF[min(d, S)] >= 0 && (int)reachR[S - min(d, S)] >= m - (int)reachF[min(d, S)]) != 0ull;
+    }
+    if (rlo <= rhi && feasible) {
       int nlistF;
       if constexpr (LDSSTR && TILE::narrow) {
         nlistF = sps_deep_list(T.row[0][S & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
@@ -864,7 +1050,7 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       const long long pred = (2ll * S * m) / covered;
       if (pred > W.pred_cap) return O;
     }
-    S = min(W.smax, (S < 8) ? S + 2 : S * 2);   // (even totals dominate: a substitution costs 2)
+    S = min(W.smax, (S < 8) ? S + 2 : (S < 32) ? S * 2 : S + SP_LB);   // (even totals dominate: a substitution costs 2)
   }
 }
 
