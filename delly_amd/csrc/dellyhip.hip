@@ -555,7 +555,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     long span = (long)J.sv_end - (long)J.sv_start;
     int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
     if (!b->h_win_len.empty()) approx = b->h_win_len[i];
-    if (b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx + m + 1 <= dh::SPS_ND) sparse.push_back(i);
+    if (b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx <= dh::SPS_NMAX && approx + m + 1 <= dh::SPS_ND) sparse.push_back(i);
     if (b->use_quad && !direct && m + 1 <= dh::HALF * 5 && approx <= dh::QNMAX) {
       const int kq = std::max(1, (m + 1 + dh::HALF - 1) / dh::HALF);
       qbins[kq].push_back(std::make_pair(approx, i));

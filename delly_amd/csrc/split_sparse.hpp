@@ -16,21 +16,22 @@
 namespace dh {
 
 constexpr int SPS_MMAX = 254;                 // consensus rows the short-read sparse path takes
-constexpr int SPS_ND = 1408;                  // diagonals (n + m + 1): one tile, no halo
+constexpr int SPS_NMAX = 1280;                // window letters
+constexpr int SPS_ND = 1536;                  // diagonals (n + m + 1): one tile, no halo
 constexpr int SPS_SMAX = 32;                  // deficit levels before the dense kernels take over
 constexpr int SPS_LIST = 1024;                // run / deep-diagonal list capacity
 typedef SpTileT<SPS_ND, 0, uint8_t, 2> SpsTile;  // rows <= 254 fit a byte, level d overwrites level d - 2: 6 KB for both matrices
 
-// the junction's strings and the post stage's masks, sized for this kernel's shapes (9.5 KB of LDS per wavefront with
+// the junction's strings and the post stage's masks, sized for this kernel's shapes (9.8 KB of LDS per wavefront with
 // the tile: 16 wavefronts per CU)
 struct __attribute__((aligned(16))) StrLdsS {
   static constexpr bool has_rc = true;
-  static constexpr int ref_cap = SPS_ND;
+  static constexpr int ref_cap = SPS_NMAX;
   static constexpr int cons_cap = SPS_MMAX + 2;
   uint8_t cons[SPS_MMAX + 2];
   uint8_t rcons[SPS_MMAX + 2];
-  uint8_t ref[SPS_ND];
-  uint8_t rref[SPS_ND];
+  uint8_t ref[SPS_NMAX];
+  uint8_t rref[SPS_NMAX + 16];   // (+ slack: the compares read 8 letters from any position <= n)
 };
 struct __attribute__((aligned(16))) PostLdsS {
   unsigned long long mV[MASKW], mR[MASKW], mE[MASKW];
@@ -56,14 +57,17 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   const unsigned long long tq0 = wall_clock64();
 #endif
   JCtx X;
+  const int prior = A.res[j].status;
   junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
   if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
-    const bool final = X.out->status == 0;
+    const int st = X.out->status;
+    const bool final = st == 0;
     if (lane == 0 && final) X.out->reserved = SPS_DONE;
+    if (lane == 0 && st != 0 && prior == 0) X.out->status = 0;   // (a limit of THIS kernel's buffers only: the dense kernels start afresh)
     return final;
   }
   const int m = X.m, n = X.n;
-  if (m < 1 || n < 1 || m > SPS_MMAX || n + m + 1 > SPS_ND) return false;   // dense kernels
+  if (m < 1 || n < 1 || m > SPS_MMAX || n > SPS_NMAX || n + m + 1 > SPS_ND) return false;   // dense kernels
   if (X.dirty) return false;   // letters outside A, C, G, T, N (case matters: the forward pass compares raw bytes): dense kernels
   SparseWs W;
   W.ndp = (n + m + 2 + 63) & ~63;

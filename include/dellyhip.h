@@ -186,8 +186,8 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_sp
                              double* ms_msa, int32_t* launches);
 /* Average duration (ms) of the dominant kernel alone over the launches covered by the last
  * dellyhip_batch_kernel_ms() call (HIP events on the launch stream): split_sparse_kernel (sparse longNeedle, one
- * junction per wavefront) when every short-read junction of the batch is offered to it -- consensus <= 254 bp, window +
- * consensus <= 1407 bp, DELLYHIP_SR_SPARSE != 0 --, else the packed dense DP kernels (split_quad_kernel<KQ, KP>, four
+ * junction per wavefront) when every short-read junction of the batch is offered to it -- consensus <= 254 bp, window <=
+ * 1280 bp, window + consensus <= 1535 bp, DELLYHIP_SR_SPARSE != 0 --, else the packed dense DP kernels (split_quad_kernel<KQ, KP>, four
  * junctions per wavefront; split_pair_kernel<K> for consensus sequences of 160 .. 319 bp). */
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
