@@ -99,6 +99,7 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int lr_waves = 8;          // resident wavefronts of the strip kernel per CU when the sparse passes are on (env DELLYHIP_LR_WAVES)
   int sps_waves = 16;        // wavefronts of split_sparse_kernel per CU (env DELLYHIP_SPS_WAVES; 16 = what LDS and registers allow)
   int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
   int sparse_cost = 160;     // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
@@ -328,8 +329,8 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   if (b->lr_count > 0 && !direct) {
     a.work_list = b->work.p + b->lr_first;
     a.n_work = b->lr_count;
-    const int rounds = (b->lr_count + b->lr_blocks - 1) / b->lr_blocks;
-    const int grid = (b->lr_count + rounds - 1) / rounds;
+    a.work_counter = c->counters.p + 28;
+    const int grid = std::min(b->lr_count, b->lr_blocks);
     dh::LrArgs lr = b->lr;
     lr.realign = (c->params.reserved & 1) ? 1 : 0;
     hipLaunchKernelGGL(dh::lr_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, lr);
@@ -414,6 +415,7 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   R.off_trF = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_stack = take((uint64_t)Q * R.strip_words * 4);
+  R.off_masks = take(dh::lr_masks_bytes());
   // sparse longNeedle (sparse_needle.hpp): furthest-reaching tables for up to 256 deficit levels of this batch's
   // longest shapes (2 int16 per diagonal + 2 int32 per consensus row and level, both matrices) + the run lists
   R.sparse_bytes = 0;
@@ -428,7 +430,7 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   R.ws_stride = o;
   // resident wavefronts: the sparse passes are latency-bound on their table loads (L2 / HBM), so as many as the
   // registers allow (156 VGPRs: 3 per SIMD) -- LDS permitting -- and the workspace budget holds
-  b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * (c->use_sparse ? 5 : 4)));
+  b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * (c->use_sparse ? c->lr_waves : 4)));
   b->lr_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lr_blocks, ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1)));
   int rc = b->lr_ws.reserve((size_t)R.ws_stride * b->lr_blocks);
   if (rc) return rc;
@@ -625,6 +627,10 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
   b->ins_first = (int)work.size();
   b->ins_count = (int)ins.size();
   work.insert(work.end(), ins.begin(), ins.end());
+  if (!b->h_win_len.empty())   // largest consensus x window first: the strip kernel's wavefronts pull from this list
+    std::stable_sort(lrv.begin(), lrv.end(), [&](int32_t x, int32_t y) {
+      return (int64_t)b->h_cons_len[x] * b->h_win_len[x] > (int64_t)b->h_cons_len[y] * b->h_win_len[y];
+    });
   b->lr_first = (int)work.size();
   b->lr_count = (int)lrv.size();
   work.insert(work.end(), lrv.begin(), lrv.end());
@@ -756,6 +762,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_LR_WAVES")) c->lr_waves = std::max(1, std::min(8, atoi(t)));
   if (const char* t = getenv("DELLYHIP_SPS_WAVES")) c->sps_waves = std::max(1, std::min(20, atoi(t)));
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;

@@ -43,6 +43,7 @@ struct LrArgs {
   uint64_t off_rcons, off_ref, off_rref, off_bnd0, off_bnd1, off_br, off_trF, off_trR, off_stack;  // cons at 0
   uint64_t strip_words;   // code words per strip
   int32_t realign;        // src/split.h:564-572
+  uint64_t off_masks;     // column masks of alignments beyond LR_MASKW_LDS * 64 columns (lr_masks_bytes())
   uint64_t off_sparse;    // furthest-reaching tables of the sparse longNeedle (sparse_needle.hpp)
   uint64_t sparse_bytes;  // 0: dense strip passes only
   int32_t sparse_cost;    // predicted deficit beyond which the dense strips are taken (SparseWs::pred_cap)
@@ -61,9 +62,21 @@ struct __attribute__((aligned(16))) PostLR {
 };
 // the strip kernel's LDS: the phases of a junction use it one after the other -- orientation test (bit-vector masks),
 // sparse longNeedle (level tiles), column masks of the result
+// column masks of lr_kernel: alignments of up to LR_MASKW_LDS * 64 columns (C4 shapes: ~10 k) keep them in LDS, longer ones
+// in the wavefront's workspace -- the full-size PostLR cost 22 KB of LDS per block (6 resident blocks per CU instead of 8)
+constexpr int LR_MASKW_LDS = 288;
+struct __attribute__((aligned(16))) PostLRS {
+  unsigned long long mV[LR_MASKW_LDS], mR[LR_MASKW_LDS], mE[LR_MASKW_LDS];
+  int32_t cumV[LR_MASKW_LDS + 1], cumR[LR_MASKW_LDS + 1];
+};
+struct PostRef {
+  unsigned long long *mV, *mR, *mE;
+  int32_t *cumV, *cumR;
+};
+__host__ __device__ inline uint64_t lr_masks_bytes() { return 3ull * LR_MASKW * 8 + 2ull * (LR_MASKW + 1) * 4; }
 struct __attribute__((aligned(16))) LrLds {
   union {
-    PostLR post;
+    PostLRS post;
     SpTile tile;
     struct {
       MyersLds<MYERS_NW> myers;
@@ -466,7 +479,18 @@ __device__ __forceinline__ int lr_dir_and_trace(const uint8_t* rowstr, const uin
 
 // ---- one long-read junction per wavefront ------------------------------------------------
 __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane) {
-  PostLR& L = LL.u.post;
+  PostRef L{LL.u.post.mV, LL.u.post.mR, LL.u.post.mE, LL.u.post.cumV, LL.u.post.cumR};
+  int maskw = LR_MASKW_LDS;
+  auto pick_masks = [&](int m_, int n_) {   // (call once m and n are known, before the masks are built)
+    const int need = (m_ + n_ + 127) / 64 + 2;
+    if (need > LR_MASKW_LDS) {
+      unsigned long long* g = reinterpret_cast<unsigned long long*>(ws + R.off_masks);
+      L = PostRef{g, g + LR_MASKW, g + 2 * LR_MASKW, reinterpret_cast<int32_t*>(g + 3 * LR_MASKW), reinterpret_cast<int32_t*>(g + 3 * LR_MASKW) + (LR_MASKW + 1)};
+      maskw = min(LR_MASKW, need);
+    } else {
+      maskw = need;
+    }
+  };
   MyersLds<MYERS_NW>& ML = LL.u.o.myers;
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
@@ -684,8 +708,9 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL
             if (lane == 0) X.out->status = DELLYHIP_E_LIMIT;
             X.go = false;
           } else {
-            spLtot = sparse_masks(L, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, LR_MASKW, lane, spPosC,
-                                  [](PostLR& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+            pick_masks(m, n);
+            spLtot = sparse_masks(L, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, maskw, lane, spPosC,
+                                  [](PostRef& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
             masks_finish(A, X, S, L, spLtot, spPosC, lane);
           }
         }
@@ -818,7 +843,8 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL
       if (lane == 0) X.out->status = DELLYHIP_E_LIMIT;
       go = false;
     } else {
-      Ltot = needle_masks(L, trF, nF, tvF, thF, trR, nR, tvR, thR, gapref, LR_MASKW, lane, posC);
+      pick_masks(m, n);
+      Ltot = needle_masks(L, trF, nF, tvF, thF, trR, nR, tvR, thR, gapref, maskw, lane, posC);
       masks_finish(A, X, S, L, Ltot, posC, lane);
     }
   }
@@ -829,10 +855,16 @@ __global__ __launch_bounds__(WAVE) void lr_kernel(SplitArgs A, LrArgs R) {
   __shared__ LrLds L;
   const int lane = threadIdx.x;
   uint8_t* ws = R.ws + (size_t)blockIdx.x * R.ws_stride;
-  for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
+  // junction latencies differ by an order of magnitude (levels of the sparse passes, dense fallback): the wavefronts
+  // pull from the host-sorted list (largest consensus x window first) instead of striding over it
+  for (;;) {
+    int w = 0;
+    if (lane == 0) w = atomicAdd(A.work_counter, 1);
+    w = rfl(w);
+    if (w >= A.n_work) break;
     const int j = A.work_list[w];
-    if (j < 0) continue;
-    process_lr(A, R, j, L, ws, lane);
+    if (j >= 0) process_lr(A, R, j, L, ws, lane);
+    __syncthreads();
   }
 }
 

@@ -212,7 +212,7 @@ struct __attribute__((aligned(16))) SpTileT {
   static __device__ __forceinline__ int dec(ELEM e) { return narrow ? (int)e - 1 : (int)e; }
   static __device__ __forceinline__ ELEM enc(int v) { return narrow ? (ELEM)(max(v, -1) + 1) : (ELEM)v; }
 };
-typedef SpTileT<960, 12288, int16_t, 2> SpTile;      // long reads: 3 % halo overhead, letters staged per tile, two rolling rows
+typedef SpTileT<960, 8192, int16_t, 2> SpTile;       // long reads: 3 % halo overhead, letters staged per tile, two rolling rows
 
 // 8 letters at an arbitrary LDS byte offset: two aligned 8-byte reads + a funnel shift
 __device__ __forceinline__ uint64_t sp_lds8(const uint8_t* p) {
