@@ -1847,6 +1847,7 @@ struct dellyhip_nwjobs {
   DevBuf<int8_t> hbuf;          // strip passes of pairs with both strings beyond MYERS_ROWS
   uint64_t hbuf_half = 0;
   int grid = 1;
+  int pairwise = 0;             // adjacent jobs side by side in one wavefront (most pairs gain from it)
   hipStream_t last_stream = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   ~dellyhip_nwjobs() {
@@ -1874,6 +1875,12 @@ int dellyhip_nwjobs_upload(dellyhip_ctx* c, uint64_t n_jobs, const dellyhip_nw_j
   for (uint64_t i = 0; i < n_jobs; ++i)
     if (jobs[i].query_len > (uint32_t)dh::MYERS_ROWS && jobs[i].target_len > (uint32_t)dh::MYERS_ROWS)
       longest = std::max<uint64_t>(longest, std::max(jobs[i].query_len, jobs[i].target_len));
+  {
+    uint64_t pays = 0;
+    for (uint64_t i = 0; i + 1 < n_jobs; i += 2)
+      pays += dh::myers_x2_pays((int)std::min(jobs[i].query_len, jobs[i].target_len), (int)std::min(jobs[i + 1].query_len, jobs[i + 1].target_len)) ? 1 : 0;
+    b->pairwise = (n_jobs >= 2 && pays * 10 >= (n_jobs / 2) * 6) ? 1 : 0;
+  }
   if (longest) {
     b->hbuf_half = (longest + 16 + 255) & ~255ull;
     if ((rc = b->hbuf.alloc((size_t)2 * b->hbuf_half * b->grid))) return rc;
@@ -1894,7 +1901,7 @@ int dellyhip_nwjobs_run(dellyhip_ctx* c, dellyhip_nwjobs* b, void* stream_) {
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n, b->next.p, b->hbuf.p, b->hbuf_half};
+  dh::NwArgs a{b->jobs.p, b->blob.p, b->dist.p, b->n, b->next.p, b->hbuf.p, b->hbuf_half, b->pairwise};
   const int grid = b->grid;
   HIPCHK(hipMemsetAsync(b->next.p, 0, sizeof(uint32_t), st));
   HIPCHK(hipEventRecord(e0, st));

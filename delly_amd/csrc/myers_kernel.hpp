@@ -378,6 +378,145 @@ __device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pa
   return __shfl(s, lastlane);
 }
 
+// TWO independent pairs per wavefront, one per 32-lane half (lanes 0-31: pair A, lanes 32-63: pair B): a 2.3 kb read is 72
+// words of 32 rows -- with one pair per wavefront that takes two words per lane on all 64 lanes (44 % padding), with
+// two pairs three words per lane on 32 lanes each (25 % padding) and the step costs ~1.3x.  Same recurrence and
+// staging as myers_nw_fast; lane 32 starts pair B's carry / text chain instead of continuing lane 31's.  Patterns of up
+// to 32 * 32 * NWORDS rows.  Returns false when a pattern holds bytes outside ACGTN (the caller falls back, per pair).
+template <int NWORDS>
+__device__ __noinline__ bool myers_nw_fast_x2(MyersLds<NWORDS>& L, const uint8_t* patA, int pnA, const uint8_t* txtA, int tnA,
+                                              const uint8_t* patB, int pnB, const uint8_t* txtB, int tnB, int lane, int& dA, int& dB) {
+  const bool hiHalf = lane >= 32;
+  const int hl = lane & 31;
+  const uint8_t* pattern = hiHalf ? patB : patA;
+  const uint8_t* text = hiHalf ? txtB : txtA;
+  const int pn = hiHalf ? pnB : pnA, tn = hiHalf ? tnB : tnA;
+  const int row0 = hl * 32 * NWORDS;
+  bool foreign = false;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    uint32_t* slot = &L.eq[w * 6 * WAVE + lane];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) slot[k * WAVE] = 0;
+    const int rbeg = row0 + w * 32;
+    if (rbeg < pn) {
+      uint4 v[2];
+      __builtin_memcpy(&v[0], pattern + rbeg, 16);
+      __builtin_memcpy(&v[1], pattern + rbeg + 16, 16);
+      const uint32_t wd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int code = (int)L.lut[(wd[q >> 2] >> ((q & 3) * 8)) & 0xff];
+        const bool in = rbeg + q < pn;
+        foreign |= in && code == 5 * WAVE;
+        if (in) slot[code] |= 1u << q;
+      }
+    }
+    slot[5 * WAVE] = 0;
+  }
+  if (__ballot(foreign)) return false;
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = 0xffffffffu;
+    Mv[w] = 0;
+  }
+  int score = row0 + 32 * NWORDS;
+  const int lastA = (pnA - 1) / (32 * NWORDS), lastB = (pnB - 1) / (32 * NWORDS);
+  const int T = max(tnA + lastA, tnB + lastB);
+  const int nblk = (T + 15) >> 4;
+  const bool first_of_b = lane == 32;
+  int hcarry = 1;
+  int c = -hl;
+  auto load_chunk = [&](int blk) -> int {
+    const int ci = blk * 16 + (lane & 15);
+    return (int)L.lut[(ci < tn) ? (int)text[ci] : 0];
+  };
+  int chunk = load_chunk(0);
+  int bs = dpp_from_prev(0, __builtin_amdgcn_readlane(chunk, 0));
+  bs = first_of_b ? __builtin_amdgcn_readlane(chunk, 32) : bs;
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = L.eq[w * 6 * WAVE + bs + lane];
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int chunk_next = load_chunk(blk + 1);
+#pragma unroll 1
+    for (int f = 0; f < 16; ++f) {
+      uint32_t EqC[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+      const int newA = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 0) : __builtin_amdgcn_readlane(chunk, f + 1);
+      const int newB = (f == 15) ? __builtin_amdgcn_readlane(chunk_next, 32) : __builtin_amdgcn_readlane(chunk, 32 + f + 1);
+      bs = dpp_from_prev(bs, newA);
+      bs = first_of_b ? newB : bs;
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) EqN[w] = L.eq[w * 6 * WAVE + bs + lane];
+      int hin = dpp_from_prev(hcarry, 1);
+      hin = first_of_b ? 1 : hin;
+      c += 1;
+      const bool valid = (unsigned)(c - 1) < (unsigned)tn;
+      uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        uint32_t Eq = EqC[w];
+        const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470 (Hyyro's block step), 32-bit words
+        const uint32_t Xv = Eq | Mv[w];
+        Eq |= hinNeg;
+        const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+        uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+        uint32_t Mh = Pv[w] & Xh;
+        const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+        Ph <<= 1;
+        Mh <<= 1;
+        Mh |= hinNeg;
+        Ph |= (hin > 0) ? 1u : 0u;
+        nP[w] = Mh | ~(Xv | Ph);
+        nM[w] = Ph & Xv;
+        hin = hout;
+      }
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) {
+        Pv[w] = valid ? nP[w] : Pv[w];
+        Mv[w] = valid ? nM[w] : Mv[w];
+      }
+      hcarry = valid ? hin : hcarry;
+      score += valid ? hin : 0;
+    }
+    chunk = chunk_next;
+  }
+  int s = score;
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, lo + 32 - pn));
+    if (nb > 0) {
+      const uint32_t mk = (nb >= 32) ? 0xffffffffu : (~0u << (32 - nb));
+      s -= __popc(Pv[w] & mk);
+      s += __popc(Mv[w] & mk);
+    }
+  }
+  dA = __shfl(s, lastA);
+  dB = __shfl(s, 32 + lastB);
+  return true;
+}
+// rows one half-wavefront holds
+constexpr int MYERS_HALF_ROWS = 32 * 32 * MYERS_NW;
+// side by side pays when the shared step (words per lane for the longer pattern on 32 lanes) is cheaper than the two
+// separate passes (words per lane on 64 lanes each): 2.3 kb reads 3 < 2 + 2, 1.5 kb strings 2 = 1 + 1 (measured: no gain)
+__host__ __device__ __forceinline__ bool myers_x2_pays(int pn0, int pn1) {
+  if (pn0 < 1 || pn1 < 1 || pn0 > MYERS_HALF_ROWS || pn1 > MYERS_HALF_ROWS) return false;
+  const int both = ((pn0 > pn1 ? pn0 : pn1) + 1023) >> 10;
+  const int apart = ((pn0 + 2047) >> 11) + ((pn1 + 2047) >> 11);
+  return both < apart;
+}
+__device__ __forceinline__ bool myers_nw_auto_x2(MyersLds<MYERS_NW>& L, const uint8_t* patA, int pnA, const uint8_t* txtA, int tnA,
+                                                 const uint8_t* patB, int pnB, const uint8_t* txtB, int tnB, int lane, int& dA, int& dB) {
+  const int pmax = max(pnA, pnB);
+  if (pmax <= 32 * 32) return myers_nw_fast_x2<1>(reinterpret_cast<MyersLds<1>&>(L), patA, pnA, txtA, tnA, patB, pnB, txtB, tnB, lane, dA, dB);
+  if (pmax <= 32 * 64) return myers_nw_fast_x2<2>(reinterpret_cast<MyersLds<2>&>(L), patA, pnA, txtA, tnA, patB, pnB, txtB, tnB, lane, dA, dB);
+  return myers_nw_fast_x2<3>(L, patA, pnA, txtA, tnA, patB, pnB, txtB, tnB, lane, dA, dB);
+}
+
 // Two patterns of the same length against one text in lock-step (the orientation test of _alignConsensus: consensus and
 // its reverse complement vs the window, src/split.h:564-572): one pass over the text, twice the independent work per
 // step.  L2: a second mask area for pattern B.  Returns false when a pattern holds bytes outside ACGTN (caller falls back).
@@ -550,7 +689,8 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
   const int lane = threadIdx.x;
   myers_lut_init(L.lut, lane);
   __syncthreads();
-  for (int item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+  struct Item { int j, a, bb, la, lb; uint64_t oa, ob; };
+  auto describe = [&](int item) -> Item {
     // junction of this item: binary search in pair_first
     int lo = 0, hi = A.n_junc;
     while (hi - lo > 1) {
@@ -558,17 +698,33 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
       if (A.pair_first[mid] <= item) lo = mid;
       else hi = mid;
     }
-    const int j = lo;
-    const dellyhip_junction J = A.junc[j];
+    Item I;
+    I.j = lo;
+    const dellyhip_junction J = A.junc[I.j];
     const int N = J.n_seq;
-    int rem = item - A.pair_first[j], a = 0;
+    int rem = item - A.pair_first[I.j], a = 0;
     while (rem >= N - 1 - a) {
       rem -= N - 1 - a;
       ++a;
     }
-    const int bb = a + 1 + rem;
-    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + bb];
-    const int la = (int)(A.seq_off[J.seq_first + a + 1] - oa), lb = (int)(A.seq_off[J.seq_first + bb + 1] - ob);
+    I.a = a;
+    I.bb = a + 1 + rem;
+    I.oa = A.seq_off[J.seq_first + I.a];
+    I.ob = A.seq_off[J.seq_first + I.bb];
+    I.la = (int)(A.seq_off[J.seq_first + I.a + 1] - I.oa);
+    I.lb = (int)(A.seq_off[J.seq_first + I.bb + 1] - I.ob);
+    return I;
+  };
+  auto store = [&](const Item& I, int d) {
+    if (lane == 0) {
+      int32_t* E = A.edit + (size_t)I.j * A.nrmax * A.nrmax;
+      E[I.a * A.nrmax + I.bb] = d;
+      E[I.bb * A.nrmax + I.a] = d;
+    }
+  };
+  auto single = [&](const Item& I) {
+    const int la = I.la, lb = I.lb;
+    const uint64_t oa = I.oa, ob = I.ob;
     int d;
     if (la == 0 || lb == 0) d = max(la, lb);                 // edlib.cpp:160-166
     else if (la > MYERS_ROWS && lb > MYERS_ROWS) {           // strips of 6144 rows (pattern = the shorter read)
@@ -579,10 +735,29 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
     }
     else if (la <= lb || lb > MYERS_ROWS) d = myers_nw_auto(L, A.seq_blob + oa, la, A.seq_blob + ob, lb, lane);   // (the blob is padded)
     else d = myers_nw_auto(L, A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
-    if (lane == 0) {
-      int32_t* E = A.edit + (size_t)j * A.nrmax * A.nrmax;
-      E[a * A.nrmax + bb] = d;
-      E[bb * A.nrmax + a] = d;
+    store(I, d);
+  };
+  // items 2k and 2k + 1 side by side in the two halves of the wavefront when both shorter reads fit 3072 rows
+  const int n_pairs_of_items = (A.n_items + 1) >> 1;
+  for (int k = blockIdx.x; k < n_pairs_of_items; k += gridDim.x) {
+    const Item I0 = describe(2 * k);
+    const bool two = 2 * k + 1 < A.n_items;
+    bool done = false;
+    if (two) {
+      const Item I1 = describe(2 * k + 1);
+      const int pn0 = min(I0.la, I0.lb), pn1 = min(I1.la, I1.lb);
+      if (myers_x2_pays(pn0, pn1)) {
+        const uint8_t* a0 = A.seq_blob + I0.oa; const uint8_t* b0 = A.seq_blob + I0.ob;
+        const uint8_t* a1 = A.seq_blob + I1.oa; const uint8_t* b1 = A.seq_blob + I1.ob;
+        int d0 = 0, d1 = 0;
+        done = myers_nw_auto_x2(L, (I0.la <= I0.lb) ? a0 : b0, pn0, (I0.la <= I0.lb) ? b0 : a0, max(I0.la, I0.lb),
+                                (I1.la <= I1.lb) ? a1 : b1, pn1, (I1.la <= I1.lb) ? b1 : a1, max(I1.la, I1.lb), lane, d0, d1);
+        done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+        if (done) { store(I0, d0); store(I1, d1); }
+      }
+      if (!done) { single(I0); single(I1); }
+    } else {
+      single(I0);
     }
   }
 }
@@ -596,6 +771,7 @@ struct NwArgs {
   uint32_t* next;   // work counter, zeroed before the launch: wavefronts pull job indices (pair lengths vary)
   int8_t* hbuf;     // per block: 2 x hbuf_half bytes for pairs with both strings > MYERS_ROWS (strip passes); 0 = none
   uint64_t hbuf_half;
+  int32_t pairwise; // 1: wavefronts pull two adjacent jobs at a time and run them side by side where that pays (host's call)
 };
 
 __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
@@ -608,10 +784,10 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
   const int n_items = __builtin_amdgcn_readfirstlane((int)(uint32_t)A.n_jobs);
   auto fetch = [&]() -> int {
     int v = 0;
-    if (lane == 0) v = (int)atomicAdd(A.next, 1u);
+    if (lane == 0) v = (int)atomicAdd(A.next, A.pairwise ? 2u : 1u);
     return __builtin_amdgcn_readfirstlane(v);
   };
-  for (int item = fetch(); item < n_items; item = fetch()) {
+  auto single = [&](int item) {
     const dellyhip_nw_job J = A.jobs[item];
     const int la = (int)J.query_len, lb = (int)J.target_len;
     const uint8_t* a = A.blob + J.query_off;
@@ -630,6 +806,29 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
       d = myers_nw_auto(L, pat, pn, txt, tn, lane);
     }
     if (lane == 0) A.dist[item] = d;
+  };
+  // two jobs per fetch: when both patterns fit a half-wavefront they run side by side (myers_nw_fast_x2)
+  for (int item = fetch(); item < n_items; item = fetch()) {
+    if (!A.pairwise) { single(item); continue; }
+    bool done = false;
+    if (item + 1 < n_items) {
+      const dellyhip_nw_job J0 = A.jobs[item], J1 = A.jobs[item + 1];
+      const int la0 = (int)J0.query_len, lb0 = (int)J0.target_len, la1 = (int)J1.query_len, lb1 = (int)J1.target_len;
+      const int pn0 = min(la0, lb0), pn1 = min(la1, lb1);
+      if (myers_x2_pays(pn0, pn1)) {
+        const uint8_t* a0 = A.blob + J0.query_off; const uint8_t* b0 = A.blob + J0.target_off;
+        const uint8_t* a1 = A.blob + J1.query_off; const uint8_t* b1 = A.blob + J1.target_off;
+        int d0 = 0, d1 = 0;
+        done = myers_nw_auto_x2(L, (la0 <= lb0) ? a0 : b0, pn0, (la0 <= lb0) ? b0 : a0, max(la0, lb0),
+                                (la1 <= lb1) ? a1 : b1, pn1, (la1 <= lb1) ? b1 : a1, max(la1, lb1), lane, d0, d1);
+        done = __builtin_amdgcn_readfirstlane((int)done) != 0;
+        if (done && lane == 0) { A.dist[item] = d0; A.dist[item + 1] = d1; }
+      }
+    }
+    if (!done) {
+      single(item);
+      if (item + 1 < n_items) single(item + 1);
+    }
   }
 }
 

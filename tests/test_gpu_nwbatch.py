@@ -42,6 +42,15 @@ def test_nw_batch_three_word_patterns(gpu_ctx, port):
     assert int(jobs["query_len"].min()) > 4096
 
 
+@pytest.mark.parametrize("lo,hi,n", [(60, 500, 301), (1050, 1500, 120), (100, 1500, 200)])
+def test_nw_batch_two_pairs_per_wavefront(gpu_ctx, port, lo, hi, n):
+    """strings of 120 .. 1000 bytes (one word per lane for two pairs), 2.1 .. 3 kb (three words) and a mix where only some
+    adjacent jobs pay: the side-by-side routine myers_nw_fast_x2, odd job counts, weird bytes (fallback per pair)"""
+    jobs, blob = synth.make_nw_jobs(n, seed=91 + lo, weird=(lo == 100), min_half=lo, max_half=hi)
+    want = port.edit_distance_nw_batch(jobs, blob, n_threads=8)
+    _check(gpu_ctx.edit_distance_nw_batch(jobs, blob), want, jobs)
+
+
 def test_nw_batch_edges_and_resident(gpu_ctx, port):
     assert gpu_ctx.edit_distance_nw_batch(np.zeros(0, dtype=abi.nw_job_dtype()), np.zeros(0, dtype=np.uint8)).shape[0] == 0
     jobs, blob = synth.make_nw_jobs(300, seed=5)
