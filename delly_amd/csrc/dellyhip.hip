@@ -150,6 +150,12 @@ struct dellyhip_batch {
   // long-read MSA of insertions (with_msa == 2, svt 4: msaWfa)
   DevBuf<int32_t> wfa_list;
   DevBuf<uint8_t> wfa_ws;
+  // the pairwise stage of msaWfa as its own kernel (wfa_pairs_kernel): one (junction, read pair) per wavefront
+  DevBuf<int32_t> wfa_pair_first, wfa_edit;
+  DevBuf<uint8_t> wfa_pair_ws;
+  DevBuf<uint32_t> wfa_next;
+  dh::WfaPairArgs wfa_pairs{};
+  int wfa_items = 0, wfa_pair_grid = 1;
   dh::LrWfaArgs wfa{};
   int wfa_count = 0, wfa_blocks = 0;
   DevBuf<SmallInv> small_inv;
@@ -817,7 +823,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->small_inv.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -960,7 +966,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       bool long_pairs = false;   // a junction with two reads beyond the rows of one bit-vector pass: strip passes need a byte workspace
       for (int i = 0; i < n; ++i) {
         const int N = std::max(0, std::min(junc[i].n_seq, (int)dh::LM_NR));
-        pf[i + 1] = pf[i] + ((junc[i].n_seq <= dh::LM_NR) ? N * (N - 1) / 2 : 0);
+        pf[i + 1] = pf[i] + ((junc[i].n_seq <= dh::LM_NR && junc[i].svt != 4) ? N * (N - 1) / 2 : 0);   // (insertions: msaWfa's own scores)
         int nlong = 0;
         for (int k = 0; k < junc[i].n_seq; ++k)
           nlong += (seq_off[junc[i].seq_first + k + 1] - seq_off[junc[i].seq_first + k] > (uint64_t)dh::MYERS_ROWS) ? 1 : 0;
@@ -995,6 +1001,40 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa workspace", e));
         b->wfa.ws = b->wfa_ws.p;
+        // pairwise scores of every insertion junction: work list + workspace of wfa_pairs_kernel
+        std::vector<int32_t> wpf(n + 1, 0);
+        for (int i = 0; i < n; ++i) {
+          const int N = junc[i].n_seq;
+          wpf[i + 1] = wpf[i] + ((junc[i].svt == 4 && N >= 2 && N <= dh::LM_NR) ? N * (N - 1) / 2 : 0);
+        }
+        b->wfa_items = wpf[n];
+        dh::WfaPairArgs& WP = b->wfa_pairs;
+        WP.ncap = b->wfa.ncap;
+        WP.acap = b->wfa.acap;
+        WP.off_tabJ = (uint64_t)dh::WFA_KTAB * 4;
+        WP.off_diag = 2 * WP.off_tabJ;
+        WP.off_hb = WP.off_diag + (((uint64_t)2 * maxlen + 64 + 63) & ~63ull) * 4;
+        WP.hb_half = (maxlen > dh::MYERS_ROWS) ? (((uint64_t)maxlen + 16 + 255) & ~255ull) : 0;
+        WP.ws_stride = (WP.off_hb + 2 * WP.hb_half + 255) & ~255ull;
+        b->wfa_pair_grid = std::max(1, std::min(b->wfa_items, c->n_cu * 16));
+        b->wfa_pair_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->wfa_pair_grid, ws_budget_bytes() / WP.ws_stride));
+        if (b->wfa_items > 0) {
+          if ((rc = b->wfa_pair_first.alloc(n + 1)) || (rc = b->wfa_edit.alloc((size_t)n * dh::LM_NR * dh::LM_NR)) ||
+              (rc = b->wfa_pair_ws.alloc((size_t)WP.ws_stride * b->wfa_pair_grid)) || (rc = b->wfa_next.alloc(1)))
+            return bail(rc);
+          e = hipMemcpy(b->wfa_pair_first.p, wpf.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+          if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa pair list", e));
+          e = hipMemsetAsync(b->wfa_pair_ws.p, 0, (size_t)WP.ws_stride * b->wfa_pair_grid, c->stream);   // k-mer tables start (and are kept) all zero
+          if (e == hipSuccess) e = hipMemsetAsync(b->wfa_edit.p, 0, (size_t)n * dh::LM_NR * dh::LM_NR * sizeof(int32_t), c->stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+          if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa pair workspace", e));
+          WP.pair_first = b->wfa_pair_first.p;
+          WP.edit = b->wfa_edit.p;
+          WP.ws = b->wfa_pair_ws.p;
+          WP.next = b->wfa_next.p;
+          WP.n_junc = n;
+          WP.n_items = b->wfa_items;
+        }
       }
     } else {
       const dh::MsaPlan& mp = b->msa_plan;
@@ -1063,6 +1103,15 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
       W.p = c->params; W.res = b->res.p; W.out_blob = b->out_blob.p; W.out_stride = b->out_stride;
       W.out_cons_cap = b->out_cons_cap; W.cons_len = b->cons_len.p;
       W.work_list = b->wfa_list.p; W.n_work = b->wfa_count; W.use_anchors = 1;
+      W.edit_all = nullptr;
+      if (b->wfa_items > 0) {   // the pairwise scores of all junctions first: throughput work for the whole chip
+        dh::WfaPairArgs WP = b->wfa_pairs;
+        WP.junc = b->junc.p; WP.seq_blob = b->seq_blob.p; WP.seq_off = b->seq_off.p;
+        HIPCHK(hipMemsetAsync(WP.next, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(dh::wfa_pairs_kernel, dim3(b->wfa_pair_grid), dim3(dh::WAVE), 0, s, WP);
+        HIPCHK(hipGetLastError());
+        W.edit_all = b->wfa_edit.p;
+      }
       hipLaunchKernelGGL(dh::lrwfa_kernel, dim3(b->wfa_blocks), dim3(dh::WAVE), 0, s, W);
       HIPCHK(hipGetLastError());
     }

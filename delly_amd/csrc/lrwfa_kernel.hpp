@@ -43,6 +43,7 @@ struct LrWfaArgs {
   uint64_t off_alnB, off_astr, off_bnd, off_ops, off_tmp, off_cons, off_dirs, off_tabI, off_tabJ, off_diag, off_supA, off_supB,
       off_pre, off_suf, off_edit;   // alnA at 0
   uint64_t strip_words;
+  const int32_t* edit_all;   // batch mode: the pairwise scores of every junction (LM_NR x LM_NR each), filled by wfa_pairs_kernel
 };
 
 __device__ __forceinline__ uint32_t wfa_char_to_int(uint8_t c) {   // charToInt, assemble.h:475-498
@@ -112,6 +113,83 @@ __device__ __forceinline__ int wfa_best_diagonal(const uint8_t* sJ, int lenI, in
   return rfl(bestDiag) - lenJ;
 }
 
+// ---- the pairwise stage of msaWfa for a whole batch: one (junction, read pair) per wavefront ---------------------------
+struct WfaPairArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  const int32_t* pair_first;   // first item of junction j (prefix sums of n (n - 1) / 2 over the svt 4 junctions), n_junc + 1 entries
+  int32_t n_junc, n_items;
+  int32_t ncap, acap;          // the limits lrwfa_junction applies to every read of a junction
+  int32_t* edit;               // edit[j * LM_NR * LM_NR + a * LM_NR + b]
+  uint8_t* ws;                 // per block: k-mer tables of both reads (all zero between items), diagonal votes, strip buffers
+  uint64_t ws_stride, off_tabJ, off_diag, off_hb, hb_half;
+  uint32_t* next;              // work counter
+};
+
+__global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
+  __shared__ MyersLds<MYERS_NW> L;
+  const int lane = threadIdx.x;
+  myers_lut_init(L.lut, lane);
+  __syncthreads();
+  uint8_t* ws = A.ws + (size_t)blockIdx.x * A.ws_stride;
+  uint32_t* tabI = reinterpret_cast<uint32_t*>(ws);
+  uint32_t* tabJ = reinterpret_cast<uint32_t*>(ws + A.off_tabJ);
+  uint32_t* diag = reinterpret_cast<uint32_t*>(ws + A.off_diag);
+  int8_t* hb = reinterpret_cast<int8_t*>(ws + A.off_hb);
+  const int n_items = __builtin_amdgcn_readfirstlane(A.n_items);
+  auto fetch = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = (int)atomicAdd(A.next, 1u);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  for (int item = fetch(); item < n_items; item = fetch()) {
+    int lo = 0, hi = A.n_junc;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (A.pair_first[mid] <= item) lo = mid;
+      else hi = mid;
+    }
+    const int j = lo;
+    const dellyhip_junction J = A.junc[j];
+    const int N = J.n_seq;
+    int rem = item - A.pair_first[j], a = 0;
+    while (rem >= N - 1 - a) {
+      rem -= N - 1 - a;
+      ++a;
+    }
+    const int b = a + 1 + rem;
+    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + b];
+    const int lenI = (int)(A.seq_off[J.seq_first + a + 1] - oa), lenJ = (int)(A.seq_off[J.seq_first + b + 1] - ob);
+    // (a junction with a read outside these limits is flagged by lrwfa_junction and never looks at its scores)
+    if (lenI > A.ncap || lenI > A.acap - 2 || lenI < WFA_KMER + 1 || lenJ > A.ncap || lenJ > A.acap - 2 || lenJ < WFA_KMER + 1) continue;
+    const uint8_t* sI = A.seq_blob + oa;
+    const uint8_t* sJ = A.seq_blob + ob;
+    wfa_fill_table(sI, lenI, tabI, lane);
+    wfa_fill_table(sJ, lenJ, tabJ, lane);
+    const int bd = wfa_best_diagonal(sJ, lenI, lenJ, tabI, tabJ, diag, lane);
+    wfa_clear_table(sJ, lenJ, tabJ, lane);
+    wfa_clear_table(sI, lenI, tabI, lane);
+    uint32_t oI, oJ, seqlen;
+    if (bd >= 0) { seqlen = min((uint32_t)lenI - (uint32_t)bd, (uint32_t)lenJ); oI = (uint32_t)bd; oJ = 0; }
+    else { seqlen = min((uint32_t)lenJ + (uint32_t)bd, (uint32_t)lenI); oI = 0; oJ = (uint32_t)(-bd); }
+    const uint32_t lI = min(seqlen, (uint32_t)lenI - oI), lJ = min(seqlen, (uint32_t)lenJ - oJ);   // substr clamps
+    int d;
+    if (lI == 0 || lJ == 0) d = (int)max(lI, lJ);
+    else if (lI > (uint32_t)MYERS_ROWS && lJ > (uint32_t)MYERS_ROWS) {
+      d = (A.hb_half && (uint64_t)max(lI, lJ) + 16 <= A.hb_half)
+              ? rfl(myers_nw_big(sI + oI, (int)lI, sJ + oJ, (int)lJ, hb, hb + A.hb_half, lane)) : -1;
+    } else if (lI <= lJ) d = rfl(myers_nw_auto(L, sI + oI, (int)lI, sJ + oJ, (int)lJ, lane));   // (pattern = the shorter string: the distance is symmetric)
+    else d = rfl(myers_nw_auto(L, sJ + oJ, (int)lJ, sI + oI, (int)lI, lane));
+    const int score = (d < 0) ? -1 : (d * 1000) / (int)max(lI, lJ);
+    if (lane == 0) {
+      int32_t* E = A.edit + (size_t)j * LM_NR * LM_NR;
+      E[a * LM_NR + b] = score;
+      E[b * LM_NR + a] = score;
+    }
+  }
+}
+
 // msaWfa for one junction
 __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* ws, int lane) {
   const dellyhip_junction J = A.junc[j];
@@ -119,6 +197,9 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
   uint8_t* cons_out = A.out_blob + (size_t)j * A.out_stride;
   const int N = J.n_seq;
   int status = 0, cons_len = 0, rows = 0;
+#ifdef DH_LR_TIMING
+  unsigned long long tw0 = 0, tw1 = 0, tw2 = 0;
+#endif
   uint8_t* alnA = ws;
   uint8_t* alnB = ws + A.off_alnB;
   uint8_t* astr = ws + A.off_astr;
@@ -134,7 +215,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
   uint8_t* supB = ws + A.off_supB;
   uint8_t* pre = ws + A.off_pre;
   uint8_t* suf = ws + A.off_suf;
-  int32_t* E = reinterpret_cast<int32_t*>(ws + A.off_edit);
+  int32_t* E = A.edit_all ? const_cast<int32_t*>(A.edit_all) + (size_t)j * LM_NR * LM_NR : reinterpret_cast<int32_t*>(ws + A.off_edit);
   const int bnd_stride = max(A.ncap, A.acap) + 128;
   const int acap = A.acap;
   const int ops_cap = 2 * max(acap, A.ncap) + 32;
@@ -184,9 +265,14 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+#ifdef DH_LR_TIMING
+    tw0 = tw1 = tw2 = wall_clock64();
+#endif
     if (!status) {
       // ---- pairwise scores: diagonal seeding, trimmed NW distance, per mille of the length (:551-574)
-      for (int a = 0; a < N; ++a) {
+      // (batch mode: wfa_pairs_kernel has filled E -- N (N - 1) / 2 independent pairs are throughput work for the whole
+      //  chip, not 2/3 of this wavefront's latency)
+      for (int a = 0; a < N && !A.edit_all; ++a) {
         const uint8_t* sI = blob + L.roff[a];
         const int lenI = L.rlen[a];
         wfa_fill_table(sI, lenI, tabI, lane);
@@ -216,6 +302,9 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+#ifdef DH_LR_TIMING
+      tw1 = wall_clock64();
+#endif
       // ---- medoid, order, 80 % cut (:576-596) -- as in msaEdlib
       if (lane < N) {
         int med = 0;
@@ -323,6 +412,9 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           uint8_t* sw = sup; sup = sup2; sup2 = sw;
         }
       }
+#ifdef DH_LR_TIMING
+      tw2 = wall_clock64();
+#endif
       // ---- progressive HW alignment of every selected read (:662-686)
       uint8_t* cur = alnA;
       uint8_t* nxt = alnB;
@@ -471,6 +563,12 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       }
     }
   }
+#ifdef DH_LR_TIMING
+  if (lane == 0 && (j & 127) == 0) {
+    const unsigned long long tw4 = wall_clock64();
+    printf("lrwfa junction %d: pairwise %llu us, superstring %llu us, progressive+consensus+trim %llu us\n", j, (tw1 - tw0) / 100, (tw2 - tw1) / 100, (tw4 - tw2) / 100);
+  }
+#endif
   if (lane == 0) {
     out->sr_support = rows;
     out->status = status;
