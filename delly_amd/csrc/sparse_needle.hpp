@@ -82,115 +82,17 @@ __device__ __forceinline__ uint64_t sp_lds8u(const uint8_t* p) {   // (gfx950 re
   return v;
 }
 
-// candidate row of diagonal q at level d from the two previous levels (before the match extension)
-__device__ __forceinline__ int sp_candidate(int d, int q, int k, int m, int n, int ND, int v1, int v1l, int v2, int v2r) {
-  int best = SP_NEG;
-  if (d == 0) {
-    if (k >= 0) best = 0;                                   // row 0, column k
-  } else {
-    best = v1;
-    if (q >= 1 && v1l >= 0 && v1l + k >= 1 && v1l + k <= n) best = max(best, v1l);            // reference-only move (r, c-1) -> (r, c)
-    if (d >= 2) {
-      if (v2 >= 0 && v2 + 1 <= m && v2 + 1 + k <= n && v2 + k >= 0) best = max(best, v2 + 1);  // mismatch (r, c) -> (r+1, c+1)
-      if (q + 1 < ND && v2r >= 0 && v2r + 1 <= m && v2r + 1 + k >= 0) best = max(best, v2r + 1);   // consensus-only move from diagonal k+1
-    }
-    if (k < 0 && 2 * (-k) <= d) best = max(best, -k);       // first column: D[r][0] = 2r
-  }
-  return best;
-}
-
-// match extension from row r on diagonal k, 8 letters per compare
-__device__ __forceinline__ int sp_extend(const uint8_t* a, const uint8_t* b, int m, int n, int r, int k) {
-  const int c = r + k;
-  const int lim = min(m - r, n - c);
-  int adv = 0;
-  while (adv < lim) {
-    const uint64_t z = sp_load8(a + r + adv) ^ sp_load8(b + c + adv);
-    if (z) {
-      adv += (int)(__builtin_ctzll(z) >> 3);
-      break;
-    }
-    adv += 8;
-  }
-  return r + min(adv, lim);
-}
-
-// one deficit level of BOTH matrices (forward: a = consensus, b = window; reverse: their reverse complements), two
-// chunks of 64 diagonals per iteration: four independent load / extend streams per wavefront.  reach[0] / reach[1] =
-// the furthest row reached on any diagonal of the forward / reverse matrix.
-__device__ __noinline__ void sp_level2(const uint8_t* __restrict__ aF, const uint8_t* __restrict__ bF, const uint8_t* __restrict__ aR,
-                                       const uint8_t* __restrict__ bR, int m, int n, int d, int16_t* __restrict__ FRf,
-                                       int16_t* __restrict__ FRr, int ndp, int lane, int (&reach)[2]) {
-  const int ND = n + m + 1;
-  int16_t* __restrict__ curF = FRf + (size_t)d * ndp;
-  int16_t* __restrict__ curR = FRr + (size_t)d * ndp;
-  const int16_t* __restrict__ p1F = FRf + (size_t)max(d - 1, 0) * ndp;
-  const int16_t* __restrict__ p2F = FRf + (size_t)max(d - 2, 0) * ndp;
-  const int16_t* __restrict__ p1R = FRr + (size_t)max(d - 1, 0) * ndp;
-  const int16_t* __restrict__ p2R = FRr + (size_t)max(d - 2, 0) * ndp;
-  int rf = SP_NEG, rr = SP_NEG;
-  for (int q0 = 0; q0 < ND; q0 += 2 * WAVE) {
-    int q[2], k[2], cf[2], cr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      q[u] = q0 + u * WAVE + lane;
-      k[u] = q[u] - m;
-      const bool in = q[u] < ND;
-      // (the level rows are padded to ndp >= ND + 1 entries; q - 1 = -1 is never used: guarded in sp_candidate)
-      const int qq = in ? q[u] : 0;
-      const int v1 = (d >= 1) ? (int)p1F[qq] : SP_NEG, v1l = (d >= 1 && qq >= 1) ? (int)p1F[qq - 1] : SP_NEG;
-      const int v2 = (d >= 2) ? (int)p2F[qq] : SP_NEG, v2r = (d >= 2) ? (int)p2F[qq + 1] : SP_NEG;
-      const int w1 = (d >= 1) ? (int)p1R[qq] : SP_NEG, w1l = (d >= 1 && qq >= 1) ? (int)p1R[qq - 1] : SP_NEG;
-      const int w2 = (d >= 2) ? (int)p2R[qq] : SP_NEG, w2r = (d >= 2) ? (int)p2R[qq + 1] : SP_NEG;
-      cf[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, v1, v1l, v2, v2r) : SP_NEG;
-      cr[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, w1, w1l, w2, w2r) : SP_NEG;
-    }
-    // match extension: the first 8 letters of all four streams in one batch of loads (a random diagonal mismatches
-    // within them: one load latency per iteration instead of four); only the rare long runs enter the loop
-    uint64_t zf[2], zr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int rf0 = max(cf[u], 0), rr0 = max(cr[u], 0);
-      const int kk = (q[u] < ND) ? k[u] : 0;
-      // (addresses stay inside the padded strings: r <= m, c = r + k clamped into [0, n])
-      const int cfc = min(max(rf0 + kk, 0), n), crc = min(max(rr0 + kk, 0), n);
-      zf[u] = sp_load8(aF + rf0) ^ sp_load8(bF + cfc);
-      zr[u] = sp_load8(aR + rr0) ^ sp_load8(bR + crc);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (cf[u] >= 0) {
-        const int lim = min(m - cf[u], n - (cf[u] + k[u]));
-        const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
-        if (adv < 8 || lim <= 8) cf[u] += min(adv, lim);
-        else cf[u] = sp_extend(aF, bF, m, n, cf[u] + 8, k[u]);
-      }
-      if (cr[u] >= 0) {
-        const int lim = min(m - cr[u], n - (cr[u] + k[u]));
-        const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
-        if (adv < 8 || lim <= 8) cr[u] += min(adv, lim);
-        else cr[u] = sp_extend(aR, bR, m, n, cr[u] + 8, k[u]);
-      }
-      if (q[u] < ND) {
-        curF[q[u]] = (int16_t)cf[u];
-        curR[q[u]] = (int16_t)cr[u];
-      }
-      rf = max(rf, cf[u]);
-      rr = max(rr, cr[u]);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    rf = max(rf, __shfl_xor(rf, o));
-    rr = max(rr, __shfl_xor(rr, o));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  reach[0] = rfl(rf);
-  reach[1] = rfl(rr);
-}
-
-// ---- level blocks in LDS -------------------------------------------------------------------------------------------
+// The recurrence of one level (the level loops below carry it out, 64 diagonals per step): diagonal k = q - m at level d
+// starts from
+//   max( FR[d-1][k],                                  level d - 1 reaches at least as far
+//        FR[d-1][k-1]      if that cell's column + 1 <= n,     reference-only move (r, c-1) -> (r, c)
+//        FR[d-2][k] + 1    clamped to the diagonal's last row, mismatch (r, c) -> (r+1, c+1)
+//        FR[d-2][k+1] + 1  if <= m,                            consensus-only move from diagonal k + 1
+//        -k                if k < 0 and 2 |k| <= d,            first column: D[r][0] = 2 r
+//        0                 if d == 0 and k >= 0 )              row 0 is free
+// and runs down the diagonal while the letters match (8 per compare).  Cells of diagonal k have rows >= -k, so the lower
+// column bounds hold for every valid entry; a same-diagonal step past the last row or column can only start from the
+// bound itself, which level d - 1 already holds.
 // A level of diagonal q only needs the two previous levels of q-1 .. q+1, so a TILE of diagonals can be carried through a
 // BLOCK of SP_LB levels entirely in LDS when a halo of SP_LB diagonals on either side is recomputed (the valid region
 // shrinks by one diagonal per level and side: 2 x 16 / 960 = 3 % redundant work).  The table rows then cost LDS latency
@@ -209,171 +111,8 @@ struct __attribute__((aligned(16))) SpTileT {
   static constexpr bool narrow = sizeof(ELEM) == 1;
   ELEM row[2][NROWS][TW + 2 * SP_LB + 64];              // [matrix][level % NROWS][diagonal - base]
   uint8_t str[STRCAP > 0 ? STRCAP : 8];
-  static __device__ __forceinline__ int dec(ELEM e) { return narrow ? (int)e - 1 : (int)e; }
-  static __device__ __forceinline__ ELEM enc(int v) { return narrow ? (ELEM)(max(v, -1) + 1) : (ELEM)v; }
 };
 typedef SpTileT<960, 8192, int16_t, 2> SpTile;       // long reads: 3 % halo overhead, letters staged per tile, two rolling rows
-
-// 8 letters at an arbitrary LDS byte offset: two aligned 8-byte reads + a funnel shift
-__device__ __forceinline__ uint64_t sp_lds8(const uint8_t* p) {
-  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-  const uint64_t* q = reinterpret_cast<const uint64_t*>(u & ~(uintptr_t)7);
-  const uint64_t lo = q[0], hi = q[1];
-  const int sh = (int)(u & 7) * 8;
-  return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-}
-
-// letters of one matrix for the extension: global strings (off = 0) or their staged copies (row letters at la, window
-// columns [c0, ...) at lb)
-struct SpStr {
-  const uint8_t* a;
-  const uint8_t* b;
-  int c0;            // window column of b[0]
-  bool lds;
-};
-template <bool ALWAYS_LDS = false>
-__device__ __forceinline__ uint64_t sp_pair8(const SpStr& s, int r, int c) {
-  if (ALWAYS_LDS) return sp_lds8(s.a + r) ^ sp_lds8(s.b + c);
-  if (s.lds) return sp_lds8(s.a + r) ^ sp_lds8(s.b + (c - s.c0));
-  return sp_load8(s.a + r) ^ sp_load8(s.b + c);
-}
-template <bool ALWAYS_LDS = false>
-__device__ __forceinline__ int sp_extend_s(const SpStr& s, int m, int n, int r, int k) {
-  const int c = r + k;
-  const int lim = min(m - r, n - c);
-  int adv = 0;
-  while (adv < lim) {
-    const uint64_t z = sp_pair8<ALWAYS_LDS>(s, r + adv, c + adv);
-    if (z) {
-      adv += (int)(__builtin_ctzll(z) >> 3);
-      break;
-    }
-    adv += 8;
-  }
-  return r + min(adv, lim);
-}
-
-// levels d0 .. d1 (at most SP_LB of them) of both matrices, tile by tile.  reachF / reachR (LDS) receive the furthest
-// row per level.  Levels d0 - 1 and d0 - 2 are read from the global tables.
-// LDSSTR: the four strings are LDS arrays already (short-read kernel) -- no staging.  resume: the tile still holds levels
-// d0 - 1 and d0 - 2 of ALL diagonals from the previous call (single tile, LDS untouched since): no reload.
-template <typename TILE, bool LDSSTR>
-__device__ __noinline__ void sp_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
-                                            int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T,
-                                            int16_t* reachF, int16_t* reachR, bool resume, int lane) {
-  typedef typename TILE::elem_t elem_t;
-  constexpr bool lds_strings = LDSSTR;
-  constexpr int SP_TW = TILE::tw;
-  constexpr int SP_STR_CAP = TILE::str_cap;
-  const int ND = n + m + 1;
-  const int nl = d1 - d0 + 1;
-  for (int d = d0 + lane; d <= d1; d += WAVE) { reachF[d] = (int16_t)SP_NEG; reachR[d] = (int16_t)SP_NEG; }
-  __syncthreads();
-  const bool stage = !lds_strings && 2 * (2 * m + SP_TW + 2 * SP_LB + 64) <= SP_STR_CAP;
-  for (int tlo = 0; tlo < ND; tlo += SP_TW) {
-    const int thi = min(tlo + SP_TW, ND);
-    const int base = tlo - SP_LB - 1;                      // diagonal of LDS index 0
-    const int len = thi + SP_LB + 1 - base;                // <= SP_TW + 2 SP_LB + 2
-    // previous two levels of the tile + halo
-    for (int i = lane; i < len && !resume; i += WAVE) {
-      const int q = base + i;
-      const bool in = q >= 0 && q < ND;
-      T.row[0][(d0 + 2) % 3][i] = TILE::enc((d0 >= 1 && in) ? sp_ld16(FRf + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
-      T.row[1][(d0 + 2) % 3][i] = TILE::enc((d0 >= 1 && in) ? sp_ld16(FRr + (size_t)(d0 - 1) * ndp + q) : SP_NEG);
-      T.row[0][(d0 + 1) % 3][i] = TILE::enc((d0 >= 2 && in) ? sp_ld16(FRf + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
-      T.row[1][(d0 + 1) % 3][i] = TILE::enc((d0 >= 2 && in) ? sp_ld16(FRr + (size_t)(d0 - 2) * ndp + q) : SP_NEG);
-    }
-    // letters this tile can touch: rows 0 .. m, columns c = r + k, k in [tlo - SP_LB - m, thi + SP_LB - m)
-    SpStr sF{consF, refF, 0, lds_strings}, sR{consR, refR, 0, lds_strings};
-    if (stage) {
-      const int c0 = max(0, tlo - SP_LB - m) & ~7, c1 = min(n, thi + SP_LB);
-      const int wl = max(c1 - c0, 0);
-      const int am = (m + 16 + 7) & ~7, bw = (wl + 16 + 7) & ~7;
-      uint8_t* la0 = T.str;
-      uint8_t* lb0 = la0 + am;
-      uint8_t* la1 = lb0 + bw;
-      uint8_t* lb1 = la1 + am;
-      for (int i = lane; i < am; i += WAVE) { la0[i] = (i < m) ? consF[i] : (uint8_t)1; la1[i] = (i < m) ? consR[i] : (uint8_t)1; }
-      for (int i = lane; i < bw; i += WAVE) { lb0[i] = (i < wl) ? refF[c0 + i] : (uint8_t)2; lb1[i] = (i < wl) ? refR[c0 + i] : (uint8_t)2; }
-      sF = SpStr{la0, lb0, c0, true};
-      sR = SpStr{la1, lb1, c0, true};
-    }
-    __syncthreads();
-    for (int j = 0; j < nl; ++j) {
-      const int d = d0 + j;
-      const int halo = nl - 1 - j;
-      const int qa = max(tlo - halo, 0), qb = min(thi + halo, ND);
-      elem_t* curF = T.row[0][d % 3];
-      elem_t* curR = T.row[1][d % 3];
-      const elem_t* p1F = T.row[0][(d + 2) % 3];
-      const elem_t* p2F = T.row[0][(d + 1) % 3];
-      const elem_t* p1R = T.row[1][(d + 2) % 3];
-      const elem_t* p2R = T.row[1][(d + 1) % 3];
-      int16_t* gF = FRf + (size_t)d * ndp;
-      int16_t* gR = FRr + (size_t)d * ndp;
-      int rf = SP_NEG, rr = SP_NEG;
-      for (int q0 = qa; q0 < qb; q0 += 2 * WAVE) {
-        int q[2], k[2], cf[2], cr[2];
-        uint64_t zf[2], zr[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          q[u] = q0 + u * WAVE + lane;
-          k[u] = q[u] - m;
-          const bool in = q[u] < qb;
-          const int i = (in ? q[u] : qa) - base;
-          const int v1 = (d >= 1) ? TILE::dec(p1F[i]) : SP_NEG, v1l = (d >= 1) ? TILE::dec(p1F[i - 1]) : SP_NEG;
-          const int v2 = (d >= 2) ? TILE::dec(p2F[i]) : SP_NEG, v2r = (d >= 2) ? TILE::dec(p2F[i + 1]) : SP_NEG;
-          const int w1 = (d >= 1) ? TILE::dec(p1R[i]) : SP_NEG, w1l = (d >= 1) ? TILE::dec(p1R[i - 1]) : SP_NEG;
-          const int w2 = (d >= 2) ? TILE::dec(p2R[i]) : SP_NEG, w2r = (d >= 2) ? TILE::dec(p2R[i + 1]) : SP_NEG;
-          cf[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, v1, v1l, v2, v2r) : SP_NEG;
-          cr[u] = in ? sp_candidate(d, q[u], k[u], m, n, ND, w1, w1l, w2, w2r) : SP_NEG;
-          const int rf0 = max(cf[u], 0), rr0 = max(cr[u], 0);
-          const int kk = in ? k[u] : 0;
-          const int cfc = min(max(rf0 + kk, sF.c0), n), crc = min(max(rr0 + kk, sR.c0), n);
-          zf[u] = sp_pair8<LDSSTR>(sF, rf0, cfc);
-          zr[u] = sp_pair8<LDSSTR>(sR, rr0, crc);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (cf[u] >= 0) {
-            const int lim = min(m - cf[u], n - (cf[u] + k[u]));
-            const int adv = zf[u] ? (int)(__builtin_ctzll(zf[u]) >> 3) : 8;
-            if (adv < 8 || lim <= 8) cf[u] += min(adv, lim);
-            else cf[u] = sp_extend_s<LDSSTR>(sF, m, n, cf[u] + 8, k[u]);
-          }
-          if (cr[u] >= 0) {
-            const int lim = min(m - cr[u], n - (cr[u] + k[u]));
-            const int adv = zr[u] ? (int)(__builtin_ctzll(zr[u]) >> 3) : 8;
-            if (adv < 8 || lim <= 8) cr[u] += min(adv, lim);
-            else cr[u] = sp_extend_s<LDSSTR>(sR, m, n, cr[u] + 8, k[u]);
-          }
-          if (q[u] < qb) {
-            curF[q[u] - base] = TILE::enc(cf[u]);
-            curR[q[u] - base] = TILE::enc(cr[u]);
-            if (q[u] >= tlo && q[u] < thi) {
-              gF[q[u]] = (int16_t)cf[u];
-              gR[q[u]] = (int16_t)cr[u];
-              rf = max(rf, cf[u]);
-              rr = max(rr, cr[u]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        rf = max(rf, __shfl_xor(rf, o));
-        rr = max(rr, __shfl_xor(rr, o));
-      }
-      if (lane == 0) {
-        reachF[d] = (int16_t)max((int)reachF[d], rf);
-        reachR[d] = (int16_t)max((int)reachR[d], rr);
-      }
-      __syncthreads();
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
 
 // The level block of the strip (long-read) kernel: tiles of TILE::tw diagonals with a halo of SP_LB, int16 rows, TWO rows
 // per matrix (level d overwrites level d - 2 in place: diagonal q reads entries q and q + 1 of that row, chunks ascend,
