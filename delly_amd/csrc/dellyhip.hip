@@ -132,6 +132,11 @@ struct dellyhip_batch {
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
   bool sps_all = false;              // every junction of the dense bins is in the sparse list too
+  // msa() batches: the sparse kernel runs on every non-insertion junction straight behind the MSA kernels (it reads the
+  // consensus lengths on the device) while the host routes the batch from the downloaded lengths
+  DevBuf<int32_t> early_list;
+  int early_count = 0;
+  bool early_done = false;           // this run: split_sparse_kernel has been launched already
   int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
   int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
@@ -184,6 +189,7 @@ struct dellyhip_batch {
   std::vector<hipEvent_t> ev;        // 4 events per launch since the last kernel_ms()
   hipEvent_t last = nullptr;
   hipEvent_t mid = nullptr;          // recorded between the DP kernels and the post kernel
+  hipEvent_t len_ev = nullptr;       // msa() batches: the consensus lengths have arrived on the host
   double ms_split = 0, ms_msa = 0, ms_dp = 0, ms_dp_last = 0;
   int launches = 0;
   bool pending = false;
@@ -252,12 +258,52 @@ void launch_quad(dh::SplitArgs a, int n_quads, int n_pairs, int max_blocks, int3
   hipLaunchKernelGGL(dh::split_post_kernel<KP>, dim3(balanced(seats)), dim3(dh::WAVE), 0, s, a);
 }
 
+dh::SplitArgs make_split_args(dellyhip_ctx* c, dellyhip_batch* b, bool direct);
+int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct, dh::SplitArgs a, bool mid_done);
+
+// msa() batches: split_sparse_kernel on every non-insertion junction, enqueued straight behind the MSA kernels
+int launch_early_sparse(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s) {
+  int rc;
+  if ((rc = ensure_chr_table(c))) return rc;
+  dh::SplitArgs a = make_split_args(c, b, false);
+  a.work_list = b->early_list.p;
+  a.n_work = b->early_count;
+  a.work_counter = c->counters.p + 30;
+  a.sps_left = c->counters.p + 31;
+  hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->early_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
+  HIPCHK(hipGetLastError());
+  if (b->mid) HIPCHK(hipEventRecord(b->mid, s));
+  b->early_done = true;
+  return 0;
+}
+
 // Launches the split-alignment kernels for every K bin of the batch.
 int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   int rc;
   if (!direct && (rc = ensure_chr_table(c))) return rc;
   if ((rc = ensure_scratch(c))) return rc;
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 32 * sizeof(int32_t), s));
+  const bool early = b->early_done;   // (slots 30 / 31 of the counters belong to the kernel that already ran)
+  b->early_done = false;
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, (early ? 30 : 32) * sizeof(int32_t), s));
+  dh::SplitArgs a = make_split_args(c, b, direct);
+  bool mid_done = false;
+  if (early) {   // every junction of the dense bins was offered to the sparse kernel
+    a.sps_left = c->counters.p + 31;
+    mid_done = true;
+  } else if (b->sps_count > 0 && !direct) {   // sparse longNeedle first: the dense kernels below skip what it finishes
+    a.work_list = b->work.p + b->sps_first;
+    a.n_work = b->sps_count;
+    a.work_counter = c->counters.p + 30;
+    a.sps_left = c->counters.p + 31;
+    hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->sps_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
+    HIPCHK(hipGetLastError());
+    if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to the sparse kernel
+    else if (b->mid) { HIPCHK(hipEventRecord(b->mid, s)); mid_done = true; }   // dp_kernel_ms = the sparse kernel (the dominant one)
+  }
+  return run_split_dense(c, b, s, direct, a, mid_done);
+}
+
+dh::SplitArgs make_split_args(dellyhip_ctx* c, dellyhip_batch* b, bool direct) {
   dh::SplitArgs a{};
   a.junc = b->junc.p;
   a.cons_off = b->cons_off.p;
@@ -282,17 +328,10 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.ref_off = b->ref_off.p;
     a.ref_len = b->ref_len.p;
   }
-  bool mid_done = false;
-  if (b->sps_count > 0 && !direct) {   // sparse longNeedle first: the dense kernels below skip what it finishes
-    a.work_list = b->work.p + b->sps_first;
-    a.n_work = b->sps_count;
-    a.work_counter = c->counters.p + 30;
-    a.sps_left = c->counters.p + 31;
-    hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->sps_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
-    HIPCHK(hipGetLastError());
-    if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to the sparse kernel
-    else if (b->mid) { HIPCHK(hipEventRecord(b->mid, s)); mid_done = true; }   // dp_kernel_ms = the sparse kernel (the dominant one)
-  }
+  return a;
+}
+
+int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct, dh::SplitArgs a, bool mid_done) {
   bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
     int cnt = b->bin_count[K];
@@ -823,8 +862,9 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
+  if (b->len_ev) (void)hipEventDestroy(b->len_ev);
   delete b;
 }
 
@@ -1043,6 +1083,17 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       // case (a node of the standard instance growing beyond its 512 columns)
       b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
       if ((rc = b->msa_big_ws.alloc(std::max<uint64_t>(1, mp.big_ws_stride * (uint64_t)b->msa_big_grid)))) return bail(rc);
+      if (c->sr_sparse && !(c->params.reserved & 1)) {   // (long-read parameters route every junction to the strip kernel)
+        std::vector<int32_t> el;
+        for (int i = 0; i < n; ++i)
+          if (junc[i].svt != 4) el.push_back(i);
+        b->early_count = (int)el.size();
+        if (b->early_count) {
+          if ((rc = b->early_list.alloc(el.size()))) return bail(rc);
+          e = hipMemcpy(b->early_list.p, el.data(), el.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+          if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D early list", e));
+        }
+      }
     }
   }
   *out = b;
@@ -1064,6 +1115,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   if (b->n == 0) return 0;
   int rc;
   hipEvent_t e3[4];
+  bool ev1_done = false;
   for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreate(&e3[q]));
   for (int q = 0; q < 4; ++q) b->ev.push_back(e3[q]);
   b->mid = e3[3];
@@ -1173,10 +1225,21 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     HIPCHK(hipGetLastError());
     // consensus lengths decide the K bin of the split kernel
     HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (b->early_count > 0) {
+      // the sparse kernel needs no routing (it reads the lengths on the device and leaves what it cannot take to the
+      // dense kernels): it runs while the host bins the batch from the downloaded lengths
+      if (!b->len_ev) HIPCHK(hipEventCreateWithFlags(&b->len_ev, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(b->len_ev, s));
+      HIPCHK(hipEventRecord(e3[1], s));
+      ev1_done = true;
+      if ((rc = launch_early_sparse(c, b, s))) return rc;
+      HIPCHK(hipEventSynchronize(b->len_ev));
+    } else {
+      HIPCHK(hipStreamSynchronize(s));
+    }
     if ((rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
   }
-  HIPCHK(hipEventRecord(e3[1], s));
+  if (!ev1_done) HIPCHK(hipEventRecord(e3[1], s));
   if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
   if (b->with_msa == 2 && b->small_inv_n > 0) {
     hipLaunchKernelGGL(small_inv_fix_kernel, dim3((b->small_inv_n + 63) / 64), dim3(64), 0, s, b->res.p, b->small_inv.p, b->small_inv_n);
