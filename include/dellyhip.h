@@ -73,6 +73,7 @@ typedef struct dellyhip_junction {
 
 /* What alignConsensus() writes into the StructuralVariantRecord
  * (src/split.h:626-637) plus msa()'s return value and consensus. */
+#define DELLYHIP_SCORE_UNKNOWN (-(1 << 30))
 typedef struct dellyhip_result {
   int32_t svid;
   int32_t ok;          /* 1: alignConsensus() returned true; 0: false          */
@@ -91,7 +92,8 @@ typedef struct dellyhip_result {
   /* longNeedle internals (parity diagnostics; src/needle.h:104-123).  For svt 4
    * (splitAlign, src/split.h:480-538) the five slots carry csStart, csEnd,
    * bestJoin, leftEnd, rightStart instead; -1 = not reached. */
-  int32_t score_unsplit;  /* mat[m][n]            */
+  int32_t score_unsplit;  /* mat[m][n]; DELLYHIP_SCORE_UNKNOWN when the sparse longNeedle proved the split score larger
+                           * without computing it (the reference only compares the two, src/needle.h:152)          */
   int32_t score_best;     /* bestScore            */
   int32_t cons_left, ref_left, ref_right;
   int32_t cons_len;       /* |consensus| used for the split alignment          */
