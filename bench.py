@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # tests/test_gpu_bench_shapes.py bit-compares the HIP path with oracle/_ref on exactly these batches.
 SIDE_PLAN = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
              ("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
+             ("u_full_n20_10k_junctions", 10000, 0, dict(mode="c2", n_reads=20)),   # the chip filled: one wavefront per junction needs > 4 096 of them
              ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
              ("ins_svt4", 5000, 5000, dict(mode="ins")),
              ("lr_c4_align_consensus", 2048, 128, dict(mode="lr", sub_rate=0.01)),

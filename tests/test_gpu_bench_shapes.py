@@ -20,7 +20,7 @@ import bench  # noqa: E402  (SIDE_PLAN only; main() is not run)
 
 THREADS = os.cpu_count() or 1
 # junctions compared per workload (None = the whole benched batch)
-COMPARE_N = {"u_full_n20": None, "u_full_n5": None, "ins_svt4": None, "lr_c4_align_consensus": 256,
+COMPARE_N = {"u_full_n20": None, "u_full_n20_10k_junctions": 1000, "u_full_n5": None, "ins_svt4": None, "lr_c4_align_consensus": 256,
              "lr_c4_msaedlib_n15": 64, "lr_ins_msawfa_n15": 64}
 
 
