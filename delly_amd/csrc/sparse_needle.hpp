@@ -519,6 +519,7 @@ __device__ __noinline__ int sp_deep_list(const int16_t* FR, int ndp, int m, int 
 }
 
 // sp_deep_list on the byte row of level S the short-read tile still holds (row + 1, 0 = none; lv = row + SP_LB + 1)
+template <bool WAIT = true>
 __device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo, int32_t* list, int cap, int lane) {
   int cnt = 0;
   for (int q0 = 0; q0 < ND; q0 += WAVE) {
@@ -532,8 +533,10 @@ __device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo,
       cnt += __popcll(bm);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if (WAIT) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   return (cnt <= cap) ? cnt : -1;
 }
 
@@ -572,6 +575,47 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
     }
   }
   for (int d = 2; d <= S; ++d) sp_offer_negative(FR + (size_t)d * ndp, cT + (size_t)d * (m + 1), m, d, rlo, rhi, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// Both first-column tables of the short-read kernel in one go when each deep list fits one chunk (the usual case): the
+// stores that clear the tables and write the lists are waited for ONCE, the list entries and the table values of four
+// levels of BOTH matrices are in flight together -- two memory round trips instead of six.
+__device__ __noinline__ void sp_first_columns_both(const int16_t* FRf, const int16_t* FRr, int ndp, int m, int S, int rloF, int rhiF,
+                                                   const int32_t* listF, int cntF, int32_t* cF, int rloR, int rhiR,
+                                                   const int32_t* listR, int cntR, int32_t* cR, int lane) {
+  const int rows = rhiF - rloF + 1;   // (= rhiR - rloR + 1)
+  for (int d = 0; d <= S; ++d)
+    for (int i = lane; i < rows; i += WAVE) {
+      cF[(size_t)d * (m + 1) + rloF + i] = SP_INF;
+      cR[(size_t)d * (m + 1) + rloR + i] = SP_INF;
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int qF = (lane < cntF) ? sp_ld32(listF + lane) : -1;
+  const int qR = (lane < cntR) ? sp_ld32(listR + lane) : -1;
+  const bool useF = qF >= m, useR = qR >= m;   // (diagonals below the main one: sp_offer_negative)
+  for (int d0 = 0; d0 <= S; d0 += 4) {
+    int vF[4], vR[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      vF[u] = (useF && d0 + u <= S) ? sp_ld16(FRf + (size_t)(d0 + u) * ndp + qF) : SP_NEG;
+      vR[u] = (useR && d0 + u <= S) ? sp_ld16(FRr + (size_t)(d0 + u) * ndp + qR) : SP_NEG;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (d0 + u <= S) {
+        int pmF = rloF - 1, pmR = rloR - 1;
+        sp_offer_chunk(cF + (size_t)(d0 + u) * (m + 1), rloF, rhiF, qF - m, vF[u], pmF, lane);
+        sp_offer_chunk(cR + (size_t)(d0 + u) * (m + 1), rloR, rhiR, qR - m, vR[u], pmR, lane);
+      }
+    }
+  }
+  for (int d = 2; d <= S; ++d) {
+    sp_offer_negative(FRf + (size_t)d * ndp, cF + (size_t)d * (m + 1), m, d, rloF, rhiF, lane);
+    sp_offer_negative(FRr + (size_t)d * ndp, cR + (size_t)d * (m + 1), m, d, rloR, rhiR, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
@@ -674,17 +718,27 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
     }
     if (rlo <= rhi && feasible) {
       int nlistF;
+      bool tables_done = false;
       if constexpr (LDSSTR && TILE::narrow) {
-        nlistF = sps_deep_list(T.row[0][S & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
-        nlistR = sps_deep_list(T.row[1][S & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+        nlistF = sps_deep_list<false>(T.row[0][S & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sps_deep_list<false>(T.row[1][S & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+        if (nlistF >= 0 && nlistF <= WAVE && nlistR >= 0 && nlistR <= WAVE) {   // (its first wait covers the list stores too)
+          sp_first_columns_both(W.frF, W.frR, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+          tables_done = true;
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
       } else {
         nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
         nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
       }
-      if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, lane);
-      else sp_first_columns(W.frF, W.ndp, m, n, S, rlo, rhi, W.cF, lane);
-      if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, S, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
-      else sp_first_columns(W.frR, W.ndp, m, n, S, m - rhi, m - rlo, W.cR, lane);
+      if (!tables_done) {
+        if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, lane);
+        else sp_first_columns(W.frF, W.ndp, m, n, S, rlo, rhi, W.cF, lane);
+        if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, S, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+        else sp_first_columns(W.frR, W.ndp, m, n, S, m - rhi, m - rlo, W.cR, lane);
+      }
 #ifdef DH_LR_TIMING
       O.t[1] = wall_clock64();
 #endif

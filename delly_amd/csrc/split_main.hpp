@@ -487,12 +487,19 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
 // masks (split.h:166-375, 596-637); writes the result record.
 template <typename STRS, typename PL>
 // pre_ma / pre_mm >= 0: the match / mismatch column counts are known (L.mE is not read).
+// clean_letters: consensus and window hold A, C, G, T, N only -- every alignment column then shows the letters of
+// S.cons / S.ref in their order (the output switch of needle.h:209-217 undoes the reverse complement), so the two
+// alleles are plain substrings and are copied eight letters at a time instead of column by column.
 __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PL& L, bool go, int Ltot,
-                                             int posC, int lane, int pre_ma = -1, int pre_mm = -1) {
+                                             int posC, int lane, int pre_ma = -1, int pre_mm = -1, bool clean_letters = false) {
   const dellyhip_params& P = A.p;
   const int m = X.m, n = X.n;
   uint8_t* ob = X.ob;
   // _findSplit (split.h:319-375) on the masks (uniform code)
+#ifdef DH_SPS_FINE
+  unsigned long long td[6];
+  td[0] = td[1] = td[2] = td[3] = td[4] = td[5] = wall_clock64();
+#endif
   if (go) {
     const int svt = X.svt;
     int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
@@ -528,6 +535,9 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
       }
       pos = b1 + 1;
     }
+#ifdef DH_SPS_FINE
+    td[1] = wall_clock64();
+#endif
     bool ok = rEnd > rStart;
     if (ok) {
       if (svt == 4) ok = ((rEnd - rStart) < 5) && ((cEnd - cStart) > 15);
@@ -551,6 +561,9 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
       percId = (float)(uint32_t)ma / (float)(uint32_t)(ma + mm);
       if (percId < P.flank_quality) ok = false;
     }
+#ifdef DH_SPS_FINE
+    td[2] = wall_clock64();
+#endif
     int homLeft = 0, homRight = 0;
     if (ok) {
       // _findHomology split.h:262-280
@@ -565,6 +578,9 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
       if ((homLeft + P.minimum_flank_size > cStart) || (varIndex < cEnd + homRight + P.minimum_flank_size)) ok = false;
       if ((homLeft + P.minimum_flank_size > rStart) || (refIndex < rEnd + homRight + P.minimum_flank_size)) ok = false;
     }
+#ifdef DH_SPS_FINE
+    td[3] = wall_clock64();
+#endif
     if (ok) {
       // _coordTransform split.h:166-244
       uint32_t gs = 0, ge = 0;
@@ -602,6 +618,9 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
         gs = (uint32_t)(sBeg + rStart);
         ge = (uint32_t)(sBeg + rEnd);
       }
+#ifdef DH_SPS_FINE
+      td[4] = wall_clock64();
+#endif
       int allele_len = 0, status = 0;
       const bool final_ok = ct_ok && (is_tra(svt) || gs < ge);
       if (final_ok) {
@@ -614,7 +633,16 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
           int nr = rB - rA, na = vB - vA;
           uint8_t* al = ob + A.out_cons_cap;
-          if (nr + na + 1 <= A.out_allele_cap) {
+          if (nr + na + 1 <= A.out_allele_cap && clean_letters) {
+            // REF = S.ref[rA .. rB), ALT = S.cons[vA .. vB)
+            const int fr = nr & ~7, fa = na & ~7;
+            for (int i = lane * 8; i < fr; i += WAVE * 8) st8u(al + i, ld8u(S.ref + rA + i));
+            if (lane < nr - fr) al[fr + lane] = S.ref[rA + fr + lane];
+            for (int i = lane * 8; i < fa; i += WAVE * 8) st8u(al + nr + 1 + i, ld8u(S.cons + vA + i));
+            if (lane < na - fa) al[nr + 1 + fa + lane] = S.cons[vA + fa + lane];
+            if (lane == 0) al[nr] = ',';
+            allele_len = nr + na + 1;
+          } else if (nr + na + 1 <= A.out_allele_cap) {
             for (int base = colA & ~63; base < colB; base += 64) {
               int jcol = base + lane;
               int w = base >> 6;
@@ -655,6 +683,14 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           R->hom_len = max(0, homLeft + homRight - 2);
           R->ci_wiggle = max(homLeft, homRight);
         }
+#ifdef DH_SPS_FINE
+        td[5] = wall_clock64();
+        R->score_unsplit = (int)((td[1] - td[0]) / 10);   // findSplit
+        R->score_best = (int)((td[2] - td[1]) / 10);      // percent identity
+        R->cons_left = (int)((td[3] - td[2]) / 10);       // homology
+        R->ref_left = (int)((td[4] - td[3]) / 10);        // coordinates
+        R->ref_right = (int)((td[5] - td[4]) / 10);       // alleles + record
+#endif
       }
     }
   }

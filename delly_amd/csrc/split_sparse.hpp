@@ -124,7 +124,7 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
 #ifdef DH_LR_TIMING
   const unsigned long long tq3 = wall_clock64();
 #endif
-  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm);
+  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm, true);
 #ifdef DH_LR_TIMING
   if (lane == 0) {   // debug build: phase times in microseconds overwrite diagnostic slots of the record
     const unsigned long long tq4 = wall_clock64();
@@ -134,6 +134,15 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
     X.out->r_end = (int)((tq2 - sr.t[0]) / 100);                 // last evaluation + traces
     X.out->hom_left = (int)((tq4 - tq2) / 100);                  // masks + split detection
     X.out->hom_right = sr.levels;
+#ifdef DH_SPS_FINE
+    if (sr.found) {   // finer: lists + first columns | join + refRight | traces | masks | detect, 100 ns units in five slots
+      X.out->r_start = (int)((sr.t[1] - sr.t[0]) / 10);
+      X.out->r_end = (int)((sr.t[3] - sr.t[1]) / 10);
+      X.out->hom_left = (int)((sr.t[4] - sr.t[3]) / 10);
+      X.out->matches = (int)((tq3 - tq2) / 10);
+      X.out->mismatches = (int)((tq4 - tq3) / 10);
+    }
+#endif
   }
 #endif
   if (lane == 0) X.out->reserved = SPS_DONE;

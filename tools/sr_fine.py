@@ -1,0 +1,19 @@
+import sys
+sys.path.insert(0,'/root/repo')
+import numpy as np
+from delly_amd import refine, synth
+b = synth.make_batch(10000, mode="c2")
+ctx = refine.Context()
+ctx.set_chromosomes(b.chroms)
+rb = ctx.upload(b)
+rb.run(); rb.sync()
+r, _ = rb.fetch()
+ok = (r["ok"] == 1)
+for S in (0, 2, 4):
+    s = ok & (r["hom_right"] == S)
+    print("S", S, "n", s.sum(), "us: lists+firstcols %.1f join+refRight %.1f traces %.1f masks %.1f detect %.1f" % tuple(r[f][s].mean() / 10 for f in ("r_start", "r_end", "hom_left", "matches", "mismatches")))
+
+for S in (0, 2):
+    s = ok & (r["hom_right"] == S)
+    print("S", S, "detect us: findSplit %.1f percentId %.1f homology %.1f coords %.1f alleles+record %.1f" % tuple(r[f][s].mean() / 10 for f in ("score_unsplit", "score_best", "cons_left", "ref_left", "ref_right")))
+print("allele_len mean", r["allele_len"][ok].mean(), "hom", r["hom_left"][ok].mean())
