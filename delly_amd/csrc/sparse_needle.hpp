@@ -437,6 +437,7 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
 // row 0, so diagonal k answers exactly the rows above everything the earlier ones reached: a running maximum (pm, uniform)
 // plus a prefix maximum over the 64 lanes of a chunk gives every lane its own, disjoint row range.
 __device__ __forceinline__ void sp_offer_chunk(int32_t* row, int rlo, int rhi, int k, int v, int& pm, int lane) {
+  if (__ballot(v > pm && v >= rlo) == 0ull) return;   // (no diagonal of the chunk reaches beyond the rows already answered: the usual case)
   int incl = v;
 #pragma unroll
   for (int o = 1; o < WAVE; o <<= 1) {
@@ -481,15 +482,23 @@ __device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m,
     for (int i = lane; i < rows; i += WAVE) cT[(size_t)d * (m + 1) + rlo + i] = SP_INF;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int d = 0; d <= S; ++d) {
-    const int16_t* lv = FR + (size_t)d * ndp;
-    int32_t* row = cT + (size_t)d * (m + 1);
-    sp_offer_negative(lv, row, m, d, rlo, rhi, lane);
-    int pm = rlo - 1;
-    for (int q0 = m; q0 < ND && pm < rhi; q0 += WAVE) {
+  // four levels at a time: their table loads are in flight together (a wide row range -- a consensus that aligns without a
+  // split -- makes this the longest phase of a junction, and one L2 round trip per chunk and level was most of it)
+  for (int d0 = 0; d0 <= S; d0 += 4) {
+    int pm[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      pm[u] = (d0 + u <= S) ? rlo - 1 : rhi;
+      if (d0 + u <= S) sp_offer_negative(FR + (size_t)(d0 + u) * ndp, cT + (size_t)(d0 + u) * (m + 1), m, d0 + u, rlo, rhi, lane);
+    }
+    for (int q0 = m; q0 < ND && (pm[0] < rhi || pm[1] < rhi || pm[2] < rhi || pm[3] < rhi); q0 += WAVE) {
       const int q = q0 + lane;
-      const int v = (q < ND) ? sp_ld16(lv + q) : SP_NEG;
-      sp_offer_chunk(row, rlo, rhi, q - m, v, pm, lane);
+      int v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (q < ND && pm[u] < rhi) ? sp_ld16(FR + (size_t)min(d0 + u, S) * ndp + q) : SP_NEG;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (pm[u] < rhi) sp_offer_chunk(cT + (size_t)(d0 + u) * (m + 1), rlo, rhi, q - m, v[u], pm[u], lane);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -704,40 +713,49 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       const unsigned long long hit = __ballot(d <= S && reachF[d] >= m);
       if (hit) du = d0 + __builtin_ctzll(hit);
     }
+    // With a complete unsplit alignment of deficit du only a split of total deficit < du changes the result (needle.h:152),
+    // so the tables are built for the levels 0 .. du - 1 only -- none at all for du = 0, and for a consensus that aligns
+    // without a split (the false-positive candidate) usually no level pair is feasible: the cheapest junctions there are.
+    const int SE = (du >= 0) ? min(S, du - 1) : S;
     // rows where both sides have cells: forward reaches row r, reverse reaches row m - r
-    const int rhi = min(m, (int)reachF[S]), rlo = max(0, m - (int)reachR[S]);
+    const int rhi = (SE >= 0) ? min(m, (int)reachF[max(SE, 0)]) : -1, rlo = (SE >= 0) ? max(0, m - (int)reachR[max(SE, 0)]) : 0;
     long long key = 0x7fffffffffffffffll;      // (total deficit << 40) | (row << 20) | column
     int dsel = 0;
     int nlistR = -1;
-    // A split of total deficit <= S needs levels d + e <= S whose furthest rows meet (reach is non-decreasing in the
+    // A split of total deficit <= SE needs levels d + e <= SE whose furthest rows meet (reach is non-decreasing in the
     // level): without one the tables cannot resolve the junction and are not built.
     bool feasible = false;
-    for (int d0 = 0; d0 <= S && !feasible; d0 += WAVE) {
+    for (int d0 = 0; SE >= 0 && d0 <= SE && !feasible; d0 += WAVE) {
       const int d = d0 + lane;
-      feasible = __ballot(d <= S && reachF[min(d, S)] >= 0 && (int)reachR[S - min(d, S)] >= m - (int)reachF[min(d, S)]) != 0ull;
+      feasible = __ballot(d <= SE && reachF[min(d, SE)] >= 0 && (int)reachR[SE - min(d, SE)] >= m - (int)reachF[min(d, SE)]) != 0ull;
     }
     if (rlo <= rhi && feasible) {
       int nlistF;
       bool tables_done = false;
       if constexpr (LDSSTR && TILE::narrow) {
-        nlistF = sps_deep_list<false>(T.row[0][S & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
-        nlistR = sps_deep_list<false>(T.row[1][S & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+        if (SE >= S - 1) {   // (the tile holds levels S and S - 1)
+          nlistF = sps_deep_list<false>(T.row[0][SE & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
+          nlistR = sps_deep_list<false>(T.row[1][SE & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+        } else {
+          nlistF = sp_deep_list(W.frF, W.ndp, m, n, SE, rlo, W.listF, W.runs_cap, lane);
+          nlistR = sp_deep_list(W.frR, W.ndp, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
+        }
         if (nlistF >= 0 && nlistF <= WAVE && nlistR >= 0 && nlistR <= WAVE) {   // (its first wait covers the list stores too)
-          sp_first_columns_both(W.frF, W.frR, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+          sp_first_columns_both(W.frF, W.frR, W.ndp, m, SE, rlo, rhi, W.listF, nlistF, W.cF, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
           tables_done = true;
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         }
       } else {
-        nlistF = sp_deep_list(W.frF, W.ndp, m, n, S, rlo, W.listF, W.runs_cap, lane);
-        nlistR = sp_deep_list(W.frR, W.ndp, m, n, S, m - rhi, W.listR, W.runs_cap, lane);
+        nlistF = sp_deep_list(W.frF, W.ndp, m, n, SE, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sp_deep_list(W.frR, W.ndp, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
       }
       if (!tables_done) {
-        if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, S, rlo, rhi, W.listF, nlistF, W.cF, lane);
-        else sp_first_columns(W.frF, W.ndp, m, n, S, rlo, rhi, W.cF, lane);
-        if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, S, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
-        else sp_first_columns(W.frR, W.ndp, m, n, S, m - rhi, m - rlo, W.cR, lane);
+        if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, SE, rlo, rhi, W.listF, nlistF, W.cF, lane);
+        else sp_first_columns(W.frF, W.ndp, m, n, SE, rlo, rhi, W.cF, lane);
+        if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, SE, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+        else sp_first_columns(W.frR, W.ndp, m, n, SE, m - rhi, m - rlo, W.cR, lane);
       }
 #ifdef DH_LR_TIMING
       O.t[1] = wall_clock64();
@@ -746,13 +764,37 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       for (int r0 = rlo; r0 <= rhi; r0 += WAVE) {
         const int r = r0 + lane;
         if (r <= rhi) {
-          // two pointers: minimal e for every d (first columns shrink with d, last allowed columns grow with e)
-          int e = S + 1;
           long long kb = 0x7fffffffffffffffll;
           int db = 0;
           const int32_t* cf = W.cF + r;
           const int32_t* cr = W.cR + (m - r);
-          for (int d = 0; d <= S; ++d) {
+          if (SE <= 8) {
+            // all table entries of this row in flight at once, then registers only: the minimal e for a given d is the
+            // number of levels whose first column is still too far right (first columns shrink with the level).  A wide
+            // row range (a consensus that aligns without a split) made the dependent loads below the longest phase.
+            int lo_[9], c2_[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+              lo_[q] = (q <= SE) ? sp_ld32(cf + (size_t)q * (m + 1)) : SP_INF;
+              c2_[q] = (q <= SE) ? sp_ld32(cr + (size_t)q * (m + 1)) : SP_INF;
+            }
+#pragma unroll
+            for (int d = 0; d < 9; ++d) {
+              const int lo = lo_[d];
+              if (d <= SE && lo <= n) {
+                int e = 0;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) e += (q <= SE && (c2_[q] > n || lo > n - c2_[q])) ? 1 : 0;
+                if (e <= SE && d + e <= SE) {
+                  const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
+                  if (kk <= kb) { kb = kk; db = d; }
+                }
+              }
+            }
+          } else {
+          // two pointers: minimal e for every d (first columns shrink with d, last allowed columns grow with e)
+          int e = SE + 1;
+          for (int d = 0; d <= SE; ++d) {
             const int lo = sp_ld32(cf + (size_t)d * (m + 1));
             if (lo > n) continue;
             while (e >= 1) {
@@ -760,10 +802,11 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
               if (c2 <= n && lo <= n - c2) --e;
               else break;
             }
-            if (e <= S && d + e <= S) {
+            if (e <= SE && d + e <= SE) {
               const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
               if (kk <= kb) { kb = kk; db = d; }   // ties in d + e: the larger d has the smaller (or equal) column
             }
+          }
           }
           if (kb < key) { key = kb; dbest = db; }
         }
@@ -843,7 +886,9 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       const long long pred = (2ll * S * m) / covered;
       if (pred > W.pred_cap) return O;
     }
-    S = min(W.smax, (S < 8) ? S + 2 : (S < 32) ? S * 2 : S + SP_LB);   // (even totals dominate: a substitution costs 2)
+    // (even totals dominate: a substitution costs 2.  The short-read kernel goes on in steps of 2 up to 16 -- its slowest
+    //  junction is the latency floor of a launch, see tools/n_sweep.py -- the strip kernel in whole level blocks.)
+    S = min(W.smax, (S < (LDSSTR ? 16 : 8)) ? S + 2 : (S < 32) ? S * 2 : S + SP_LB);
   }
 }
 

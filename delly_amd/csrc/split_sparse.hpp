@@ -135,6 +135,10 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
     X.out->hom_left = (int)((tq4 - tq2) / 100);                  // masks + split detection
     X.out->hom_right = sr.levels;
 #ifdef DH_SPS_FINE
+    if (!sr.found) {
+      X.out->r_start = (int)((sr.t[1] - sr.t[0]) / 10);
+      X.out->r_end = (int)((sr.t[2] - sr.t[1]) / 10);
+    }
     if (sr.found) {   // finer: lists + first columns | join + refRight | traces | masks | detect, 100 ns units in five slots
       X.out->r_start = (int)((sr.t[1] - sr.t[0]) / 10);
       X.out->r_end = (int)((sr.t[3] - sr.t[1]) / 10);

@@ -17,3 +17,7 @@ for S in (0, 2):
     s = ok & (r["hom_right"] == S)
     print("S", S, "detect us: findSplit %.1f percentId %.1f homology %.1f coords %.1f alleles+record %.1f" % tuple(r[f][s].mean() / 10 for f in ("score_unsplit", "score_best", "cons_left", "ref_left", "ref_right")))
 print("allele_len mean", r["allele_len"][ok].mean(), "hom", r["hom_left"][ok].mean())
+
+kinds = np.array([t["kind"] for t in b.truth])
+nr = kinds == "noref"
+print("noref n", nr.sum(), "S", np.bincount(r["hom_right"][nr]), "us: lists+firstcols %.1f join %.1f" % (r["r_start"][nr].mean() / 10, r["r_end"][nr].mean() / 10), "max", r["r_start"][nr].max() / 10, r["r_end"][nr].max() / 10)

@@ -2,7 +2,8 @@ import sys
 sys.path.insert(0,'/root/repo')
 import numpy as np
 from delly_amd import refine, synth
-b = synth.make_batch(10000, mode="c2")
+import os
+b = synth.make_batch(int(os.environ.get("N", "10000")), mode="c2")
 ctx = refine.Context()
 ctx.set_chromosomes(b.chroms)
 rb = ctx.upload(b)
