@@ -55,6 +55,19 @@ def _mutate(rng, seq, rate):
     return seq
 
 
+def _indel(rng, seq, p):
+    """with probability p one insertion or deletion of 1..3 letters (a copy of the neighbouring letters half of the
+    time: inside a repeat that is a slipped unit)"""
+    if seq.size < 30 or rng.random() >= p:
+        return seq
+    at = int(rng.integers(10, seq.size - 10))
+    k = int(rng.integers(1, 4))
+    if rng.integers(0, 2):
+        return np.delete(seq, slice(at, at + k))
+    ins = seq[at:at + k].copy() if rng.integers(0, 2) else ACGT[rng.integers(0, 4, k)]
+    return np.insert(seq, at, ins)
+
+
 class Batch:
     """Host-side junction batch in the layout of include/dellyhip.h."""
 
@@ -99,8 +112,92 @@ def subset(batch, idx):
     return Batch(batch.chroms, junc, blob, np.asarray(off, dtype=np.uint64), batch.with_msa, truth)
 
 
+def _str(unit, n):
+    u = np.frombuffer(unit, dtype=np.uint8)
+    return np.tile(u, n // u.size + 2)[:n]
+
+
+LOWCX_KINDS = 12
+
+
+def plant_low_complexity(rng, G, s, e, sel, real=None):
+    """Non-random sequence content around the breakpoints s (left) and e (right) of one private genome window -- the
+    inputs on which the reference's tie-break rules decide the result (src/needle.h:107-123 join / refRight,
+    :160-191 traceback order, src/gotoh.h:135-138, src/edlib.cpp:1021-1086, src/msa.h:46-89): homopolymers,
+    short tandem repeats at and across the breakpoints, tandem duplications, a second copy of a flank inside the
+    window, two-letter sequence, windows of a real chromosome (`real`, e.g. the reference's example/ref.fa).
+    `rng` is a stream of its own, so the default batches do not change.  -> (G, kind name)"""
+    W = G.size
+    sel %= LOWCX_KINDS
+    if real is not None and sel in (7, 8):
+        o = int(rng.integers(0, real.size - W))
+        G = real[o:o + W].copy()
+    span = max(20, min(200, (e - s) // 2 if e - s > 60 else 200))
+    if sel == 0:        # homopolymer across the left breakpoint
+        L = int(rng.integers(20, span + 1)); a = int(rng.integers(0, L + 1))
+        G[s - a:s - a + L] = ACGT[rng.integers(0, 4)]
+        kind = "homopolymer"
+    elif sel == 1:      # (CA)n across the left breakpoint
+        L = int(rng.integers(20, span + 1)); a = int(rng.integers(0, L + 1))
+        G[s - a:s - a + L] = _str(b"CA", L)
+        kind = "str2"
+    elif sel == 2:      # (CAG)n across the right breakpoint
+        L = int(rng.integers(20, span + 1)); a = int(rng.integers(0, L + 1))
+        G[e - a:e - a + L] = _str(b"CAG", L)
+        kind = "str3"
+    elif sel == 3:      # the same repeat at both breakpoints: long micro-homology, many co-optimal joins
+        L = int(rng.integers(20, span + 1)); a = int(rng.integers(0, L + 1))
+        unit = [b"CA", b"CAG", b"A", b"GATA"][int(rng.integers(0, 4))]
+        ph = int(rng.integers(0, len(unit)))
+        G[s - a:s - a + L] = _str(unit, L + ph)[ph:]
+        G[e - a:e - a + L] = _str(unit, L)
+        kind = "str_both"
+    elif sel == 4:      # tandem duplication ending at the left breakpoint, unit 5 .. 100, 2 .. 4 copies
+        u = int(rng.integers(5, 101)); c = int(rng.integers(2, 5))
+        c = max(2, min(c, 300 // u))
+        unit = G[s - u:s].copy()
+        G[s - u * c:s] = np.tile(unit, c)
+        if rng.integers(0, 2):
+            G[e:e + u] = unit      # ... and once more behind the right breakpoint
+        kind = "tandem"
+    elif sel == 5:      # a second copy of the left flank behind the right breakpoint (and of the right flank before the left)
+        L = int(rng.integers(100, 301))
+        G[e + 20:e + 20 + L] = G[s - L:s]
+        if rng.integers(0, 2):
+            G[s - 40 - L:s - 40] = G[e:e + L]
+        kind = "repeat"
+    elif sel == 6:      # two-letter sequence
+        lo, hi = max(0, s - 400), min(W, e + 400)
+        G[lo:hi] = np.frombuffer(b"AT", dtype=np.uint8)[rng.integers(0, 2, hi - lo)]
+        kind = "two_letter"
+    elif sel == 7:
+        kind = "real" if real is not None else "random"
+    elif sel == 8:      # real sequence with a homopolymer at the left breakpoint
+        L = int(rng.integers(10, 60))
+        G[s - L // 2:s - L // 2 + L] = ord("T")
+        kind = "real_homopolymer" if real is not None else "homopolymer"
+    elif sel == 9:      # a deletion between two poly-A runs: the breakpoint can slide by the whole run
+        L = int(rng.integers(10, 80)); R = int(rng.integers(10, 80))
+        G[s - L:s + int(rng.integers(0, 20))] = ord("A")
+        G[e - int(rng.integers(0, 20)):e + R] = ord("A")
+        kind = "polya_both"
+    elif sel == 10:     # repeats on the deleted side of both breakpoints
+        L = int(rng.integers(20, span + 1))
+        G[s:s + L] = _str(b"CA", L)
+        G[e - L:e] = _str(b"CA", L)
+        G[s - 10:s] = _str(b"CA", 10)
+        kind = "str_inside"
+    else:               # the whole neighbourhood is one periodic sequence (unit 2 .. 9) with a few point changes
+        lo, hi = max(0, s - 450), min(W, e + 450)
+        unit = ACGT[rng.integers(0, 4, int(rng.integers(2, 10)))]
+        G[lo:hi] = np.tile(unit, (hi - lo) // unit.size + 1)[:hi - lo]
+        G[rng.integers(lo, hi, max(4, (hi - lo) // 60))] = ACGT[rng.integers(0, 4, max(4, (hi - lo) // 60))]
+        kind = "periodic"
+    return G, kind
+
+
 def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_flank=75,
-               sub_rate=0.005, del_len=700):
+               sub_rate=0.005, del_len=700, genome=None, real=None, read_indel=0.0, dup_reads=False, junction_ins=0):
     """Builds junctions first..first+n-1.
 
     mode "c2"   : BASELINE config 2 -- DEL, 150 bp consensus (or reads), ref
@@ -123,6 +220,13 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   reference stretches, pure-reference negatives.
     n_reads 0   : unit U (one consensus per junction); >0: unit U_full (that
                   many distinct split reads per junction, host order = as generated).
+    genome      : None = uniform random letters; "lowcx" = plant_low_complexity() around the breakpoints of every junction
+                  (kind = junction index mod LOWCX_KINDS; `real` = a real chromosome to cut windows from); "real" = every
+                  window is cut from `real`.
+    read_indel  : probability that a read / consensus gets one 1..3 bp indel (inside a repeat these are the co-optimal cases)
+    dup_reads   : short reads only: every third read is repeated verbatim (the ABI takes what the host hands over; equal
+                  distances everywhere are UPGMA's tie case, src/msa.h:46-89)
+    junction_ins: that many non-templated bases between the two flanks of the ALT haplotype
     """
     two_chr = mode == "mixed"
     lr_like = mode in ("lr", "lrins")
@@ -204,6 +308,16 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                 kind = "hom"
         e = s + ell
         ins_seq = None
+        if genome is not None:
+            rng2 = _rng(seed ^ 0x10c0, j)
+            if genome == "real":
+                o = int(rng2.integers(0, real.size - WINDOW))
+                G = real[o:o + WINDOW].copy()
+                lkind = "real"
+            else:
+                G, lkind = plant_low_complexity(rng2, G, s, e if svt != 4 else s + 60, j, real)
+                if H is not None and j % 2:
+                    H, _ = plant_low_complexity(rng2, H, s, e, j, real)
         if svt == 4:
             e = s + int(rng.integers(0, 3))
             if kind == "insdup":
@@ -246,6 +360,10 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             left, right = H[e - L:e], G[s:s + L]
         else:
             raise ValueError(kind)
+        if junction_ins and svt != 4:
+            left = np.concatenate([left, ACGT[_rng(seed ^ 0x1115, j).integers(0, 4, junction_ins)]])
+            L = left.size
+            flankL += junction_ins
         alt = np.concatenate([left, right])
         chrA[base:base + WINDOW] = G
         if two_chr:
@@ -266,6 +384,8 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         rec["seq_first"] = len(seqs)
         if n_reads <= 0:
             cons = _mutate(rng, alt[L - flankL:L + flankR], sub_rate)
+            if read_indel:
+                cons = _indel(_rng(seed ^ 0x1de1, j), cons, read_indel)
             if lr_like:
                 # sparse 1-base indels on top of the substitutions, then orientation
                 keep = rng.random(cons.size) >= 0.004
@@ -289,12 +409,19 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                     r = _ont(rng, alt[o:alt.size - int(rng.integers(0, 101))], sub_rate)
                 else:
                     r = _mutate(rng, alt[o:o + read_len], sub_rate)
+                if read_indel:
+                    r = _indel(_rng(seed ^ 0x1de1, j * 64 + tries), r, read_indel)
                 key = r.tobytes()
                 if key in seen:
                     continue
                 seen.add(key)
                 seqs.append(r)
+                if dup_reads and len(seen) % 3 == 0 and len(seen) < n_reads:
+                    seen.add(key + b"#%d" % len(seen))
+                    seqs.append(r.copy())
             rec["n_seq"] = len(seen)
+        if genome is not None:
+            kind = kind + "/" + lkind
         truth.append(dict(kind=kind, svt=svt, start=base + s, end=base + e, flankL=flankL, flankR=flankR))
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([x.size for x in seqs], dtype=np.uint64)
@@ -407,3 +534,15 @@ def make_nw_jobs(n_reads, *, seed=17, err=0.06, min_half=500, max_half=1000, wei
     for k, name in enumerate(("query_off", "target_off", "query_len", "target_len")):
         jobs[name] = [x[k] for x in rows]
     return jobs, (np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8))
+
+
+def load_real_chromosome(path=None):
+    """The 2-bit packed real chromosome fixture (tests/golden/chr18_example.npz = the reference's example/ref.fa,
+    made by tests/golden/make_real_fixture.py) as upper-case bytes."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "chr18_example.npz")
+    z = np.load(path)
+    p = z["packed"]
+    c = np.stack([p & 3, (p >> 2) & 3, (p >> 4) & 3, p >> 6], axis=1).reshape(-1)[:int(z["n"])]
+    return ACGT[c]
