@@ -5,11 +5,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dellyhip.h"
@@ -51,12 +54,13 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;   // false: p points into another allocation (the staging block of a stream slot)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
     return *this;
   }
   ~DevBuf() { release(); }
@@ -69,24 +73,54 @@ struct DevBuf {
     return 0;
   }
   // keeps the allocation when it is already large enough (hipMalloc/hipFree synchronise the device)
-  int reserve(size_t count) { return (p && n >= count) ? 0 : alloc(count); }
+  int reserve(size_t count) { return (p && owned && n >= count) ? 0 : alloc(count); }
+  // like reserve(), but a growing buffer gets 25 % head room (recycled batches of a stream: sizes wobble from batch to batch)
+  int reserve_grow(size_t count) { return (p && owned && n >= count) ? 0 : alloc(count + count / 4 + 64); }
+  void borrow(T* ptr, size_t count) {
+    release();
+    p = ptr;
+    n = count;
+    owned = false;
+  }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
   }
 };
 
 }  // namespace
+
+// The resident chromosomes of one device.  Shared (ref-counted) by every context created with dellyhip_create_shared:
+// the worker threads of the reference's ThreadPool (src/shortpe.h:175-201) and the slots of a dellyhip_stream all see ONE
+// copy of the genome (3.1 GB), not one per context.
+struct ChrTable {
+  std::mutex mu;
+  int device = 0;
+  std::vector<uint8_t*> dev;
+  std::vector<int64_t> len;
+  uint64_t version = 1;
+  ~ChrTable() {
+    (void)hipSetDevice(device);
+    for (auto p : dev)
+      if (p) (void)hipFree(p);
+  }
+};
+
+struct dellyhip_stream;
 
 struct dellyhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   dellyhip_params params{};
   int n_cu = 0;
-  // chromosome table
+  // chromosome table: the shared object and this context's snapshot of it (refresh_chr)
+  std::shared_ptr<ChrTable> chrs;
+  uint64_t chr_seen = 0;
   std::vector<uint8_t*> chr_dev;   // device pointers
   std::vector<int64_t> chr_len;
+  dellyhip_stream* host_streams[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the host-buffer entry points run through persistent one-slot streams (run_host_batch)
   DevBuf<const uint8_t*> d_chr_ptr;
   DevBuf<int64_t> d_chr_len;
   bool chr_dirty = true;
@@ -105,6 +139,7 @@ struct dellyhip_ctx {
   int sparse_cost = 160;     // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
+  int msa_only = 0;          // env DELLYHIP_MSA_ONLY=1 (profiling builds): msa() batches stop after the MSA kernels
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
@@ -137,6 +172,9 @@ struct dellyhip_batch {
   DevBuf<int32_t> early_list;
   int early_count = 0;
   bool early_done = false;           // this run: split_sparse_kernel has been launched already
+  int lazy = 0;                      // stream slot: dense routing of the sparse kernel's leftovers happens at collect time
+  bool lazy_pending = false;         // ... and has not happened yet for the current run
+  int32_t* pin_cons_len = nullptr;   // stream slot: pinned destination of the consensus lengths (msa() batches)
   int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
   int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
@@ -187,6 +225,7 @@ struct dellyhip_batch {
   int msa_big_grid = 0;
   // timing
   std::vector<hipEvent_t> ev;        // 4 events per launch since the last kernel_ms()
+  std::vector<hipEvent_t> ev_free;   // recycled events (hipEventCreate costs ~10 us each: not inside a pipelined loop)
   hipEvent_t last = nullptr;
   hipEvent_t mid = nullptr;          // recorded between the DP kernels and the post kernel
   hipEvent_t len_ev = nullptr;       // msa() batches: the consensus lengths have arrived on the host
@@ -197,11 +236,23 @@ struct dellyhip_batch {
 
 namespace {
 
+// this context's view of the shared chromosome table
+void refresh_chr(dellyhip_ctx* c) {
+  std::lock_guard<std::mutex> g(c->chrs->mu);
+  if (c->chr_seen == c->chrs->version) return;
+  c->chr_dev = c->chrs->dev;
+  c->chr_len = c->chrs->len;
+  c->chr_seen = c->chrs->version;
+  c->chr_dirty = true;
+}
+
 int ensure_chr_table(dellyhip_ctx* c) {
+  refresh_chr(c);
   if (!c->chr_dirty) return 0;
   size_t n = c->chr_dev.size();
   if (n == 0) return fail(DELLYHIP_E_ARG, "no chromosome uploaded (dellyhip_set_chromosome)");
   int rc;
+  HIPCHK(hipDeviceSynchronize());   // (kernels in flight may still read the old table)
   if ((rc = c->d_chr_ptr.alloc(n))) return rc;
   if ((rc = c->d_chr_len.alloc(n))) return rc;
   HIPCHK(hipMemcpy(c->d_chr_ptr.p, c->chr_dev.data(), n * sizeof(uint8_t*), hipMemcpyHostToDevice));
@@ -572,7 +623,14 @@ uint64_t wfa_layout(dh::LrWfaArgs& W, int maxlen) {
 // so that partners need (almost) the same number of DP steps.  bin_count[] counts PAIRS; a
 // leftover junction is paired with -1.  Junctions beyond the kernel limit go to the KMAX bin,
 // where the kernel flags them with DELLYHIP_E_LIMIT.
-int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
+// mode BINS_ALL: the classic layout -- every short-read junction sits in a dense bin AND (when eligible) in the sparse
+// list; the dense kernels skip what split_sparse_kernel finished.  Stream slots split this in two so that the host does
+// not sort junctions the dense kernels will never touch: BINS_LAZY = sparse-eligible junctions ONLY in the sparse list
+// (bins hold the rest: ineligible shapes, insertions, long-read shapes); BINS_LEFTOVER = a second pass for a batch whose
+// sparse kernel left junctions behind: dense bins of the sparse-eligible junctions only, nothing else.
+// work_out: the list is handed back instead of being copied to b->work (the caller stages it with its other inputs).
+enum { BINS_ALL = 0, BINS_LAZY = 1, BINS_LEFTOVER = 2 };
+int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL, std::vector<int32_t>* work_out = nullptr) {
   b->bin_first.assign(dh::KMAX + 2, 0);
   b->bin_count.assign(dh::KMAX + 2, 0);
   std::vector<std::vector<std::pair<int, int>>> bins(dh::KMAX + 2);  // (approx n, junction)
@@ -588,6 +646,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     kk = std::max(1, std::min(kk, dh::KMAX));
     const dellyhip_junction& J = b->h_junc[i];
     if (J.svt == 4) {  // splitAlign path: own kernels, one junction per wavefront
+      if (mode == BINS_LEFTOVER) continue;
       if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
           b->lri_blocks > 0)
         lriv.push_back(i);
@@ -596,13 +655,15 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     }
     if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
         b->h_win_len[i] <= dh::LR_NMAX && b->lr_blocks > 0) {  // strip kernel (else: E_LIMIT in the short-read kernels)
-      lrv.push_back(i);
+      if (mode != BINS_LEFTOVER) lrv.push_back(i);
       continue;
     }
     long span = (long)J.sv_end - (long)J.sv_start;
     int approx = (J.svt == 2 && span <= P.indelsize && span >= 0) ? (int)std::min<long>(2L * m + span, 1 << 20) : 4 * m;
     if (!b->h_win_len.empty()) approx = b->h_win_len[i];
-    if (b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx <= dh::SPS_NMAX && approx + m + 1 <= dh::SPS_ND) sparse.push_back(i);
+    const bool eligible = b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx <= dh::SPS_NMAX && approx + m + 1 <= dh::SPS_ND;
+    if (eligible && mode != BINS_LEFTOVER) sparse.push_back(i);
+    if ((mode == BINS_LAZY && eligible) || (mode == BINS_LEFTOVER && !eligible)) continue;
     if (b->use_quad && !direct && m + 1 <= dh::HALF * 5 && approx <= dh::QNMAX) {
       const int kq = std::max(1, (m + 1 + dh::HALF - 1) / dh::HALF);
       qbins[kq].push_back(std::make_pair(approx, i));
@@ -689,9 +750,13 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P) {
     for (auto& v : bins) dense += v.size();
     for (auto& v : qbins) dense += v.size();
     for (auto& v : qextra) dense += v.size();
-    b->sps_all = !sparse.empty() && sparse.size() == dense;
+    b->sps_all = mode == BINS_ALL && !sparse.empty() && sparse.size() == dense;
   }
   work.insert(work.end(), sparse.begin(), sparse.end());
+  if (work_out) {
+    work_out->swap(work);
+    return 0;
+  }
   int rc = b->work.reserve(std::max<size_t>(work.size(), (size_t)3 * b->n + 2 * dh::KMAX + 64));
   if (rc) return rc;
   if (!work.empty()) HIPCHK(hipMemcpy(b->work.p, work.data(), work.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -771,6 +836,111 @@ __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* bl
   }
 }
 
+namespace {
+
+// Pinned host memory, grown geometrically and kept (hipHostMalloc / hipHostFree synchronise the device).
+template <typename T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf&) = delete;
+  PinBuf& operator=(const PinBuf&) = delete;
+  ~PinBuf() { release(); }
+  int reserve(size_t count) {
+    if (p && n >= count) return 0;
+    release();
+    const size_t want = count + count / 4 + 64;
+    hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail(DELLYHIP_E_NOMEM, "hipHostMalloc", e); }
+    n = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// Staging arena of a stream slot: one pinned host block and one device block with the SAME layout.  Everything a batch
+// uploads (junction records, offsets, sequence bytes, work lists) is appended to the host block, the batch's device pointers
+// are borrowed from the device block at the same offsets, and ONE asynchronous copy moves the used prefix.
+struct Arena {
+  PinBuf<uint8_t> h;
+  DevBuf<uint8_t> d;
+  size_t used = 0;
+  int begin(size_t cap) {
+    used = 0;
+    int rc = h.reserve(cap);
+    if (!rc) rc = d.reserve_grow(cap);
+    return rc;
+  }
+  // -> host pointer of the appended range (the caller may still fill it); *dev = its device twin
+  template <typename T>
+  T* put(const T* src, size_t count, size_t pad_bytes, T** dev) {
+    used = (used + 15) & ~(size_t)15;
+    const size_t bytes = count * sizeof(T);
+    if (used + bytes + pad_bytes > h.n || used + bytes + pad_bytes > d.n) return nullptr;
+    T* hp = reinterpret_cast<T*>(h.p + used);
+    if (src && bytes) memcpy(hp, src, bytes);
+    *dev = reinterpret_cast<T*>(d.p + used);
+    used += bytes + pad_bytes;
+    return hp;
+  }
+};
+
+struct UploadOpts {
+  dellyhip_batch* recycle = nullptr;   // reuse this batch object and its device allocations
+  Arena* arena = nullptr;              // stage the inputs (else: one allocation + synchronous copy per array)
+  bool lazy = false;                   // stream slot: host routing of what split_sparse_kernel leaves behind is deferred
+};
+
+// per-batch host state back to "freshly constructed", device allocations kept
+void batch_reset(dellyhip_batch* b) {
+  b->ever_run = false; b->probe_mode = 0; b->n = 0; b->n_seq = 0; b->with_msa = 0; b->want_alignment = 0;
+  b->h_junc.clear(); b->h_cons_len.clear(); b->h_win_len.clear();
+  b->out_stride = 0;
+  b->out_cons_cap = dh::OUT_CONS_CAP; b->out_allele_cap = dh::OUT_ALLELE_CAP; b->out_aln_cap = dh::OUT_ALN_CAP;
+  b->bin_first.clear(); b->bin_count.clear(); b->qbin_first.clear(); b->qbin_count.clear(); b->qbin_pairs.clear();
+  b->ins_first = b->ins_count = 0; b->sps_all = false; b->early_count = 0; b->early_done = false; b->sps_first = b->sps_count = 0;
+  b->lr_first = b->lr_count = b->lr_blocks = 0; b->lri_first = b->lri_count = b->lri_blocks = 0;
+  b->wfa_items = 0; b->wfa_pair_grid = 1; b->wfa_count = b->wfa_blocks = 0; b->small_inv_n = 0;
+  b->lm_hbuf_half = 0; b->lm_pair_grid = 1; b->lm_items = b->lm_blocks = 0;
+  b->msa_big_grid = 0; b->lazy = 0; b->lazy_pending = false;
+  b->ms_split = b->ms_msa = b->ms_dp = b->ms_dp_last = 0; b->launches = 0; b->pending = false;
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release();
+}
+
+}  // namespace
+
+// stream slots: the compaction also emits the records as the caller sees them -- blob offsets rebased to the compact blob,
+// transient kernel state (result.reserved) cleared -- so that the host only copies
+__global__ void blob_gather_records_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out,
+                                           dellyhip_result* rec_out, int n) {
+  const int lane = threadIdx.x;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    dellyhip_result R = res[i];
+    uint64_t at = off[i];
+    uint8_t* dst = out + at;
+    const uint64_t src[3] = {R.cons_off, R.allele_off, R.aln_off};
+    const int len[3] = {max(R.cons_len, 0), max(R.allele_len, 0), 2 * max(R.aln_len, 0)};
+    for (int k = 0; k < 3; ++k) {
+      for (int q = lane; q < len[k]; q += dh::WAVE) dst[q] = blob[src[k] + q];
+      dst += len[k];
+    }
+    if (lane == 0) {
+      R.cons_off = len[0] ? at : 0;
+      at += len[0];
+      R.allele_off = len[1] ? at : 0;
+      at += len[1];
+      R.aln_off = len[2] ? at : 0;
+      R.reserved = 0;
+      rec_out[i] = R;
+    }
+  }
+}
+
 extern "C" {
 
 const char* dellyhip_last_error(void) { return g_err.c_str(); }
@@ -804,6 +974,8 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   c->device = device;
   c->params = *params;
   c->n_cu = prop.multiProcessorCount;
+  c->chrs = std::make_shared<ChrTable>();
+  c->chrs->device = device;
   if (const char* t = getenv("DELLYHIP_QUAD")) c->use_quad = atoi(t) != 0;  // tuning / test knobs
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
@@ -811,6 +983,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   if (const char* t = getenv("DELLYHIP_SPS_WAVES")) c->sps_waves = std::max(1, std::min(20, atoi(t)));
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_MSA_ONLY")) c->msa_only = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -821,11 +994,24 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   return 0;
 }
 
+int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out) {
+  if (!share_with || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  dellyhip_ctx* c = nullptr;
+  int rc = dellyhip_create(params ? params : &share_with->params, share_with->device, &c);
+  if (rc) return rc;
+  c->chrs = share_with->chrs;
+  *out = c;
+  return 0;
+}
+
 void dellyhip_destroy(dellyhip_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (auto p : c->chr_dev)
-    if (p) (void)hipFree(p);
+  for (auto& hs : c->host_streams) {
+    if (hs) dellyhip_stream_destroy(hs);
+    hs = nullptr;
+  }
+  c->chrs.reset();   // (the last context of a table frees the chromosomes)
   c->d_chr_ptr.release();
   c->d_chr_len.release();
   c->scratch.release();
@@ -838,10 +1024,6 @@ void dellyhip_destroy(dellyhip_ctx* c) {
 int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64_t len) {
   if (!c || chr < 0 || len < 0 || (!seq && len)) return fail(DELLYHIP_E_ARG, "bad chromosome");
   HIPCHK(hipSetDevice(c->device));
-  if ((size_t)chr >= c->chr_dev.size()) {
-    c->chr_dev.resize(chr + 1, nullptr);
-    c->chr_len.resize(chr + 1, 0);
-  }
   uint8_t* d = nullptr;   // allocate and fill the new buffer first: a failure leaves the old chromosome in place
   hipError_t e = hipMalloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
   if (e != hipSuccess) return fail(DELLYHIP_E_NOMEM, "hipMalloc(chromosome)", e);
@@ -849,10 +1031,22 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
     e = hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(DELLYHIP_E_RUNTIME, "H2D chromosome", e); }
   }
-  if (c->chr_dev[chr]) (void)hipFree(c->chr_dev[chr]);
-  c->chr_dev[chr] = d;
-  c->chr_len[chr] = len;
-  c->chr_dirty = true;
+  {
+    std::lock_guard<std::mutex> g(c->chrs->mu);
+    ChrTable& T = *c->chrs;
+    if ((size_t)chr >= T.dev.size()) {
+      T.dev.resize(chr + 1, nullptr);
+      T.len.resize(chr + 1, 0);
+    }
+    if (T.dev[chr]) {
+      (void)hipDeviceSynchronize();   // (a kernel of any context sharing the table may still read the old copy)
+      (void)hipFree(T.dev[chr]);
+    }
+    T.dev[chr] = d;
+    T.len[chr] = len;
+    ++T.version;
+  }
+  refresh_chr(c);
   return 0;
 }
 
@@ -864,15 +1058,17 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
   b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release();
   for (auto e : b->ev) (void)hipEventDestroy(e);
+  for (auto e : b->ev_free) (void)hipEventDestroy(e);
   if (b->len_ev) (void)hipEventDestroy(b->len_ev);
   delete b;
 }
 
 static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
                              const uint64_t* seq_off, uint64_t n_seq, int with_msa, int want_alignment,
-                             dellyhip_batch** out) {
+                             dellyhip_batch** out, const UploadOpts* opts = nullptr) {
   if (!c || !out || n < 0 || (n && (!junc || !seq_off))) return fail(DELLYHIP_E_ARG, "bad batch arguments");
   HIPCHK(hipSetDevice(c->device));
+  refresh_chr(c);
   if (n_seq && (!seq_off || (seq_off[n_seq] && !seq_blob))) return fail(DELLYHIP_E_ARG, "null sequence blob / offsets");
   for (uint64_t i = 0; i < n_seq; ++i)
     if (seq_off[i + 1] < seq_off[i] || seq_off[i + 1] - seq_off[i] > 0x7fffffffull)
@@ -891,7 +1087,10 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       return fail(DELLYHIP_E_ARG, "junction coordinates outside the chromosome");
     if (J.svt >= 0 && J.svt <= 4 && J.chr != J.chr2) return fail(DELLYHIP_E_ARG, "svt 0-4 with chr != chr2");
   }
-  dellyhip_batch* b = new dellyhip_batch();
+  const bool recycle = opts && opts->recycle;
+  Arena* arena = opts ? opts->arena : nullptr;
+  dellyhip_batch* b = recycle ? opts->recycle : new dellyhip_batch();
+  if (recycle) batch_reset(b);
   b->n = n;
   b->n_seq = n_seq;
   b->with_msa = with_msa;
@@ -951,29 +1150,51 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->out_stride = (b->out_stride + 15) & ~15ull;
   uint64_t blob_bytes = n_seq ? seq_off[n_seq] : 0;
   int rc = 0;
-  auto bail = [&](int r) { dellyhip_batch_free(c, b); return r; };
-  if ((rc = b->junc.alloc(std::max(n, 1)))) return bail(rc);
-  if ((rc = b->seq_blob.alloc(blob_bytes + 64))) return bail(rc);   // (+64: the bit-vector kernels fetch pattern bytes 32 at a time)
-  if ((rc = b->seq_off.alloc(n_seq + 1))) return bail(rc);
-  if ((rc = b->cons_off.alloc(std::max(n, 1)))) return bail(rc);
-  if ((rc = b->cons_len.alloc(std::max(n, 1)))) return bail(rc);
-  if ((rc = b->res.alloc(std::max(n, 1)))) return bail(rc);
-  if ((rc = b->out_blob.alloc(std::max<uint64_t>((uint64_t)n * b->out_stride, 1)))) return bail(rc);
+  auto bail = [&](int r) {
+    if (!recycle) dellyhip_batch_free(c, b);
+    return r;
+  };
   hipError_t e;
-  if (n) {
-    e = hipMemcpy(b->junc.p, junc, n * sizeof(dellyhip_junction), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D junctions", e));
-    if (blob_bytes) {
-      e = hipMemcpy(b->seq_blob.p, seq_blob, blob_bytes, hipMemcpyHostToDevice);
-      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D sequences", e));
+  // one array of the batch onto the device: staged (arena) or allocation + synchronous copy
+  auto push = [&](auto& dst, const auto* src, size_t count, size_t pad_elems, const char* what) -> int {
+    typedef typename std::remove_reference<decltype(*dst.p)>::type T;
+    if (arena) {
+      T* dev = nullptr;
+      if (!arena->put<T>(src, count, pad_elems * sizeof(T), &dev)) return fail(DELLYHIP_E_RUNTIME, "staging arena overflow");
+      dst.borrow(dev, count + pad_elems);
+      return 0;
     }
-    e = hipMemcpy(b->seq_off.p, seq_off, (n_seq + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D offsets", e));
+    int r = dst.alloc(std::max<size_t>(count + pad_elems, 1));
+    if (r) return r;
+    if (count) {
+      hipError_t ee = hipMemcpy(dst.p, src, count * sizeof(T), hipMemcpyHostToDevice);
+      if (ee != hipSuccess) return fail(DELLYHIP_E_RUNTIME, what, ee);
+    }
+    return 0;
+  };
+  if (arena) {
+    // everything push() appends below: records, offsets, bytes, per-junction arrays, work lists (<= 3 n + bins), pair lists
+    const size_t cap = (size_t)n * (sizeof(dellyhip_junction) + 8 + 4 + 16 + 12 + 8) + (n_seq + 1) * 8 + blob_bytes + 64 + 4096;
+    if ((rc = arena->begin(cap))) return bail(rc);
   }
-  // (memsets go onto the context's stream and are waited for: hipMemset on the null stream returns before the fill is done
-  //  and is not ordered with a hipStreamNonBlocking stream -- a kernel launched there could be overwritten by the fill)
+  if ((rc = push(b->junc, junc, (size_t)n, 0, "H2D junctions"))) return bail(rc);
+  if ((rc = push(b->seq_blob, reinterpret_cast<const uint8_t*>(seq_blob), (size_t)blob_bytes, 64, "H2D sequences"))) return bail(rc);   // (+64: the bit-vector kernels fetch pattern bytes 32 at a time)
+  if ((rc = push(b->seq_off, seq_off, (size_t)n_seq + 1, 0, "H2D offsets"))) return bail(rc);
+  const bool cons_len_staged = arena && !with_msa;   // (given consensus: the lengths travel with the other inputs)
+  if (recycle) {
+    if ((!cons_len_staged && (rc = b->cons_len.reserve_grow(std::max(n, 1)))) || (rc = b->res.reserve_grow(std::max(n, 1))) ||
+        (rc = b->out_blob.reserve_grow(std::max<uint64_t>((uint64_t)n * b->out_stride, 1))))
+      return bail(rc);
+  } else {
+    if (!cons_len_staged && (rc = b->cons_len.alloc(std::max(n, 1)))) return bail(rc);
+    if ((rc = b->res.alloc(std::max(n, 1)))) return bail(rc);
+    if ((rc = b->out_blob.alloc(std::max<uint64_t>((uint64_t)n * b->out_stride, 1)))) return bail(rc);
+  }
+  // (memsets go onto the context's stream: hipMemset on the null stream returns before the fill is done and is not ordered
+  //  with a hipStreamNonBlocking stream -- a kernel launched there could be overwritten by the fill.  Staged uploads stay
+  //  asynchronous: every later operation of the batch is enqueued on the same stream.)
   e = hipMemsetAsync(b->res.p, 0, std::max(n, 1) * sizeof(dellyhip_result), c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && !arena) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset results", e));
   b->h_cons_len.resize(n);
   if (!with_msa) {
@@ -982,23 +1203,26 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       coff[i] = seq_off[junc[i].seq_first];
       b->h_cons_len[i] = (int32_t)(seq_off[junc[i].seq_first + 1] - seq_off[junc[i].seq_first]);
     }
-    if (n) {
-      e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
-      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
+    if ((rc = push(b->cons_off, coff.data(), (size_t)n, 0, "H2D cons_off"))) return bail(rc);
+    if (arena) {
+      if ((rc = push(b->cons_len, b->h_cons_len.data(), (size_t)n, 4, "H2D cons_len"))) return bail(rc);
+    } else if (n) {
       e = hipMemcpy(b->cons_len.p, b->h_cons_len.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_len", e));
     }
     if (lr_cnt && (rc = setup_lr_workspace(c, b, lr_m, lr_n, lr_cnt))) return bail(rc);
     if (lri_cnt && (rc = setup_lri_workspace(c, b, lri_m, lri_n, lri_cnt))) return bail(rc);
-    if ((rc = build_bins(b, c->params))) return bail(rc);
+    if (arena) {
+      std::vector<int32_t> work;
+      b->lazy = (opts->lazy && b->sr_sparse) ? 1 : 0;
+      if ((rc = build_bins(b, c->params, b->lazy ? BINS_LAZY : BINS_ALL, &work))) return bail(rc);
+      if ((rc = push(b->work, work.data(), work.size(), 64, "H2D work list"))) return bail(rc);
+    } else if ((rc = build_bins(b, c->params))) return bail(rc);
   } else {
     // consensus is produced on the device at out_blob + i*stride
     std::vector<uint64_t> coff(n);
     for (int i = 0; i < n; ++i) coff[i] = (uint64_t)i * b->out_stride;
-    if (n) {
-      e = hipMemcpy(b->cons_off.p, coff.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice);
-      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D cons_off", e));
-    }
+    if ((rc = push(b->cons_off, coff.data(), (size_t)n, 0, "H2D cons_off"))) return bail(rc);
     if (with_msa == 2) {
       // msaEdlib: all-pairs work list + per-block workspace sized from the longest read
       std::vector<int32_t> pf(n + 1, 0);
@@ -1014,17 +1238,17 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       }
       b->lm_hbuf_half = long_pairs ? (((uint64_t)maxlen + 16 + 255) & ~255ull) : 0;
       b->lm_items = pf[n];
-      if ((rc = b->lm_pair_first.alloc(n + 1)) || (rc = b->lm_edit.alloc(std::max<size_t>((size_t)n * dh::LM_NR * dh::LM_NR, 1)))) return bail(rc);
-      e = hipMemcpy(b->lm_pair_first.p, pf.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
-      if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D pair list", e));
+      if ((rc = push(b->lm_pair_first, pf.data(), (size_t)n + 1, 0, "H2D pair list")) ||
+          (rc = b->lm_edit.reserve(std::max<size_t>((size_t)n * dh::LM_NR * dh::LM_NR, 1))))
+        return bail(rc);
       dh::LrMsaArgs& M = b->lm;
       lm_layout(M, maxlen);
       b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4));
       b->lm_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lm_blocks, ws_budget_bytes() / std::max<uint64_t>(M.ws_stride, 1)));
-      if ((rc = b->lm_ws.alloc((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
+      if ((rc = b->lm_ws.reserve((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
       M.ws = b->lm_ws.p;
       b->lm_pair_grid = std::max(1, std::min(b->lm_items, c->n_cu * 16));
-      if (b->lm_hbuf_half && (rc = b->lm_hbuf.alloc((size_t)2 * b->lm_hbuf_half * b->lm_pair_grid))) return bail(rc);
+      if (b->lm_hbuf_half && (rc = b->lm_hbuf.reserve((size_t)2 * b->lm_hbuf_half * b->lm_pair_grid))) return bail(rc);
       // insertions: msaWfa kernel
       std::vector<int32_t> wl;
       for (int i = 0; i < n; ++i)
@@ -1034,11 +1258,9 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         wfa_layout(b->wfa, maxlen);
         b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 4));
         b->wfa_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->wfa_blocks, ws_budget_bytes() / std::max<uint64_t>(b->wfa.ws_stride, 1)));
-        if ((rc = b->wfa_list.alloc(wl.size())) || (rc = b->wfa_ws.alloc((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
-        e = hipMemcpy(b->wfa_list.p, wl.data(), wl.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa list", e));
+        if ((rc = push(b->wfa_list, wl.data(), wl.size(), 0, "H2D wfa list")) || (rc = b->wfa_ws.reserve((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
         e = hipMemsetAsync(b->wfa_ws.p, 0, (size_t)b->wfa.ws_stride * b->wfa_blocks, c->stream);   // k-mer tables start (and are kept) all zero
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && !arena) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa workspace", e));
         b->wfa.ws = b->wfa_ws.p;
         // pairwise scores of every insertion junction: work list + workspace of wfa_pairs_kernel
@@ -1059,14 +1281,12 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         b->wfa_pair_grid = std::max(1, std::min(b->wfa_items, c->n_cu * 16));
         b->wfa_pair_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->wfa_pair_grid, ws_budget_bytes() / WP.ws_stride));
         if (b->wfa_items > 0) {
-          if ((rc = b->wfa_pair_first.alloc(n + 1)) || (rc = b->wfa_edit.alloc((size_t)n * dh::LM_NR * dh::LM_NR)) ||
-              (rc = b->wfa_pair_ws.alloc((size_t)WP.ws_stride * b->wfa_pair_grid)) || (rc = b->wfa_next.alloc(1)))
+          if ((rc = push(b->wfa_pair_first, wpf.data(), (size_t)n + 1, 0, "H2D wfa pair list")) || (rc = b->wfa_edit.reserve((size_t)n * dh::LM_NR * dh::LM_NR)) ||
+              (rc = b->wfa_pair_ws.reserve((size_t)WP.ws_stride * b->wfa_pair_grid)) || (rc = b->wfa_next.reserve(1)))
             return bail(rc);
-          e = hipMemcpy(b->wfa_pair_first.p, wpf.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
-          if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D wfa pair list", e));
           e = hipMemsetAsync(b->wfa_pair_ws.p, 0, (size_t)WP.ws_stride * b->wfa_pair_grid, c->stream);   // k-mer tables start (and are kept) all zero
           if (e == hipSuccess) e = hipMemsetAsync(b->wfa_edit.p, 0, (size_t)n * dh::LM_NR * dh::LM_NR * sizeof(int32_t), c->stream);
-          if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+          if (e == hipSuccess && !arena) e = hipStreamSynchronize(c->stream);
           if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa pair workspace", e));
           WP.pair_first = b->wfa_pair_first.p;
           WP.edit = b->wfa_edit.p;
@@ -1078,23 +1298,26 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       }
     } else {
       const dh::MsaPlan& mp = b->msa_plan;
-      if ((rc = b->msa_ws.alloc(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+      if ((rc = b->msa_ws.reserve(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
       // msa_big: as many resident wavefronts as junctions are expected there; a few stand by for the unpredictable
       // case (a node of the standard instance growing beyond its 512 columns)
       b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
-      if ((rc = b->msa_big_ws.alloc(std::max<uint64_t>(1, mp.big_ws_stride * (uint64_t)b->msa_big_grid)))) return bail(rc);
+      if ((rc = b->msa_big_ws.reserve(std::max<uint64_t>(1, mp.big_ws_stride * (uint64_t)b->msa_big_grid)))) return bail(rc);
       if (c->sr_sparse && !(c->params.reserved & 1)) {   // (long-read parameters route every junction to the strip kernel)
         std::vector<int32_t> el;
         for (int i = 0; i < n; ++i)
           if (junc[i].svt != 4) el.push_back(i);
         b->early_count = (int)el.size();
-        if (b->early_count) {
-          if ((rc = b->early_list.alloc(el.size()))) return bail(rc);
-          e = hipMemcpy(b->early_list.p, el.data(), el.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-          if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D early list", e));
-        }
+        if (b->early_count && (rc = push(b->early_list, el.data(), el.size(), 0, "H2D early list"))) return bail(rc);
+        // every junction goes through split_sparse_kernel first: a stream slot routes what it leaves behind (usually
+        // nothing) when the results are collected, not in the middle of the run
+        b->lazy = (opts && opts->lazy && b->early_count == n && n > 0) ? 1 : 0;
       }
     }
+  }
+  if (arena && arena->used) {
+    e = hipMemcpyAsync(arena->d.p, arena->h.p, arena->used, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D staged inputs", e));
   }
   *out = b;
   return 0;
@@ -1116,8 +1339,11 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   int rc;
   hipEvent_t e3[4];
   bool ev1_done = false;
-  for (int q = 0; q < 4; ++q) HIPCHK(hipEventCreate(&e3[q]));
-  for (int q = 0; q < 4; ++q) b->ev.push_back(e3[q]);
+  for (int q = 0; q < 4; ++q) {
+    if (!b->ev_free.empty()) { e3[q] = b->ev_free.back(); b->ev_free.pop_back(); }
+    else HIPCHK(hipEventCreate(&e3[q]));
+    b->ev.push_back(e3[q]);
+  }
   b->mid = e3[3];
   if (!c->serial_ev) HIPCHK(hipEventCreateWithFlags(&c->serial_ev, hipEventDisableTiming));
   if (c->serial_valid) HIPCHK(hipStreamWaitEvent(s, c->serial_ev, 0));
@@ -1223,9 +1449,28 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
                              b->msa_plan.big_nmax)))
       return fail(rc, "msa_launch");
     HIPCHK(hipGetLastError());
+    if (c->msa_only) {   // profiling: the records keep what the MSA kernels wrote (tools/msa_phases.py)
+      HIPCHK(hipEventRecord(e3[1], s));
+      HIPCHK(hipEventRecord(e3[3], s));
+      HIPCHK(hipEventRecord(e3[2], s));
+      HIPCHK(hipEventRecord(c->serial_ev, s));
+      c->serial_valid = true;
+      b->last = e3[2];
+      b->pending = true;
+      b->launches++;
+      b->ever_run = true;
+      return 0;
+    }
     // consensus lengths decide the K bin of the split kernel
-    HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (b->early_count > 0) {
+    HIPCHK(hipMemcpyAsync((b->lazy && b->pin_cons_len) ? b->pin_cons_len : b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, s));
+    if (b->lazy) {
+      // stream slot: every junction goes through split_sparse_kernel; what it leaves behind (counters[31]) is routed to the
+      // dense kernels when the results are collected (finish_lazy) -- no host synchronisation inside the run
+      HIPCHK(hipEventRecord(e3[1], s));
+      ev1_done = true;
+      if ((rc = launch_early_sparse(c, b, s))) return rc;
+    } else if (b->early_count > 0) {
       // the sparse kernel needs no routing (it reads the lengths on the device and leaves what it cannot take to the
       // dense kernels): it runs while the host bins the batch from the downloaded lengths
       if (!b->len_ev) HIPCHK(hipEventCreateWithFlags(&b->len_ev, hipEventDisableTiming));
@@ -1237,10 +1482,11 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     } else {
       HIPCHK(hipStreamSynchronize(s));
     }
-    if ((rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
+    if (!b->lazy && (rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
   }
   if (!ev1_done) HIPCHK(hipEventRecord(e3[1], s));
-  if ((rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
+  if (!(b->lazy && b->with_msa == 1) && (rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
+  b->lazy_pending = b->lazy != 0;
   if (b->with_msa == 2 && b->small_inv_n > 0) {
     hipLaunchKernelGGL(small_inv_fix_kernel, dim3((b->small_inv_n + 63) / 64), dim3(64), 0, s, b->res.p, b->small_inv.p, b->small_inv_n);
     HIPCHK(hipGetLastError());
@@ -1268,7 +1514,7 @@ int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
     b->ms_split += d;
     b->ms_dp += e;
   }
-  for (auto e : b->ev) (void)hipEventDestroy(e);
+  for (auto e : b->ev) b->ev_free.push_back(e);
   b->ev.clear();
   b->pending = false;
   hipError_t e = hipGetLastError();
@@ -1358,7 +1604,10 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
     HIPCHK(hipMemcpyAsync(results, b->res.p, b->n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
     if (used > 0) HIPCHK(hipMemcpyAsync(out_blob, b->blob_compact.p, used, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < b->n; ++i) rebase_offsets(results[i], off[i]);
+    for (int i = 0; i < b->n; ++i) {
+      rebase_offsets(results[i], off[i]);
+      results[i].reserved = 0;   // (transient kernel state -- SPS_DONE and the like -- does not cross the ABI)
+    }
   }
   if (out_blob_len) *out_blob_len = used;
   return 0;
@@ -1378,7 +1627,8 @@ int dellyhip_shard_by_cost(const dellyhip_params* P, int32_t n, const dellyhip_j
   std::vector<double> cost((size_t)n);
   for (int i = 0; i < n; ++i) {
     const dellyhip_junction& J = junc[i];
-    if (J.n_seq < 0 || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
+    if (J.n_seq < 0 || J.seq_first > n_seq || J.seq_first + (uint64_t)J.n_seq > n_seq) return fail(DELLYHIP_E_ARG, "junction sequence range");
+    if (seq_off[J.seq_first + J.n_seq] < seq_off[J.seq_first]) return fail(DELLYHIP_E_ARG, "seq_off is not monotonic");
     const double N = (double)J.n_seq;
     const double bytes = (double)(seq_off[J.seq_first + J.n_seq] - seq_off[J.seq_first]);
     const double L = N > 0 ? bytes / N : 0.0;
@@ -1546,6 +1796,7 @@ int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b
         dellyhip_result& R = results[k];
         const uint64_t len = (uint64_t)std::max(R.cons_len, 0) + (uint64_t)std::max(R.allele_len, 0) + 2ull * (uint64_t)std::max(R.aln_len, 0);
         rebase_offsets(R, at);
+        R.reserved = 0;
         at += len;
       }
     }
@@ -1553,16 +1804,307 @@ int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b
   return 0;
 }
 
+// ---- pipelined host-buffer path: dellyhip_stream (SURVEY.md 8d "GPU time includes H2D/D2H and host marshalling") ----
+// A stream owns `depth` slots.  Each slot is a child context (own HIP stream, scratch area and work counters, sharing the
+// parent's resident chromosomes), a recycled batch object, a pinned staging arena for the inputs and a pinned block for
+// the outputs.  submit() validates and routes the junctions, copies the inputs into the arena and enqueues -- one H2D
+// copy, the kernels, the device-side compaction, the D2H copies -- without waiting; collect() waits for the oldest slot
+// and hands out pointers into its pinned output block.  Nothing is allocated per batch once the buffers have grown to
+// the batch size; with depth >= 2 the copies of one slot overlap the kernels of the others.
+struct StreamHeader {      // head of the pinned output block
+  uint64_t used;           // bytes of the compact blob
+  int32_t sps_left;        // junctions split_sparse_kernel left to the dense kernels
+  int32_t pad_;
+};
+struct StreamSlot {
+  dellyhip_ctx* ctx = nullptr;
+  dellyhip_batch* b = nullptr;
+  Arena in;
+  PinBuf<uint8_t> out;
+  DevBuf<dellyhip_result> d_rec;
+  hipEvent_t done = nullptr;
+  int state = 0;           // 0 free, 1 submitted, 2 collected (the caller still reads its output block)
+  int32_t n = 0;
+  uint64_t tag = 0;
+  uint64_t blob_copied = 0, blob_cap = 0;
+  size_t o_rec = 0, o_len = 0, o_blob = 0;
+};
+struct dellyhip_stream {
+  dellyhip_ctx* parent = nullptr;
+  int with_msa = 0, want_alignment = 0;
+  std::vector<StreamSlot> slots;
+  uint64_t n_submit = 0, n_collect = 0;
+  int held = -1;                    // slot whose output the caller holds since the last collect()
+  double blob_per_junction = 0;     // running estimate: bytes of compact blob per junction (sizes the first D2H copy)
+  // host seconds since creation / the last dellyhip_stream_stats(reset): validation + routing + staging | kernel launches |
+  // compaction + download enqueue | waiting in collect | slow-path batches (leftovers routed at collect) | blob top-ups
+  double t_stage = 0, t_launch = 0, t_down = 0, t_wait = 0;
+  uint64_t n_slow = 0, n_topup = 0;
+};
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+namespace {
+
+// offsets + gather + rebased records of slot S on its stream, then the D2H copies into the pinned block
+int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob) {
+  dellyhip_ctx* c = S.ctx;
+  dellyhip_batch* b = S.b;
+  const int n = b->n;
+  int rc;
+  if ((rc = b->blob_off.reserve_grow((size_t)n + 1)) || (rc = b->blob_compact.reserve_grow(std::max<uint64_t>((uint64_t)n * b->out_stride, 1))) ||
+      (rc = S.d_rec.reserve_grow((size_t)std::max(n, 1))))
+    return rc;
+  hipStream_t s = c->stream;
+  StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
+  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, n, b->blob_off.p);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(blob_gather_records_kernel, dim3(std::min(n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p,
+                     b->blob_off.p, b->blob_compact.p, S.d_rec.p, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&H->used, b->blob_off.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  if (c->counters.p) HIPCHK(hipMemcpyAsync(&H->sps_left, c->counters.p + 31, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p, (size_t)n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s));
+  // the blob's size is only known on the device: copy what the previous batches predict (all of it after a slow path)
+  uint64_t want = all_blob ? S.blob_cap : (uint64_t)(st->blob_per_junction * 1.25 * n) + 4096;
+  want = std::min<uint64_t>(std::min<uint64_t>(want, S.blob_cap), (uint64_t)n * b->out_stride);
+  if (all_blob) want = std::min<uint64_t>(want, H->used);   // (slow path: the header has been read already)
+  S.blob_copied = want;
+  if (want) HIPCHK(hipMemcpyAsync(S.out.p + S.o_blob, b->blob_compact.p, want, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(S.done, s));
+  return 0;
+}
+
+// the compact blob turned out larger than the pinned block: a larger block (header, records and lengths are copied over)
+int grow_out_block(StreamSlot& S, uint64_t blob_bytes) {
+  PinBuf<uint8_t> bigger;
+  int rc = bigger.reserve(S.o_blob + blob_bytes + 64);
+  if (rc) return rc;
+  memcpy(bigger.p, S.out.p, S.o_blob);
+  std::swap(bigger.p, S.out.p);
+  std::swap(bigger.n, S.out.n);
+  S.blob_cap = S.out.n - S.o_blob - 64;
+  if (S.b) S.b->pin_cons_len = reinterpret_cast<int32_t*>(S.out.p + S.o_len);
+  return 0;
+}
+
+// a lazy run whose sparse kernel left junctions behind: route them on the host, run the dense kernels (synchronous)
+int finish_lazy(StreamSlot& S) {
+  dellyhip_ctx* c = S.ctx;
+  dellyhip_batch* b = S.b;
+  int rc;
+  if (b->with_msa == 1) {
+    if (b->pin_cons_len) memcpy(b->h_cons_len.data(), b->pin_cons_len, (size_t)b->n * sizeof(int32_t));
+    b->lazy = 0;
+    if ((rc = route_after_msa(c, b))) return rc;   // (launch_early_sparse has set early_done: the sparse kernel is not launched again)
+  } else {
+    b->work.release();
+    if ((rc = build_bins(b, c->params, BINS_LEFTOVER))) return rc;
+    b->early_done = true;   // slots 30 / 31 of the counters belong to the sparse kernel that already ran
+  }
+  if ((rc = run_split(c, b, c->stream, false))) return rc;
+  b->lazy_pending = false;
+  return 0;
+}
+
+}  // namespace
+
+int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int32_t want_alignment, dellyhip_stream** out) {
+  if (!c || !out || depth < 1 || depth > 8 || with_msa < 0 || with_msa > 2) return fail(DELLYHIP_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<dellyhip_stream> st(new dellyhip_stream());
+  st->parent = c;
+  st->with_msa = with_msa;
+  st->want_alignment = want_alignment ? 1 : 0;
+  st->slots = std::vector<StreamSlot>((size_t)depth);
+  for (auto& S : st->slots) {
+    int rc = dellyhip_create_shared(c, &c->params, &S.ctx);
+    if (!rc) {
+      S.b = new dellyhip_batch();
+      hipError_t e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
+      if (e != hipSuccess) rc = fail(DELLYHIP_E_RUNTIME, "hipEventCreate", e);
+    }
+    if (rc) {
+      dellyhip_stream_destroy(st.release());
+      return rc;
+    }
+    // the tuning knobs of the parent (they are read from the environment at dellyhip_create: same values, but a caller
+    // may have changed the parent's since)
+    S.ctx->sr_sparse = c->sr_sparse; S.ctx->use_sparse = c->use_sparse; S.ctx->use_quad = c->use_quad; S.ctx->quad_mix = c->quad_mix;
+    S.ctx->sps_waves = c->sps_waves; S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
+  }
+  *out = st.release();
+  return 0;
+}
+
+void dellyhip_stream_destroy(dellyhip_stream* st) {
+  if (!st) return;
+  for (auto& S : st->slots) {
+    if (S.ctx) {
+      (void)hipSetDevice(S.ctx->device);
+      (void)hipStreamSynchronize(S.ctx->stream);
+    }
+    if (S.b) dellyhip_batch_free(S.ctx, S.b);
+    if (S.done) (void)hipEventDestroy(S.done);
+    S.in.d.release();
+    S.d_rec.release();
+    if (S.ctx) dellyhip_destroy(S.ctx);
+  }
+  delete st;
+}
+
+int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_junction* junc, const char* seq_blob, const uint64_t* seq_off,
+                           uint64_t n_seq, uint64_t tag) {
+  if (!st) return fail(DELLYHIP_E_ARG, "null argument");
+  StreamSlot& S = st->slots[st->n_submit % st->slots.size()];
+  if (S.state != 0) return fail(DELLYHIP_E_ARG, "dellyhip_stream_submit: every slot is in flight or held (collect first)");
+  dellyhip_ctx* c = S.ctx;
+  HIPCHK(hipSetDevice(c->device));
+  UploadOpts o;
+  o.recycle = S.b;
+  o.arena = &S.in;
+  o.lazy = true;
+  dellyhip_batch* b = nullptr;
+  const double t0 = now_s();
+  int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, st->with_msa, st->want_alignment, &b, &o);
+  if (rc) return rc;
+  // pinned output block: header | records | consensus lengths (msa) | compact blob (at most every slot full)
+  S.n = n;
+  S.tag = tag;
+  S.o_rec = 64;
+  S.o_len = S.o_rec + (((size_t)n * sizeof(dellyhip_result) + 63) & ~(size_t)63);
+  S.o_blob = S.o_len + (((size_t)n * sizeof(int32_t) + 63) & ~(size_t)63);
+  if (st->blob_per_junction <= 0) st->blob_per_junction = st->with_msa ? 1400.0 : 1100.0;
+  // capacity: what the estimate asks for with head room; a batch that needs more grows the block at collect time
+  S.blob_cap = std::min<uint64_t>((uint64_t)n * b->out_stride, (uint64_t)(st->blob_per_junction * 2.0 * n) + (1u << 16));
+  if ((rc = S.out.reserve(S.o_blob + S.blob_cap + 64))) return rc;
+  S.blob_cap = S.out.n - S.o_blob - 64;   // (use what the block has)
+  S.blob_cap = std::min<uint64_t>(S.blob_cap, (uint64_t)n * b->out_stride);
+  StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
+  H->used = 0;
+  H->sps_left = 0;
+  b->pin_cons_len = reinterpret_cast<int32_t*>(S.out.p + S.o_len);
+  const double t1 = now_s();
+  double t2 = t1;
+  if (n > 0) {
+    if ((rc = dellyhip_batch_run(c, b, nullptr))) return rc;
+    t2 = now_s();
+    if ((rc = slot_compact_and_download(st, S, false))) return rc;
+  }
+  const double t3 = now_s();
+  st->t_stage += t1 - t0;
+  st->t_launch += t2 - t1;
+  st->t_down += t3 - t2;
+  S.state = 1;
+  ++st->n_submit;
+  return 0;
+}
+
+void dellyhip_stream_release(dellyhip_stream* st) {
+  if (st && st->held >= 0) {
+    st->slots[st->held].state = 0;
+    st->held = -1;
+  }
+}
+
+void dellyhip_stream_stats(dellyhip_stream* st, double out[6], int32_t reset) {
+  if (!st || !out) return;
+  out[0] = st->t_stage; out[1] = st->t_launch; out[2] = st->t_down; out[3] = st->t_wait;
+  out[4] = (double)st->n_slow; out[5] = (double)st->n_topup;
+  if (reset) { st->t_stage = st->t_launch = st->t_down = st->t_wait = 0; st->n_slow = st->n_topup = 0; }
+}
+
+int dellyhip_stream_pending(dellyhip_stream* st) {
+  return st ? (int)(st->n_submit - st->n_collect) : 0;
+}
+
+int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results, const char** blob, uint64_t* blob_len, int32_t* n_out,
+                            uint64_t* tag) {
+  if (!st) return fail(DELLYHIP_E_ARG, "null argument");
+  dellyhip_stream_release(st);   // the previous collect()'s output block is released now
+  if (st->n_collect == st->n_submit) return fail(DELLYHIP_E_ARG, "dellyhip_stream_collect: nothing submitted");
+  const int si = (int)(st->n_collect % st->slots.size());
+  StreamSlot& S = st->slots[si];
+  dellyhip_ctx* c = S.ctx;
+  dellyhip_batch* b = S.b;
+  HIPCHK(hipSetDevice(c->device));
+  StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
+  if (S.n > 0) {
+    const double tw0 = now_s();
+    HIPCHK(hipEventSynchronize(S.done));
+    st->t_wait += now_s() - tw0;
+    int rc = dellyhip_batch_sync(c, b);
+    if (rc) return rc;
+    if (b->lazy_pending && H->sps_left > 0) {
+      ++st->n_slow;
+      // rare: junctions beyond the sparse kernel's shapes or level budget -> dense kernels now, then compact again
+      if ((rc = finish_lazy(S))) return rc;
+      HIPCHK(hipStreamSynchronize(c->stream));
+      blob_offsets_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(b->res.p, b->n, b->blob_off.p);
+      HIPCHK(hipMemcpyAsync(&H->used, b->blob_off.p + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (H->used > S.blob_cap) {
+        if ((rc = grow_out_block(S, H->used))) return rc;
+        H = reinterpret_cast<StreamHeader*>(S.out.p);
+      }
+      if ((rc = slot_compact_and_download(st, S, true))) return rc;
+      HIPCHK(hipEventSynchronize(S.done));
+    }
+    b->lazy_pending = false;
+    if (H->used > S.blob_copied) {   // the estimate was short: fetch the rest
+      ++st->n_topup;
+      if (H->used > S.blob_cap) {
+        const uint64_t used = H->used;
+        int rc2 = grow_out_block(S, used);
+        if (rc2) return rc2;
+        H = reinterpret_cast<StreamHeader*>(S.out.p);
+        S.blob_copied = 0;   // (the block moved: records and blob again)
+        HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p, (size_t)S.n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
+        H->used = used;
+      }
+      HIPCHK(hipMemcpyAsync(S.out.p + S.o_blob + S.blob_copied, b->blob_compact.p + S.blob_copied, H->used - S.blob_copied,
+                            hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      S.blob_copied = H->used;
+    }
+    const double per = (double)H->used / (double)S.n;
+    st->blob_per_junction = (st->n_collect == 0) ? per : 0.75 * st->blob_per_junction + 0.25 * per;
+  }
+  if (results) *results = reinterpret_cast<const dellyhip_result*>(S.out.p + S.o_rec);
+  if (blob) *blob = reinterpret_cast<const char*>(S.out.p + S.o_blob);
+  if (blob_len) *blob_len = S.n > 0 ? H->used : 0;
+  if (n_out) *n_out = S.n;
+  if (tag) *tag = S.tag;
+  S.state = 2;
+  st->held = si;
+  ++st->n_collect;
+  return 0;
+}
+
+// The host-buffer entry points run through a persistent one-slot stream per (mode, want_alignment): staging and device
+// buffers survive between calls, so a call costs the copies and the kernels, not hipMalloc / hipFree.
 static int run_host_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
                           const uint64_t* seq_off, uint64_t n_seq, dellyhip_result* results, char* out_blob,
                           uint64_t cap, uint64_t* used, int with_msa, int want_alignment) {
-  dellyhip_batch* b = nullptr;
-  int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, with_msa, want_alignment, &b);
+  if (!c) return fail(DELLYHIP_E_ARG, "null argument");
+  if (n < 0 || (n && !results)) return fail(DELLYHIP_E_ARG, "null argument");
+  const int key = with_msa * 2 + (want_alignment ? 1 : 0);
+  int rc;
+  if (!c->host_streams[key] && (rc = dellyhip_stream_create(c, 1, with_msa, want_alignment, &c->host_streams[key]))) return rc;
+  dellyhip_stream* st = c->host_streams[key];
+  dellyhip_stream_release(st);
+  if ((rc = dellyhip_stream_submit(st, n, junc, seq_blob, seq_off, n_seq, 0))) return rc;
+  const dellyhip_result* r = nullptr;
+  const char* blob = nullptr;
+  uint64_t len = 0;
+  rc = dellyhip_stream_collect(st, &r, &blob, &len, nullptr, nullptr);
   if (rc) return rc;
-  rc = dellyhip_batch_run(c, b, nullptr);
-  if (!rc) rc = dellyhip_batch_fetch(c, b, results, out_blob, cap, used);
-  dellyhip_batch_free(c, b);
-  return rc;
+  if (used) *used = len;
+  if (len > 0 && (!out_blob || len > cap)) return fail(DELLYHIP_E_ARG, "out_blob too small");
+  if (n) memcpy(results, r, (size_t)n * sizeof(dellyhip_result));
+  if (len) memcpy(out_blob, blob, len);
+  return 0;
 }
 
 int dellyhip_align_consensus_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,

@@ -686,7 +686,9 @@ __device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL
           X.out->cons_left = sr.found ? sr.consLeft : 0;
           X.out->ref_left = sr.found ? sr.refLeft : 0;
           X.out->ref_right = sr.found ? sr.refRight : n;   // (no split: the last column of the free-gap row m ties its maximum)
+#ifdef DH_LR_TIMING
           X.out->reserved = sr.levels;                     // diagnostic: deficit levels the sparse passes used
+#endif
         }
         X.consLeft = sr.found ? sr.consLeft : 0;
         X.refLeft = sr.found ? sr.refLeft : 0;

@@ -33,6 +33,8 @@ EXPORTS = [
     "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
+    "dellyhip_create_shared", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
+    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats",
 ]
 
 
@@ -58,6 +60,9 @@ def load_library():
         lib.dellyhip_jobs_free.restype = None
         lib.dellyhip_nwjobs_free.restype = None
         lib.dellyhip_comm_destroy.restype = None
+        lib.dellyhip_stream_destroy.restype = None
+        lib.dellyhip_stream_release.restype = None
+        lib.dellyhip_stream_stats.restype = None
         _lib = lib
     return _lib
 
@@ -120,11 +125,16 @@ class Comm:
 class Context:
     """One context per GPU (per process rank): replaces the ThreadPool of src/shortpe.h:80."""
 
-    def __init__(self, params=None, device=0):
+    def __init__(self, params=None, device=0, share_with=None):
+        """share_with: another Context whose resident chromosomes this one shares (dellyhip_create_shared)"""
         self.lib = load_library()
-        self.params = params if params is not None else abi.params_sr()
         self._ctx = C.c_void_p()
-        rc = self.lib.dellyhip_create(C.byref(self.params), int(device), C.byref(self._ctx))
+        if share_with is not None:
+            self.params = params if params is not None else share_with.params
+            rc = self.lib.dellyhip_create_shared(share_with._ctx, C.byref(self.params), C.byref(self._ctx))
+        else:
+            self.params = params if params is not None else abi.params_sr()
+            rc = self.lib.dellyhip_create(C.byref(self.params), int(device), C.byref(self._ctx))
         self._check(rc)
         self._chroms = []
 
@@ -317,6 +327,75 @@ class Context:
     def msa_edlib(self, reads):
         """msaEdlib(c, sps, cs) -> (rows, consensus)"""
         return self._msa_like(self.lib.dellyhip_msa_edlib, reads)
+
+
+class Stream:
+    """dellyhip_stream: the pipelined host-buffer path (the loop of src/shortpe.h:175-201 over many batches).
+    submit() returns without waiting; collect() hands out the oldest batch's results."""
+
+    def __init__(self, ctx, depth=3, with_msa=0, want_alignment=False):
+        self.ctx = ctx
+        self._s = C.c_void_p()
+        ctx._check(ctx.lib.dellyhip_stream_create(ctx._ctx, int(depth), int(with_msa), int(bool(want_alignment)), C.byref(self._s)))
+        self._keep = []
+
+    def submit(self, batch, tag=0):
+        junc = np.ascontiguousarray(batch.junctions)
+        blob = _u8(batch.seq_blob)
+        off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
+        self.ctx._check(self.ctx.lib.dellyhip_stream_submit(self._s, int(junc.shape[0]), _p(junc, C.c_void_p), _p(blob),
+                                                            _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1), C.c_uint64(tag)))
+
+    def submit_raw(self, n, junc_ptr, blob_ptr, off_ptr, n_seq, tag=0):
+        """pre-marshalled arguments (benchmark loops: no numpy work between the calls)"""
+        self.ctx._check(self.ctx.lib.dellyhip_stream_submit(self._s, n, junc_ptr, blob_ptr, off_ptr, n_seq, C.c_uint64(tag)))
+
+    def pending(self):
+        return int(self.ctx.lib.dellyhip_stream_pending(self._s))
+
+    def collect(self, copy=True):
+        """-> (results, blob, tag); copy=False: views of the stream's pinned block, valid until the next collect()"""
+        r, bl = C.c_void_p(), C.c_void_p()
+        ln, tag = C.c_uint64(0), C.c_uint64(0)
+        n = C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_stream_collect(self._s, C.byref(r), C.byref(bl), C.byref(ln), C.byref(n), C.byref(tag)))
+        if n.value == 0:
+            if copy:
+                self.release()
+            return np.zeros(0, dtype=abi.result_dtype()), np.zeros(0, dtype=np.uint8), tag.value
+        res = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_uint8)), shape=(n.value * abi.result_dtype().itemsize,)).view(abi.result_dtype())
+        blob = np.ctypeslib.as_array(C.cast(bl, C.POINTER(C.c_uint8)), shape=(max(int(ln.value), 1),))[:int(ln.value)]
+        if copy:
+            res, blob = res.copy(), blob.copy()
+            self.release()
+        return res, blob, tag.value
+
+    def release(self):
+        self.ctx.lib.dellyhip_stream_release(self._s)
+
+    def stats(self, reset=False):
+        """host seconds spent staging / launching / enqueueing downloads / waiting, slow-path and top-up batch counts"""
+        out = (C.c_double * 6)()
+        self.ctx.lib.dellyhip_stream_stats(self._s, out, int(bool(reset)))
+        return dict(stage_s=out[0], launch_s=out[1], download_enqueue_s=out[2], wait_s=out[3], slow_batches=int(out[4]), topup_batches=int(out[5]))
+
+    def collect_raw(self):
+        """-> (n, blob bytes): no numpy views (benchmark loops)"""
+        ln = C.c_uint64(0)
+        n = C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_stream_collect(self._s, None, None, C.byref(ln), C.byref(n), None))
+        return n.value, ln.value
+
+    def close(self):
+        if self._s:
+            self.ctx.lib.dellyhip_stream_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ResidentBatch:

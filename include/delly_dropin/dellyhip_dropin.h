@@ -7,7 +7,14 @@
  * channel on this path; a silent skip would change the VCF).
  *
  * One dellyhip_ctx per host thread and parameter set (thread_local): the reference calls msa()/alignConsensus() from
- * its ThreadPool workers (src/shortpe.h:175-201), a context is single-threaded.  Device: $DELLYHIP_DEVICE (default 0).
+ * its ThreadPool workers (src/shortpe.h:175-201), a context is single-threaded.  All of them are created with
+ * dellyhip_create_shared against ONE process-wide root context, so the resident chromosomes exist once per GPU however
+ * many threads and parameter sets there are (a chromosome is uploaded by whichever thread sees it first).
+ * Device: $DELLYHIP_DEVICE (default 0).
+ *
+ * The per-call wrappers (msa, alignConsensus, ...) run a batch of ONE junction per call: they exist so that every call
+ * site compiles and gives the reference's result, not to fill a GPU.  The ThreadPool loop itself is torali::refineBatch
+ * (split.h), one call per chromosome.
  */
 #ifndef DELLYHIP_DROPIN_H
 #define DELLYHIP_DROPIN_H
@@ -17,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -68,21 +76,37 @@ inline dellyhip_params make_params(TConfig const& c, bool realign = false) {
   return p;
 }
 
-/* ---- one context per thread and parameter set ---- */
+/* ---- the process-wide root: owns the shared chromosome table ---- */
+struct Root {
+  std::mutex mu;
+  dellyhip_ctx* ctx = nullptr;
+  std::map<int32_t, std::pair<const char*, int64_t>> chr;   /* chromosome index -> the host buffer that is resident */
+  ~Root() {
+    if (ctx) dellyhip_destroy(ctx);
+  }
+};
+inline Root& root() {
+  static Root R;
+  return R;
+}
+
+/* ---- one context per thread and parameter set, all sharing the root's chromosomes ---- */
 struct Session {
   dellyhip_ctx* ctx = nullptr;
   dellyhip_params params{};
-  std::map<int32_t, std::pair<const char*, int64_t>> chr;   /* chromosome index -> the host buffer that is resident */
   ~Session() {
     if (ctx) dellyhip_destroy(ctx);
   }
   /* alignConsensus(c, hdr, seq, sndSeq, sv): `seq` is the caller's faidx buffer of chromosome `idx`
-   * (src/shortpe.h:88); it is uploaded when the (pointer, length) pair changes */
+   * (src/shortpe.h:88); it is uploaded -- once per process, not per thread -- when the (pointer, length) pair changes
+   * (replacing a chromosome waits for the kernels of every context that may still read the old copy) */
   void chromosome(int32_t idx, const char* seq, int64_t len) {
-    auto it = chr.find(idx);
-    if (it != chr.end() && it->second.first == seq && it->second.second == len) return;
-    check(dellyhip_set_chromosome(ctx, idx, seq, len));
-    chr[idx] = std::make_pair(seq, len);
+    Root& R = root();
+    std::lock_guard<std::mutex> g(R.mu);
+    auto it = R.chr.find(idx);
+    if (it != R.chr.end() && it->second.first == seq && it->second.second == len) return;
+    check(dellyhip_set_chromosome(R.ctx, idx, seq, len));
+    R.chr[idx] = std::make_pair(seq, len);
   }
 };
 
@@ -92,8 +116,15 @@ inline Session& session(dellyhip_params const& p) {
     if (std::memcmp(&s->params, &p, sizeof p) == 0) return *s;
   std::unique_ptr<Session> s(new Session());
   s->params = p;
-  const char* dev = std::getenv("DELLYHIP_DEVICE");
-  check(dellyhip_create(&p, dev ? std::atoi(dev) : 0, &s->ctx));
+  Root& R = root();
+  {
+    std::lock_guard<std::mutex> g(R.mu);
+    if (!R.ctx) {
+      const char* dev = std::getenv("DELLYHIP_DEVICE");
+      check(dellyhip_create(&p, dev ? std::atoi(dev) : 0, &R.ctx));
+    }
+    check(dellyhip_create_shared(R.ctx, &p, &s->ctx));
+  }
   cache.push_back(std::move(s));
   return *cache.back();
 }

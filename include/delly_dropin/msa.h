@@ -11,7 +11,7 @@ namespace torali {
 template <typename TConfig, typename TSplitReadSet>
 inline int msa(TConfig const& c, TSplitReadSet const& sps, std::string& cs) {
   namespace dd = dellyhip_dropin;
-  cs.clear();
+  // (the reference never clears cs: consensus() appends with push_back, src/msa.h:170-172 -- so does this)
   const std::size_t n = sps.size();
   if (n == 0) return 0;
   if (n == 1) return 1;   // one row, coverage below max(2, ...) everywhere: empty consensus (src/msa.h:111-173)
@@ -24,7 +24,7 @@ inline int msa(TConfig const& c, TSplitReadSet const& sps, std::string& cs) {
   std::vector<char> out(2 * longest + 2048);
   int32_t len = 0, rows = 0;
   dd::check(dellyhip_msa(S.ctx, (int32_t)n, blob.data(), off.data(), out.data(), (int32_t)out.size(), &len, &rows));
-  cs.assign(out.data(), (std::size_t)len);
+  cs.append(out.data(), (std::size_t)len);
   return rows;
 }
 

@@ -125,6 +125,13 @@ void dellyhip_abi_info(int32_t out[4]);
 void dellyhip_default_params_sr(dellyhip_params* p);
 void dellyhip_default_params_lr(dellyhip_params* p);
 
+/* A second context on the same device that SHARES share_with's resident chromosomes (one ref-counted table: a
+ * dellyhip_set_chromosome through either context is seen by both; the chromosomes are freed with the last context).
+ * Own HIP stream, scratch area and work counters, so the two can run batches concurrently.  params NULL = the same
+ * parameters.  This is what the worker threads of the reference's ThreadPool (src/shortpe.h:80,175-201) use: one
+ * context per thread, ONE copy of the genome per GPU. */
+int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out);
+
 /* Keeps chromosome `chr` resident in HBM.  Replaces the per-chromosome
  * faidx_fetch_seq() buffer `seq` that src/shortpe.h:88 hands to
  * alignConsensus(c, hdr, seq, sndSeq, sv), and hdr->target_len[chr]
@@ -156,6 +163,39 @@ int dellyhip_align_consensus_batch(dellyhip_ctx* ctx, int32_t n_junctions,
                                    dellyhip_result* results, char* out_blob,
                                    uint64_t out_blob_cap, uint64_t* out_blob_len,
                                    int want_alignment);
+
+/* ---- pipelined host-buffer path ------------------------------------------
+ * The loop of src/shortpe.h:175-201 over MANY batches (one per chromosome, or chunks of a chromosome's junctions) with
+ * the host work, the PCIe copies and the kernels of consecutive batches overlapped.  A stream owns `depth` slots (each:
+ * a context of its own sharing the resident chromosomes, pinned staging for inputs and outputs, device buffers that
+ * are grown geometrically and reused -- no allocation per batch once warmed up).
+ *   submit : validates + routes the junctions, copies the inputs into pinned staging, enqueues ONE H2D copy, the
+ *            kernels, the device-side compaction and the D2H copies on the slot's HIP stream; returns without waiting.
+ *            with_msa as dellyhip_batch_upload (0 = consensus given, 1 = msa() first, 2 = the long-read loop body; the
+ *            modes whose routing needs the consensus lengths on the host -- 2, and 1 with insertions or long-read
+ *            parameters -- wait for the MSA stage inside submit).  DELLYHIP_E_ARG when every slot is in flight or held.
+ *   collect: waits for the OLDEST submitted batch and hands out pointers into its pinned output block: n records
+ *            (blob offsets relative to *blob) and the consensus / "REF,ALT" (/ alignment) bytes.  The pointers stay
+ *            valid until the NEXT collect (or dellyhip_stream_release) on this stream: the slot is not reused before that.
+ * Typical loop, depth 3:  submit(0); submit(1); for k: collect(k) -> consume; submit(k + 2).
+ * One stream per calling thread. */
+typedef struct dellyhip_stream dellyhip_stream;
+int dellyhip_stream_create(dellyhip_ctx* ctx, int32_t depth, int32_t with_msa, int32_t want_alignment, dellyhip_stream** out);
+void dellyhip_stream_destroy(dellyhip_stream* stream);
+int dellyhip_stream_submit(dellyhip_stream* stream, int32_t n_junctions, const dellyhip_junction* junctions,
+                           const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq, uint64_t tag);
+int dellyhip_stream_collect(dellyhip_stream* stream, const dellyhip_result** results, const char** blob,
+                            uint64_t* blob_len, int32_t* n_junctions, uint64_t* tag);
+/* Gives the output block of the last collect() back before the next collect() does (a caller that has copied what it
+ * needs; with depth 1 this is what allows the next submit). */
+void dellyhip_stream_release(dellyhip_stream* stream);
+/* Where the host time of this stream went since its creation (or the last reset), in seconds: out[0] validation +
+ * routing + staging copies, out[1] kernel launches, out[2] enqueueing compaction + downloads, out[3] waiting in collect;
+ * out[4] batches that needed the dense kernels for junctions the sparse kernel left (routed at collect time),
+ * out[5] batches whose blob download had to be topped up (the size estimate was short). */
+void dellyhip_stream_stats(dellyhip_stream* stream, double out[6], int32_t reset);
+/* batches submitted and not yet collected */
+int dellyhip_stream_pending(dellyhip_stream* stream);
 
 /* ---- device-resident batches (bench / pipelined callers) ---------------- */
 
