@@ -113,6 +113,7 @@ struct dellyhip_stream;
 struct dellyhip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;   // (the slots of a dellyhip_stream run on the stream object's two compute streams)
   dellyhip_params params{};
   int n_cu = 0;
   // chromosome table: the shared object and this context's snapshot of it (refresh_chr)
@@ -799,27 +800,32 @@ __global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list,
 // ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
 // off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
 __global__ void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
+  // one block of 1024 threads; round k handles records k * 1024 + t (independent loads), a block scan per round carries
+  // the running total (n = 10 000: ten rounds)
   __shared__ uint64_t part[1024];
+  __shared__ uint64_t carry;
   const int t = threadIdx.x;
-  const int per = (n + 1023) / 1024;
-  const int lo = min(n, t * per), hi = min(n, lo + per);
-  uint64_t sum = 0;
-  for (int i = lo; i < hi; ++i)
-    sum += (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
-  part[t] = sum;
+  if (t == 0) carry = 0;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
-    uint64_t v = (t >= d) ? part[t - d] : 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + t;
+    uint64_t len = 0;
+    if (i < n) len = (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
+    part[t] = len;
     __syncthreads();
-    part[t] += v;
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
+      const uint64_t v = (t >= d) ? part[t - d] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    const uint64_t c = carry;
+    if (i < n) off[i] = c + part[t] - len;
+    __syncthreads();
+    if (t == 1023) carry = c + part[1023];
     __syncthreads();
   }
-  uint64_t run = part[t] - sum;
-  for (int i = lo; i < hi; ++i) {
-    off[i] = run;
-    run += (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
-  }
-  if (t == 1023) off[n] = part[1023];
+  if (t == 0) off[n] = carry;
 }
 // one wavefront per junction: its three pieces, back to back, at out + off[i]
 __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n) {
@@ -894,6 +900,8 @@ struct UploadOpts {
   dellyhip_batch* recycle = nullptr;   // reuse this batch object and its device allocations
   Arena* arena = nullptr;              // stage the inputs (else: one allocation + synchronous copy per array)
   bool lazy = false;                   // stream slot: host routing of what split_sparse_kernel leaves behind is deferred
+  hipStream_t up = nullptr;            // the staged inputs travel on this stream (else the context's); up_done is recorded
+  hipEvent_t up_done = nullptr;        // behind the copy and the context's stream waits for it
 };
 
 // per-batch host state back to "freshly constructed", device allocations kept
@@ -1017,7 +1025,7 @@ void dellyhip_destroy(dellyhip_ctx* c) {
   c->scratch.release();
   c->counters.release();
   if (c->serial_ev) (void)hipEventDestroy(c->serial_ev);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -1316,7 +1324,12 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     }
   }
   if (arena && arena->used) {
-    e = hipMemcpyAsync(arena->d.p, arena->h.p, arena->used, hipMemcpyHostToDevice, c->stream);
+    hipStream_t up = (opts->up && opts->up_done) ? opts->up : c->stream;
+    e = hipMemcpyAsync(arena->d.p, arena->h.p, arena->used, hipMemcpyHostToDevice, up);
+    if (e == hipSuccess && up != c->stream) {
+      e = hipEventRecord(opts->up_done, up);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, opts->up_done, 0);
+    }
     if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "H2D staged inputs", e));
   }
   *out = b;
@@ -1350,7 +1363,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   HIPCHK(hipEventRecord(e3[0], s));
   // with_msa == 0: junction_setup treats res[j].status / sr_support as input from an MSA stage; without one they
   // must be zero on EVERY run, or a junction flagged in run 1 takes the "prior status" branch in run 2
-  if (!b->with_msa) HIPCHK(hipMemsetAsync(b->res.p, 0, (size_t)b->n * sizeof(dellyhip_result), s));
+  if (!b->with_msa && b->ever_run) HIPCHK(hipMemsetAsync(b->res.p, 0, (size_t)b->n * sizeof(dellyhip_result), s));   // (the upload zeroed them for the first run)
   if (b->with_msa == 2) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
     if (b->lm_items > 0) {
@@ -1822,7 +1835,7 @@ struct StreamSlot {
   Arena in;
   PinBuf<uint8_t> out;
   DevBuf<dellyhip_result> d_rec;
-  hipEvent_t done = nullptr;
+  hipEvent_t done = nullptr, up_done = nullptr, comp_done = nullptr;
   int state = 0;           // 0 free, 1 submitted, 2 collected (the caller still reads its output block)
   int32_t n = 0;
   uint64_t tag = 0;
@@ -1834,6 +1847,15 @@ struct dellyhip_stream {
   int with_msa = 0, want_alignment = 0;
   std::vector<StreamSlot> slots;
   uint64_t n_submit = 0, n_collect = 0;
+  // The copies run on two streams of their own, created with priorities other than the compute streams': the runtime keeps
+  // one pool of hardware queues per priority, so a copy never sits in the hardware queue of another slot's kernels (streams
+  // of one priority share at most GPU_MAX_HW_QUEUES = 4 queues; commands of one hardware queue execute in order, and a
+  // slot's 0.2 ms download in front of the next slot's kernels was measured to cost 40 % of the throughput).
+  hipStream_t s_up = nullptr, s_down = nullptr;
+  // ... and the slots' kernels on TWO compute streams, even and odd slots alternating: consecutive batches may overlap
+  // (the tail of one sparse kernel -- 2.4 wavefronts per slot at 10 000 junctions -- under the head of the next) without
+  // one stream per slot competing for the four hardware queues of the normal priority.
+  hipStream_t s_comp[2] = {nullptr, nullptr};
   int held = -1;                    // slot whose output the caller holds since the last collect()
   double blob_per_junction = 0;     // running estimate: bytes of compact blob per junction (sizes the first D2H copy)
   // host seconds since creation / the last dellyhip_stream_stats(reset): validation + routing + staging | kernel launches |
@@ -1858,16 +1880,22 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
     return rc;
   hipStream_t s = c->stream;
   StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
+  const bool split = st->s_down && S.comp_done && !all_blob;   // (the slow path stays on the slot's own stream)
   hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_records_kernel, dim3(std::min(n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p,
                      b->blob_off.p, b->blob_compact.p, S.d_rec.p, n);
   HIPCHK(hipGetLastError());
+  if (split) {
+    HIPCHK(hipEventRecord(S.comp_done, s));
+    s = st->s_down;
+    HIPCHK(hipStreamWaitEvent(s, S.comp_done, 0));
+  }
   HIPCHK(hipMemcpyAsync(&H->used, b->blob_off.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   if (c->counters.p) HIPCHK(hipMemcpyAsync(&H->sps_left, c->counters.p + 31, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p, (size_t)n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s));
   // the blob's size is only known on the device: copy what the previous batches predict (all of it after a slow path)
-  uint64_t want = all_blob ? S.blob_cap : (uint64_t)(st->blob_per_junction * 1.25 * n) + 4096;
+  uint64_t want = all_blob ? S.blob_cap : (uint64_t)(st->blob_per_junction * 1.06 * n) + 4096;
   want = std::min<uint64_t>(std::min<uint64_t>(want, S.blob_cap), (uint64_t)n * b->out_stride);
   if (all_blob) want = std::min<uint64_t>(want, H->used);   // (slow path: the header has been read already)
   S.blob_copied = want;
@@ -1918,11 +1946,30 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   st->with_msa = with_msa;
   st->want_alignment = want_alignment ? 1 : 0;
   st->slots = std::vector<StreamSlot>((size_t)depth);
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (least != greatest && !getenv("DELLYHIP_STREAM_ONE_QUEUE")) {   // (numerically lower = higher priority; normal = 0 lies between)
+      if (hipStreamCreateWithPriority(&st->s_up, hipStreamNonBlocking, greatest) != hipSuccess) st->s_up = nullptr;
+      if (hipStreamCreateWithPriority(&st->s_down, hipStreamNonBlocking, least) != hipSuccess) st->s_down = nullptr;
+    }
+  }
+  for (int q = 0; q < std::min(depth, 2); ++q)
+    if (hipStreamCreateWithFlags(&st->s_comp[q], hipStreamNonBlocking) != hipSuccess) st->s_comp[q] = nullptr;
+  int slot_index = 0;
   for (auto& S : st->slots) {
     int rc = dellyhip_create_shared(c, &c->params, &S.ctx);
+    if (!rc && st->s_comp[slot_index & 1]) {
+      (void)hipStreamDestroy(S.ctx->stream);
+      S.ctx->stream = st->s_comp[slot_index & 1];
+      S.ctx->owns_stream = false;
+    }
+    ++slot_index;
     if (!rc) {
       S.b = new dellyhip_batch();
       hipError_t e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S.up_done, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S.comp_done, hipEventDisableTiming);
       if (e != hipSuccess) rc = fail(DELLYHIP_E_RUNTIME, "hipEventCreate", e);
     }
     if (rc) {
@@ -1940,6 +1987,8 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
 
 void dellyhip_stream_destroy(dellyhip_stream* st) {
   if (!st) return;
+  if (st->s_up) (void)hipStreamSynchronize(st->s_up);
+  if (st->s_down) (void)hipStreamSynchronize(st->s_down);
   for (auto& S : st->slots) {
     if (S.ctx) {
       (void)hipSetDevice(S.ctx->device);
@@ -1947,10 +1996,16 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
     }
     if (S.b) dellyhip_batch_free(S.ctx, S.b);
     if (S.done) (void)hipEventDestroy(S.done);
+    if (S.up_done) (void)hipEventDestroy(S.up_done);
+    if (S.comp_done) (void)hipEventDestroy(S.comp_done);
     S.in.d.release();
     S.d_rec.release();
     if (S.ctx) dellyhip_destroy(S.ctx);
   }
+  if (st->s_up) (void)hipStreamDestroy(st->s_up);
+  if (st->s_down) (void)hipStreamDestroy(st->s_down);
+  for (auto& cs : st->s_comp)
+    if (cs) (void)hipStreamDestroy(cs);
   delete st;
 }
 
@@ -1965,6 +2020,8 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   o.recycle = S.b;
   o.arena = &S.in;
   o.lazy = true;
+  o.up = st->s_up;
+  o.up_done = S.up_done;
   dellyhip_batch* b = nullptr;
   const double t0 = now_s();
   int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, st->with_msa, st->want_alignment, &b, &o);

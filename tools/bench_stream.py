@@ -72,10 +72,11 @@ def main():
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--batches", type=int, default=100)
     ap.add_argument("--distinct", type=int, default=6)
-    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--mode", default="c2")
     ap.add_argument("--n-reads", type=int, default=0)
     ap.add_argument("--sub-rate", type=float, default=0.005)
+    ap.add_argument("--only-depth", type=int, default=0)
     args = ap.parse_args()
     lr = args.mode.startswith("lr")
     params = abi.params_lr(realign=True) if lr else abi.params_sr()
@@ -84,7 +85,7 @@ def main():
     ctx = refine.Context(params=params)
     ctx.set_chromosomes(chroms)
     out = {}
-    for depth in sorted(set([1, 2, args.depth])):
+    for depth in ([args.only_depth] if args.only_depth else sorted(set([1, 2, 3, args.depth]))):
         out["depth_%d" % depth] = stream_rate(ctx, batches, raw[0].with_msa, depth, args.batches)
     print(json.dumps(out))
     ctx.close()
