@@ -4,10 +4,15 @@
 
 A "step" is one pass of the hot path (alignConsensus: window construction,
 longNeedle, split detection, coordinates) over one resident batch of synthetic
-junctions (BASELINE config 2: 10 000 junctions per GPU).  Inputs
-are in HBM before the timed region; result records stay in HBM and, for N > 1,
-are gathered to every rank with one RCCL all_gather per step (junctions shard
-across ranks, no other exchange).
+junctions (BASELINE config 2: 10 000 junctions per GPU); the steps
+rotate through RESIDENT_BATCHES different batches.  Inputs are in HBM before the
+timed region and result records stay in HBM: that is `value` (the bench
+contract).  The quantity SURVEY.md 8d defines -- host buffers in, host buffers out,
+marshalling + H2D + kernels + D2H -- is measured in the same run through the
+pipelined path (dellyhip_stream) over >= 1 s of batches and reported beside it as
+`host_inclusive`.  For N > 1 junctions shard across ranks; the records and bytes
+of step k - 1 are gathered to rank 0 over RCCL AND copied to its host memory
+inside step k (`config.gather_ms_per_step`).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -41,6 +46,31 @@ SIDE_PLAN = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
              ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)),
              # INS 800 bp, 15 reads of ~3.8 kb at 6 % error: msaWfa + alignConsensus (splitAlign)
              ("lr_ins_msawfa_n15", 512, 64, dict(mode="lrins", n_reads=15, sub_rate=0.06)))
+
+
+RESIDENT_BATCHES = 4          # distinct resident batches the timed steps rotate through
+HOST_INCLUSIVE_SECONDS = 1.0  # wall time of the pipelined host-buffer measurement
+STREAM_DEPTH = 4
+
+# deficit sweep: the C2 shape under different consensus / genome content.  The sparse longNeedle's cost
+# grows with a junction's deficit (errors between consensus and reference); the reference's does not (src/needle.h:64-115
+# fills every cell).  (name, synth.make_batch kwargs); tests/test_gpu_bench_shapes.py bit-compares every one with oracle/_ref.
+SWEEP_PLAN = (("substitutions_0", dict(sub_rate=0.0)),
+              ("substitutions_0.5pct_baseline", dict()),
+              ("substitutions_2pct", dict(sub_rate=0.02)),
+              ("substitutions_5pct", dict(sub_rate=0.05)),
+              ("indel_1to3bp_per_consensus", dict(read_indel=1.0)),
+              ("nontemplated_insertion_12bp", dict(junction_ins=12)),
+              ("real_chr18_windows", dict(genome="real")),
+              ("low_complexity_mix", dict(genome="lowcx")))
+SWEEP_N = 10000
+
+
+def sweep_batch(synth, kw, n=SWEEP_N):
+    kw = dict(kw)
+    if kw.get("genome"):
+        kw["real"] = synth.load_real_chromosome()
+    return synth.make_batch(n, mode="c2", seed=77, **kw)
 
 
 class _DevPtr:
@@ -80,7 +110,7 @@ def cpu_baseline(batch, budget_s=12.0):
 
 def _profile_file(name):
     """newest committed copy of a profile artefact (profiles/rNN/<name>)"""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             return path
@@ -98,27 +128,13 @@ def _measured_traffic():
         return None
 
 
-# VALU issue ceiling of one SIMD for the op mix of the DP kernels (v_pk_*_i16, v_max, DPP moves, v_bfi ...), measured with
-# tools/valu_rate.hip at 4-8 resident wavefronts per SIMD, >= 50 ms kernels: profiles/r02/valu_rate.txt (0.51-0.55 G
-# wave-instructions/s; plain v_add / v_and reach 0.73 G).  Nominal figure of MI355X_MICROARCH.md: a wave64 VALU
-# instruction issues over 2 cycles = 1.2 G/s per SIMD at 2.4 GHz (157.3 TFLOP/s fp32).
-VALU_PEAK_MEASURED_PER_SIMD = 0.55e9
-VALU_PEAK_NOMINAL_PER_SIMD = 1.2e9
-N_SIMD = 1024
-
-
-def _valu_instructions(kernel_prefix, n_junctions):
-    """VALU wave-instructions per launch of the dominant kernel from the committed SQ counter pass
-    (profiles/rNN/pmc_sq_summary.txt, SQ_INSTS_VALU, collected at 10 000 C2 junctions), scaled to this launch"""
-    try:
-        for line in open(_profile_file("pmc_sq_summary.txt")):
-            if kernel_prefix in line and "SQ_INSTS_VALU" in line:
-                import ast
-                d = ast.literal_eval(line[line.index("{"):])
-                return d["SQ_INSTS_VALU"] * (n_junctions / 10000.0)
-    except Exception:
-        pass
-    return None
+# VALU issue ceiling (profiles/r03/valu_clock.txt, tools/valu_clock.hip: the shader clock is MEASURED there -- s_memtime
+# against the 100 MHz s_memrealtime: 2.35 GHz under load, rocm-smi agrees): a SIMD issues a wave64 integer VALU instruction
+# every ~2 cycles (v_add_u32 1.5, v_fma_f32 1.9, v_max_i32 / v_pk_add_i16 2.5) once >= 8 wavefronts are resident, as
+# MI355X_MICROARCH.md says; ONE wavefront alone issues one every 5.8 cycles, so a kernel with W resident wavefronts per
+# SIMD cannot exceed min(W / 5.8, ~0.5) instructions per cycle.  Round 2's "0.55 G/s measured ceiling" was a 2-4-wave figure.
+VALU_CEILING = {"cycles_per_wave64_valu_at_8_waves_per_simd": 2.0, "cycles_per_instruction_one_wave": 5.8, "sclk_mhz_measured": 2350,
+                "source": "profiles/r03/valu_clock.txt (tools/valu_clock.hip)"}
 
 
 def _subbatch(batch, n):
@@ -128,6 +144,131 @@ def _subbatch(batch, n):
     last = int(batch.junctions["seq_first"][n - 1] + batch.junctions["n_seq"][n - 1])
     return synth.Batch(batch.chroms, batch.junctions[:n].copy(), batch.seq_blob, batch.seq_off[:last + 1].copy(),
                        batch.with_msa, batch.truth[:n])
+
+
+def one_genome(synth, batches):
+    """independently generated batches -> one chromosome table (concatenated), coordinates shifted"""
+    import numpy as np
+    chroms = [np.concatenate([b.chroms[c] for b in batches]) for c in range(len(batches[0].chroms))]
+    out, base = [], [0] * len(chroms)
+    for b in batches:
+        j = b.junctions.copy()
+        j["sv_start"] += base[0]
+        j["sv_end"] += np.where(j["chr2"] == 0, base[0], base[-1])
+        out.append(synth.Batch(chroms, j, b.seq_blob, b.seq_off, b.with_msa, b.truth))
+        base = [x + c.size for x, c in zip(base, b.chroms)]
+    return chroms, out
+
+
+def host_inclusive_rate(ctx, batches, with_msa, seconds=HOST_INCLUSIVE_SECONDS, depth=STREAM_DEPTH, min_batches=3):
+    """host buffers in, host buffers out.  The batches (host arrays) cycle through a dellyhip_stream with `depth`
+    slots -- depth - 1 in flight while the consumer still holds the block of the last collect -- for >= `seconds` of wall
+    time; the clock covers validation, routing, staging copies, H2D, kernels, device-side compaction, D2H and the waits."""
+    import numpy as np
+    from delly_amd import abi, refine
+    st = refine.Stream(ctx, depth=depth, with_msa=with_msa)
+    args = []
+    for b in batches:
+        junc = np.ascontiguousarray(b.junctions)
+        blob = np.ascontiguousarray(b.seq_blob, dtype=np.uint8)
+        off = np.ascontiguousarray(b.seq_off, dtype=np.uint64)
+        args.append((junc.shape[0], junc.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_char_p),
+                     off.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1), (junc, blob, off)))
+    state = {"nxt": 0, "k": 0}
+
+    def pump(until_batches=None, until_time=None):
+        nj = nb = 0
+        inflight = max(1, depth - 1)
+        while True:
+            if until_batches is not None and state["k"] >= until_batches:
+                break
+            if until_time is not None and time.perf_counter() >= until_time and state["k"] >= min_batches:
+                break
+            if depth == 1:
+                st.release()
+            while state["nxt"] - state["k"] < inflight:
+                a = args[state["nxt"] % len(args)]
+                st.submit_raw(a[0], a[1], a[2], a[3], a[4], state["nxt"])
+                state["nxt"] += 1
+            n, ln = st.collect_raw()
+            state["k"] += 1
+            nj += n
+            nb += ln
+        return nj, nb
+
+    pump(until_batches=max(depth + 1, len(args)))          # warm-up: the buffers grow to the batch size
+    while st.pending():                                    # drain, so that the timed region starts and ends idle
+        st.collect_raw()
+        state["k"] += 1
+    state["nxt"] = state["k"] = 0
+    st.stats(reset=True)
+    t0 = time.perf_counter()
+    nj, nb = pump(until_time=t0 + seconds)
+    while st.pending():
+        n, ln = st.collect_raw()
+        state["k"] += 1
+        nj += n
+        nb += ln
+    dt = time.perf_counter() - t0
+    total = state["k"]
+    stats = st.stats()
+    st.close()
+    up = sum(a[5][0].nbytes + a[5][1].nbytes + a[5][2].nbytes for a in args) / len(args)
+    return {"value": nj / dt, "unit": "junctions/s", "batches": total, "junctions_per_batch": nj / max(total, 1), "wall_s": dt,
+            "ms_per_batch": dt / max(total, 1) * 1e3, "depth": depth,
+            "host_ms_per_batch": {k: (v / max(total, 1) * 1e3 if k.endswith("_s") else v) for k, v in stats.items()},
+            "bytes_up_per_batch": int(up), "bytes_down_per_batch": int(nb / max(total, 1) + nj / max(total, 1) * abi.result_dtype().itemsize),
+            "note": "dellyhip_stream: host buffers in -> host buffers out (validation, routing, pinned staging, H2D, kernels, compaction, D2H); chromosome resident"}
+
+
+def deficit_sweep(ctx, synth, device, with_cpu, steps=5):
+    """SWEEP_PLAN: the headline shape under other consensus / genome content.  Per point: resident alignments/s, how many
+    junctions the sparse kernel resolved per level bucket (deficit = |consensus| - bestScore of the resolved junctions), how
+    many it left to the dense kernels, and the reference's CPU rate on a 1000-junction prefix (which should not move)."""
+    import numpy as np
+    out = {}
+    orc = None
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle
+        orc = pyoracle.Oracle("reference" if pyoracle.have_reference() else "port")
+    cores = os.cpu_count() or 1
+    for name, kw in SWEEP_PLAN:
+        b = sweep_batch(synth, kw)
+        ctx.set_chromosomes(b.chroms)
+        rb = ctx.upload(b)
+        rb.run(); rb.sync(); rb.kernel_ms()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rb.run()
+        rb.sync()
+        dt = (time.perf_counter() - t0) / steps
+        ms_split, _, _ = rb.kernel_ms()
+        ms_dp = rb.dp_kernel_ms()
+        left = rb.sparse_left()
+        res, _ = rb.fetch()
+        ran = (res["status"] == 0) & (res["score_best"] != -1)
+        deficit = (res["cons_len"] - res["score_best"])[ran]
+        edges = [0, 2, 4, 6, 8, 16, 32]
+        hist = {}
+        lo = -1
+        for e in edges:
+            hist["<=%d" % e] = int(((deficit > lo) & (deficit <= e)).sum())
+            lo = e
+        hist[">32"] = int((deficit > 32).sum())
+        out[name] = {"junctions": b.n, "alignments_per_s": b.n / dt, "ms_per_step": dt * 1e3, "sparse_kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
+                     "refined_ok": int(res["ok"].sum()), "left_to_dense_kernels": int(left), "left_to_dense_frac": left / max(b.n, 1),
+                     "deficit_histogram": hist, "make_batch": {k: v for k, v in kw.items()}}
+        rb.free()
+        if orc is not None:
+            sub = _subbatch(b, 1000)
+            threads = max(1, min(cores, sub.n // 8))
+            sec, visits, _ = orc.time_refine(sub, n_threads=threads, reps=1)
+            reps = int(max(1, min(20, 1.0 / max(sec, 1e-3))))
+            if reps > 1:
+                sec, visits, _ = orc.time_refine(sub, n_threads=threads, reps=reps)
+            out[name]["cpu_" + orc.kind] = {"alignments_per_s": visits / sec, "cores": threads, "sample": "%d x %d junctions, %.2f s" % (reps, sub.n, sec)}
+    return out
 
 
 def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
@@ -146,28 +287,6 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     out = {}
     want = (lambda name: True) if not only else (lambda name: name in only)
     plan = tuple(x for x in SIDE_PLAN if want(x[0]))
-    # SURVEY.md 8d "GPU time includes H2D/D2H and host marshalling": the same 10 000 C2 junctions through the host-buffer
-    # entry point dellyhip_align_consensus_batch -- upload of records + consensus bytes, host binning, kernels,
-    # device-side compaction, download of records + consensus / allele bytes (chromosome resident).  Never `value`.
-    try:
-        if not want("u_c2_host_inclusive"):
-            raise KeyError("skipped")
-        bb = synth.make_batch(10000, mode="c2")
-        ctx.set_chromosomes(bb.chroms)
-        ctx.refine(bb)
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            res, blob = ctx.refine(bb)
-        dt = (time.perf_counter() - t0) / reps
-        out["u_c2_host_inclusive"] = {"junctions": bb.n, "junctions_per_s": bb.n / dt, "ms_per_call": dt * 1e3,
-                                      "refined_ok": int(res["ok"].sum()), "bytes_up": int(bb.seq_blob.size + bb.junctions.nbytes + bb.seq_off.nbytes),
-                                      "bytes_down": int(res.nbytes + blob.size),
-                                      "note": "dellyhip_align_consensus_batch from host buffers: H2D + binning + kernels + compaction + D2H"}
-    except KeyError:
-        pass
-    except Exception as e:  # side figure only
-        out["u_c2_host_inclusive"] = {"error": repr(e)}
     # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
     # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
     try:
@@ -223,6 +342,12 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
                      "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
         rb.free()
+        try:   # the same batch from host buffers through the pipelined path
+            hi = host_inclusive_rate(ctx, [b], b.with_msa, seconds=0.5 if dt < 0.05 else 3 * dt, depth=3)
+            out[name]["host_inclusive"] = {k: hi[k] for k in ("value", "unit", "batches", "wall_s", "ms_per_batch", "depth", "bytes_up_per_batch", "bytes_down_per_batch")}
+            out[name]["host_inclusive"]["vs_resident"] = hi["value"] / (n / dt)
+        except Exception as e:
+            out[name]["host_inclusive"] = {"error": repr(e)}
         if orc is not None and ncpu > 0:
             sub = b if ncpu >= n else synth.make_batch(ncpu, **kw)
             threads = max(1, min(cores, sub.n))
@@ -335,6 +460,7 @@ def main():
     ap.add_argument("--junctions", type=int, default=10000, help="junctions per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pipelined host-buffer measurement")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
     ap.add_argument("--force-comm", action="store_true",
                     help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
@@ -361,57 +487,60 @@ def main():
     if world > 1:
         dist.barrier()
 
+    import numpy as np
     n = args.junctions
-    batch = synth.make_batch(n, mode="c2", first=rank * n)  # weak scaling: shard by junction index
+    multi = world > 1 or args.force_comm
+    n_res = 2 if multi else RESIDENT_BATCHES
+    # weak scaling: rank r owns the junctions [(k * world + r) * n, +n) of the synthetic stream, k = 0 .. n_res - 1
+    raw = [synth.make_batch(n, mode="c2", first=(k * world + rank) * n) for k in range(n_res)]
+    chroms, batches = one_genome(synth, raw)
+    batch = batches[0]
     ctx = refine.Context(device=local)
+    ctx.set_chromosomes(chroms)
     side = torch.cuda.Stream(device=local)  # the kernels are launched on this stream
     stream = side.cuda_stream
+    rbs = [ctx.upload(b) for b in batches]
     comm = None
-    gather_kind = "none (one GPU: results stay in HBM)"
-    rbs = []
-    multi = world > 1 or args.force_comm
-    if not multi:
-        ctx.set_chromosomes(batch.chroms)
-        rbs.append(ctx.upload(batch))
-    else:
-        # N > 1: every rank keeps TWO resident batches of n junctions and alternates; the results of the batch refined in
-        # the previous step are gathered to rank 0's HBM -- dellyhip_gather_results_device in the host library: RCCL called
-        # directly (ncclAllGather of the counts, grouped ncclSend / ncclRecv of the records + consensus / allele bytes,
-        # SURVEY.md 8e) -- while the kernels of the current step run on their own stream.  One run + one gather per step.
-        # The 128-byte RCCL id travels through torch.distributed.
-        b2 = synth.make_batch(n, mode="c2", first=(world + rank) * n)
-        chrom = __import__("numpy").concatenate([batch.chroms[0], b2.chroms[0]])
-        j2 = b2.junctions.copy()
-        j2["sv_start"] += batch.chroms[0].size
-        j2["sv_end"] += batch.chroms[0].size
-        b2 = synth.Batch([chrom], j2, b2.seq_blob, b2.seq_off, b2.with_msa, b2.truth)
-        ctx.set_chromosomes([chrom])
-        rbs = [ctx.upload(batch), ctx.upload(b2)]
+    gather_kind = "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"
+    pinned = None
+    if multi:
+        # N > 1: every rank alternates between TWO resident batches; the results of the batch refined in the previous step
+        # are gathered to rank 0 -- dellyhip_gather_results in the host library: RCCL called directly (ncclAllGather of
+        # the counts, grouped ncclSend / ncclRecv of the records + consensus / allele bytes) -- AND copied
+        # into rank 0's pinned host memory (VCF emission needs them there) while the kernels of the current step run on
+        # their own stream.  One run + one gather per step.  The 128-byte RCCL id travels through torch.distributed.
         ids = [refine.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         comm = refine.Comm(ctx, rank, world, ids[0])
-        gather_kind = ("dellyhip_gather_results_device: RCCL ncclSend/ncclRecv of records + consensus/allele bytes to rank 0, "
-                       "gather of step k-1 overlapping the kernels of step k")
-    rb = rbs[0]
+        gather_kind = ("dellyhip_gather_results: RCCL ncclSend/ncclRecv of records + consensus/allele bytes to rank 0's HBM, then D2H into "
+                       "its pinned host memory, all inside the step; gather of step k-1 overlaps the kernels of step k")
+        if rank == 0:
+            cap_n = world * n + 64
+            cap_b = world * n * 1400 + (1 << 20)
+            pinned = (torch.empty(cap_n * abi.result_dtype().itemsize, dtype=torch.uint8).pin_memory(),
+                      torch.empty(cap_b, dtype=torch.uint8).pin_memory())
     gathered_n = [0, 0]
+    gather_s = [0.0]
     k_step = [0]
 
     def step():
         cur = rbs[k_step[0] % len(rbs)]
         with torch.cuda.stream(side):
             cur.run(stream)
-        if comm is not None:
+        if comm is not None and k_step[0] > 0:
             prev = rbs[(k_step[0] + 1) % 2]
-            if k_step[0] > 0:
-                gathered_n[0], gathered_n[1] = prev.gather_device(comm, 0)   # (waits for prev's kernels, not for cur's)
+            tg = time.perf_counter()
+            gathered_n[0], gathered_n[1] = prev.gather_into(comm, 0, pinned)   # (waits for prev's kernels, not for cur's)
+            gather_s[0] += time.perf_counter() - tg
         k_step[0] += 1
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1 if multi else 0)):
         step()
     torch.cuda.synchronize()
     for x in rbs:
         x.kernel_ms()  # reset the kernel timers
+    gather_s[0] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -423,10 +552,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms_split, ms_msa, launches = rb.kernel_ms()
-    ms_dp = rb.dp_kernel_ms()
-    for other in rbs[1:]:
-        other.sync()
+    kms = [x.kernel_ms() for x in rbs]          # (sync + averages over each batch's launches)
+    dps = [x.dp_kernel_ms() for x in rbs]
+    used = [i for i, k in enumerate(kms) if k[2] > 0]
+    launches = sum(kms[i][2] for i in used)
+    ms_split = sum(kms[i][0] * kms[i][2] for i in used) / max(launches, 1)
+    ms_dp = sum(dps[i] * kms[i][2] for i in used) / max(launches, 1)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
     per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
@@ -436,26 +567,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # sanity: the timed work is the real work (every junction refined, parity spot check vs oracle in smoke())
-    res, _ = rb.fetch()
-    n_ok = int(res["ok"].sum())
+    # sanity: the timed work is the real work (every junction refined; tests/test_gpu_bench_shapes.py compares exactly these
+    # batches with oracle/_ref)
+    n_ok = [int(x.fetch()[0]["ok"].sum()) for x in rbs]
+
+    # the same junctions from host buffers to host buffers through the pipelined path (every rank its own share)
+    hi = None
+    try:
+        if not args.no_host_inclusive:
+            for x in rbs:
+                x.free()
+            rbs = []
+            hi = host_inclusive_rate(ctx, batches, 0)
+            if world > 1:
+                hv = torch.tensor([hi["value"], hi["wall_s"]], dtype=torch.float64, device="cuda:%d" % local)
+                allh = [torch.zeros_like(hv) for _ in range(world)]
+                dist.all_gather(allh, hv)
+                hi["per_rank_junctions_per_s"] = [float(x[0].item()) for x in allh]
+                hi["value"] = float(sum(x[0].item() for x in allh))   # independent shards, no exchange in this leg
+                hi["note"] += "; N > 1: sum over ranks, every rank streams its own shard (results stay on each rank's host)"
+    except Exception as e:  # the contract line must still come out
+        hi = {"error": repr(e)}
 
     if rank == 0:
         total_units = world * n * args.steps
         value = total_units / dt
         ach = n * ALG_BYTES_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0
         traffic = _measured_traffic()
-        valu_n = _valu_instructions("split_sparse_kernel", n)
-        valu = None
-        if valu_n and ms_dp > 0:
-            rate = valu_n / (ms_dp * 1e-3)
-            valu = {"wave_instructions_per_launch": valu_n, "achieved_G_per_s": rate / 1e9,
-                    "peak_measured_G_per_s": VALU_PEAK_MEASURED_PER_SIMD * N_SIMD / 1e9,
-                    "frac_of_measured_peak": rate / (VALU_PEAK_MEASURED_PER_SIMD * N_SIMD),
-                    "peak_nominal_G_per_s": VALU_PEAK_NOMINAL_PER_SIMD * N_SIMD / 1e9,
-                    "frac_of_nominal_peak": rate / (VALU_PEAK_NOMINAL_PER_SIMD * N_SIMD),
-                    "source": "SQ_INSTS_VALU of profiles/*/pmc_sq_summary.txt / live kernel time; peaks: profiles/r02/valu_rate.txt "
-                              "(tools/valu_rate.hip) and MI355X_MICROARCH.md (wave64 VALU over 2 cycles)"}
         out = {
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,
@@ -469,31 +607,36 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU, 150 bp consensus x 1 kb "
-                                   "ref window, alignConsensus (longNeedle + split detection), bit-exact" % n,
-                       "junctions_per_gpu": n, "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
+            "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU and step, 150 bp consensus x 1 kb "
+                                   "ref window, alignConsensus (longNeedle + split detection), bit-exact; steps rotate through %d "
+                                   "different resident batches" % (n, len(batches)),
+                       "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
+                       "value_is": "inputs resident in HBM, results left in HBM (bench contract); host_inclusive = SURVEY.md 8d's definition",
                        "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if comm is not None else None),
+                       "gather_ms_per_step": (gather_s[0] / max(args.steps, 1) * 1e3 if comm is not None else None),
                        "ms_per_step_per_rank": per_rank_ms, "kernels_ms_per_step_rank0": ms_split},
+            "host_inclusive": hi,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "split_sparse_kernel (sparse longNeedle: furthest-reaching tables per deficit level, one junction per wavefront, alignment + split detection fused)",
-                         "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split,
+                         "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split, "kernel_launches_timed": launches,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
-                         "gcups_dense_equivalent": n * CELLS_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0,
-                         "valu": valu, "valu_frac": valu["frac_of_measured_peak"] if valu else None,
-                         "note": "path is integer-VALU bound with DP state on chip; HBM fraction is reported because "
-                                 "BASELINE asks for it (SURVEY.md 8d)"},
+                         "binding_roof": "integer VALU issue / latency, DP state on chip (SURVEY.md 8d); the HBM fraction is reported because BASELINE asks for it",
+                         "valu_ceiling": VALU_CEILING,
+                         "note": "the kernel's cost depends on the junctions' deficits (extras.deficit_sweep); cells of the dense matrices are not computed, so no GCUPS figure"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras:
-            rb.free()
-            rb = None
-            rbs = []
-            out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline,
-                                                only=set(filter(None, args.only_extras.split(','))) or None)
+            only = set(filter(None, args.only_extras.split(','))) or None
+            out["extras"] = side_measurements(ctx, synth, device=local, with_cpu=not args.no_cpu_baseline, only=only)
+            if only is None or "deficit_sweep" in only:
+                try:
+                    out["extras"]["deficit_sweep"] = deficit_sweep(refine.Context(device=local), synth, local, with_cpu=not args.no_cpu_baseline)
+                except Exception as e:  # side figure only
+                    out["extras"]["deficit_sweep"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     for x in rbs:
         x.free()

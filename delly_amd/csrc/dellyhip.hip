@@ -1542,6 +1542,16 @@ int dellyhip_batch_device_results(dellyhip_ctx* c, dellyhip_batch* b, void** dpt
   return 0;
 }
 
+int dellyhip_batch_sparse_left(dellyhip_ctx* c, dellyhip_batch* b, int32_t* left) {
+  if (!c || !b || !left) return fail(DELLYHIP_E_ARG, "null argument");
+  *left = 0;
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc || !c->counters.p || !b->ever_run) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(left, c->counters.p + 31, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_dp) {
   if (!b || !ms_dp) return fail(DELLYHIP_E_ARG, "null argument");
   (void)c;

@@ -23,6 +23,8 @@
 // clean letters (A, C, G, T, N, upper case: then reverseComplement is an involution and mat[m][n] == rev[m][n] always);
 // other inputs, and junctions not resolved at the deficit budget the workspace allows, take the dense strip passes.
 #pragma once
+#include <type_traits>
+
 #include "split_kernel.hpp"
 
 namespace dh {
@@ -69,6 +71,34 @@ __device__ __forceinline__ int sp_ld16(const int16_t* p) {
 __device__ __forceinline__ int sp_ld32(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+__device__ __forceinline__ int sp_ld8(const uint8_t* p) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+  const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t*>(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (int)((v >> (8 * (u & 3))) & 0xffu);
+}
+
+// Where the furthest-reaching tables are read from.  Everything below the level loops -- deep lists, first-column tables,
+// refRight, the tracebacks -- goes through get(level, diagonal index q = k + m); "no cell" is any negative value.
+//   FrGlobal16: the strip (long-read) kernel's int16 tables in the wavefront's HBM workspace.
+//   FrTile8   : the short-read kernel.  Its LDS tile holds the two newest levels (byte rows, row + 1, 0 = none); a level is
+//               written to the HBM workspace -- as bytes -- only when the level two above it overwrites it in the tile
+//               (sps_level_block), so a junction resolved at S levels has written S - 1 of its S + 1 levels, none at S = 0,
+//               and the reads of the newest levels (most of them) cost LDS latency instead of an HBM round trip.
+struct FrGlobal16 {
+  const int16_t* base;
+  int ndp;
+  __device__ __forceinline__ int get(int d, int q) const { return sp_ld16(base + (size_t)d * ndp + q); }
+};
+struct FrTile8 {
+  const uint8_t* base;     // [level][ndp] bytes, levels 0 .. S - 2
+  int ndp;
+  const uint8_t* row[2];   // LDS rows of the even / odd newest level, indexed by q
+  int S;                   // newest level computed
+  __device__ __forceinline__ int get(int d, int q) const {
+    return (d >= S - 1) ? (int)row[d & 1][q] - 1 : sp_ld8(base + (size_t)d * ndp + q) - 1;
+  }
+};
 
 __device__ __forceinline__ uint64_t sp_load8(const uint8_t* p) {
   uint64_t v;
@@ -320,8 +350,9 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
     const uint8_t* p2F = curF;
     const uint8_t* p1R = T.row[1][(d + 1) & 1] + OFF;
     const uint8_t* p2R = curR;
-    int16_t* gF = FRf + (size_t)d * ndp;
-    int16_t* gR = FRr + (size_t)d * ndp;
+    // level d - 2 leaves the tile now (level d is written over it): its entries go to the workspace as bytes
+    uint8_t* gF = reinterpret_cast<uint8_t*>(FRf) + (size_t)max(d - 2, 0) * ndp;
+    uint8_t* gR = reinterpret_cast<uint8_t*>(FRr) + (size_t)max(d - 2, 0) * ndp;
     const int seed = (d == 0) ? 0 : -1;        // level 0: row 0 of every diagonal k >= 0
     int rf = -1, rr = -1;
     for (int q0 = 0; q0 < ND; q0 += 2 * WAVE) {
@@ -336,6 +367,10 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
         const int first = (k < 0 && -2 * k <= d) ? -k : ((k >= 0) ? seed : -1);
         bf[u] = br[u] = first;
         if (d > 0) {     // (level 0 has no predecessors: row 0 of the diagonals k >= 0)
+          if (d >= 2 && q0 + u * WAVE + lane < ND) {
+            gF[q] = p2F[q];
+            gR[q] = p2R[q];
+          }
           {
             const int e1 = p1F[q], e1l = p1F[q - 1], e2 = p2F[q], e2r = p2F[q + 1];
             int b = max(e1 - 1, first);
@@ -411,8 +446,6 @@ __device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t
         if (q < ND) {
           curF[q] = (uint8_t)(bf[u] + 1);
           curR[q] = (uint8_t)(br[u] + 1);
-          gF[q] = (int16_t)bf[u];
-          gR[q] = (int16_t)br[u];
           rf = max(rf, bf[u]);
           rr = max(rr, br[u]);
         }
@@ -460,11 +493,12 @@ __device__ __forceinline__ void sp_offer_chunk(int32_t* row, int rlo, int rhi, i
 }
 // Diagonals below the main one start at (row -k, column 0), a cell of deficit 2 |k|: at level d only the d / 2 diagonals
 // next to the main one hold cells.  Each offers its rows with the whole wavefront.
-__device__ __forceinline__ void sp_offer_negative(const int16_t* lv, int32_t* row, int m, int d, int rlo, int rhi, int lane) {
+template <typename FRV>
+__device__ __forceinline__ void sp_offer_negative(const FRV& FR, int32_t* row, int m, int d, int rlo, int rhi, int lane) {
   const int nneg = min(d / 2, m);
   for (int i0 = 0; i0 < nneg; i0 += WAVE) {
     const int i = i0 + lane;
-    const int v = (i < nneg) ? sp_ld16(lv + (m - 1 - i)) : SP_NEG;
+    const int v = (i < nneg) ? FR.get(d, m - 1 - i) : SP_NEG;
     const int cnt = min(WAVE, nneg - i0);
     for (int t = 0; t < cnt; ++t) {
       const int vt = __shfl(v, t), kt = -(i0 + t + 1);
@@ -475,7 +509,8 @@ __device__ __forceinline__ void sp_offer_negative(const int16_t* lv, int32_t* ro
 }
 
 // cT[d][r] = min over diagonals k with FR[d][k] >= r (and r on the diagonal) of r + k, for rows rlo .. rhi, levels 0 .. S
-__device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
+template <typename FRV>
+__device__ __noinline__ void sp_first_columns(const FRV& FR, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
   const int ND = n + m + 1;
   const int rows = rhi - rlo + 1;
   for (int d = 0; d <= S; ++d)
@@ -489,13 +524,13 @@ __device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m,
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       pm[u] = (d0 + u <= S) ? rlo - 1 : rhi;
-      if (d0 + u <= S) sp_offer_negative(FR + (size_t)(d0 + u) * ndp, cT + (size_t)(d0 + u) * (m + 1), m, d0 + u, rlo, rhi, lane);
+      if (d0 + u <= S) sp_offer_negative(FR, cT + (size_t)(d0 + u) * (m + 1), m, d0 + u, rlo, rhi, lane);
     }
     for (int q0 = m; q0 < ND && (pm[0] < rhi || pm[1] < rhi || pm[2] < rhi || pm[3] < rhi); q0 += WAVE) {
       const int q = q0 + lane;
       int v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (q < ND && pm[u] < rhi) ? sp_ld16(FR + (size_t)min(d0 + u, S) * ndp + q) : SP_NEG;
+      for (int u = 0; u < 4; ++u) v[u] = (q < ND && pm[u] < rhi) ? FR.get(min(d0 + u, S), q) : SP_NEG;
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (pm[u] < rhi) sp_offer_chunk(cT + (size_t)(d0 + u) * (m + 1), rlo, rhi, q - m, v[u], pm[u], lane);
@@ -507,13 +542,13 @@ __device__ __noinline__ void sp_first_columns(const int16_t* FR, int ndp, int m,
 
 // the diagonals that reach row rlo at level S (FR is non-decreasing in the level: no other diagonal can reach it at a lower
 // one), compacted into list[]; returns their number or -1 when the list overflows
-__device__ __noinline__ int sp_deep_list(const int16_t* FR, int ndp, int m, int n, int S, int rlo, int32_t* list, int cap, int lane) {
+template <typename FRV>
+__device__ __noinline__ int sp_deep_list(const FRV& FR, int m, int n, int S, int rlo, int32_t* list, int cap, int lane) {
   const int ND = n + m + 1;
-  const int16_t* lv = FR + (size_t)S * ndp;
   int cnt = 0;
   for (int q0 = 0; q0 < ND; q0 += WAVE) {
     const int q = q0 + lane;
-    const bool hit = (q < ND) && (sp_ld16(lv + min(q, ND - 1)) >= rlo);
+    const bool hit = (q < ND) && (FR.get(S, min(q, ND - 1)) >= rlo);
     const unsigned long long bm = __ballot(hit);
     if (bm) {
       const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -550,7 +585,8 @@ __device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo,
 }
 
 // sp_first_columns restricted to the listed diagonals (ascending)
-__device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, int m, int S, int rlo, int rhi, const int32_t* list,
+template <typename FRV>
+__device__ __noinline__ void sp_first_columns_list(const FRV& FR, int m, int S, int rlo, int rhi, const int32_t* list,
                                                    int cnt, int32_t* cT, int lane) {
   const int rows = rhi - rlo + 1;
   for (int d = 0; d <= S; ++d)
@@ -563,7 +599,7 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
     for (int d0 = 0; d0 <= S; d0 += 4) {
       int v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = (use && d0 + u <= S) ? sp_ld16(FR + (size_t)(d0 + u) * ndp + q) : SP_NEG;
+      for (int u = 0; u < 4; ++u) v[u] = (use && d0 + u <= S) ? FR.get(d0 + u, q) : SP_NEG;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (d0 + u <= S) {
@@ -578,12 +614,12 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
       for (int i0 = 0; i0 < cnt && pm < rhi; i0 += WAVE) {
         const int i = i0 + lane;
         const int q = (i < cnt) ? sp_ld32(list + i) : -1;
-        const int v = (q >= m) ? sp_ld16(FR + (size_t)d * ndp + q) : SP_NEG;
+        const int v = (q >= m) ? FR.get(d, q) : SP_NEG;
         sp_offer_chunk(cT + (size_t)d * (m + 1), rlo, rhi, q - m, v, pm, lane);
       }
     }
   }
-  for (int d = 2; d <= S; ++d) sp_offer_negative(FR + (size_t)d * ndp, cT + (size_t)d * (m + 1), m, d, rlo, rhi, lane);
+  for (int d = 2; d <= S; ++d) sp_offer_negative(FR, cT + (size_t)d * (m + 1), m, d, rlo, rhi, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
@@ -591,7 +627,8 @@ __device__ __noinline__ void sp_first_columns_list(const int16_t* FR, int ndp, i
 // Both first-column tables of the short-read kernel in one go when each deep list fits one chunk (the usual case): the
 // stores that clear the tables and write the lists are waited for ONCE, the list entries and the table values of four
 // levels of BOTH matrices are in flight together -- two memory round trips instead of six.
-__device__ __noinline__ void sp_first_columns_both(const int16_t* FRf, const int16_t* FRr, int ndp, int m, int S, int rloF, int rhiF,
+template <typename FRV>
+__device__ __noinline__ void sp_first_columns_both(const FRV& FRf, const FRV& FRr, int m, int S, int rloF, int rhiF,
                                                    const int32_t* listF, int cntF, int32_t* cF, int rloR, int rhiR,
                                                    const int32_t* listR, int cntR, int32_t* cR, int lane) {
   const int rows = rhiF - rloF + 1;   // (= rhiR - rloR + 1)
@@ -609,8 +646,8 @@ __device__ __noinline__ void sp_first_columns_both(const int16_t* FRf, const int
     int vF[4], vR[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      vF[u] = (useF && d0 + u <= S) ? sp_ld16(FRf + (size_t)(d0 + u) * ndp + qF) : SP_NEG;
-      vR[u] = (useR && d0 + u <= S) ? sp_ld16(FRr + (size_t)(d0 + u) * ndp + qR) : SP_NEG;
+      vF[u] = (useF && d0 + u <= S) ? FRf.get(d0 + u, qF) : SP_NEG;
+      vR[u] = (useR && d0 + u <= S) ? FRr.get(d0 + u, qR) : SP_NEG;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -622,8 +659,8 @@ __device__ __noinline__ void sp_first_columns_both(const int16_t* FRf, const int
     }
   }
   for (int d = 2; d <= S; ++d) {
-    sp_offer_negative(FRf + (size_t)d * ndp, cF + (size_t)d * (m + 1), m, d, rloF, rhiF, lane);
-    sp_offer_negative(FRr + (size_t)d * ndp, cR + (size_t)d * (m + 1), m, d, rloR, rhiR, lane);
+    sp_offer_negative(FRf, cF + (size_t)d * (m + 1), m, d, rloF, rhiF, lane);
+    sp_offer_negative(FRr, cR + (size_t)d * (m + 1), m, d, rloR, rhiR, lane);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -631,12 +668,13 @@ __device__ __noinline__ void sp_first_columns_both(const int16_t* FRf, const int
 
 // traceback from (r, c) with deficit D: the reference's rule (vertical, then horizontal, then diagonal; src/needle.h:154-192)
 // decided on the tables; runs in push order.  Returns the number of runs or -1 on overflow.  Wave-uniform.
-__device__ __noinline__ int sp_trace(const int16_t* FR, int ndp, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
+template <typename FRV>
+__device__ __noinline__ int sp_trace(const FRV& FR, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
                                      int* mismatches = nullptr) {
   const int ND = n + m + 1;
   const int D0 = rfl(D);
   int nv = 0, nh = 0;
-  auto fr = [&](int d, int q) -> int { return (d < 0 || q < 0 || q >= ND) ? SP_NEG : sp_ld16(FR + (size_t)d * ndp + q); };
+  auto fr = [&](int d, int q) -> int { return (d < 0 || q < 0 || q >= ND) ? SP_NEG : FR.get(d, q); };
   int nruns = 0, last_op = -1, last_len = 0;
   auto emit = [&](int op, int len) {
     if (len <= 0) return;
@@ -706,6 +744,17 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
     O.t[0] = wall_clock64();
 #endif
     done = S;
+    // where the tables of levels 0 .. S are read from (see FrTile8 / FrGlobal16)
+    constexpr bool TILED8 = LDSSTR && TILE::narrow;
+    typedef typename std::conditional<TILED8, FrTile8, FrGlobal16>::type FRV;
+    FRV frF, frR;
+    if constexpr (TILED8) {
+      frF = FrTile8{reinterpret_cast<const uint8_t*>(W.frF), W.ndp, {&T.row[0][0][0] + SP_LB + 1, &T.row[0][1][0] + SP_LB + 1}, S};
+      frR = FrTile8{reinterpret_cast<const uint8_t*>(W.frR), W.ndp, {&T.row[1][0][0] + SP_LB + 1, &T.row[1][1][0] + SP_LB + 1}, S};
+    } else {
+      frF = FrGlobal16{W.frF, W.ndp};
+      frR = FrGlobal16{W.frR, W.ndp};
+    }
     // deficit of the unsplit (semi-global) alignment: first level that reaches row m
     int du = -1;
     for (int d0 = 0; d0 <= S && du < 0; d0 += WAVE) {
@@ -737,25 +786,25 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
           nlistF = sps_deep_list<false>(T.row[0][SE & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
           nlistR = sps_deep_list<false>(T.row[1][SE & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
         } else {
-          nlistF = sp_deep_list(W.frF, W.ndp, m, n, SE, rlo, W.listF, W.runs_cap, lane);
-          nlistR = sp_deep_list(W.frR, W.ndp, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
+          nlistF = sp_deep_list(frF, m, n, SE, rlo, W.listF, W.runs_cap, lane);
+          nlistR = sp_deep_list(frR, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
         }
         if (nlistF >= 0 && nlistF <= WAVE && nlistR >= 0 && nlistR <= WAVE) {   // (its first wait covers the list stores too)
-          sp_first_columns_both(W.frF, W.frR, W.ndp, m, SE, rlo, rhi, W.listF, nlistF, W.cF, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+          sp_first_columns_both(frF, frR, m, SE, rlo, rhi, W.listF, nlistF, W.cF, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
           tables_done = true;
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
         }
       } else {
-        nlistF = sp_deep_list(W.frF, W.ndp, m, n, SE, rlo, W.listF, W.runs_cap, lane);
-        nlistR = sp_deep_list(W.frR, W.ndp, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
+        nlistF = sp_deep_list(frF, m, n, SE, rlo, W.listF, W.runs_cap, lane);
+        nlistR = sp_deep_list(frR, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
       }
       if (!tables_done) {
-        if (nlistF >= 0) sp_first_columns_list(W.frF, W.ndp, m, SE, rlo, rhi, W.listF, nlistF, W.cF, lane);
-        else sp_first_columns(W.frF, W.ndp, m, n, SE, rlo, rhi, W.cF, lane);
-        if (nlistR >= 0) sp_first_columns_list(W.frR, W.ndp, m, SE, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
-        else sp_first_columns(W.frR, W.ndp, m, n, SE, m - rhi, m - rlo, W.cR, lane);
+        if (nlistF >= 0) sp_first_columns_list(frF, m, SE, rlo, rhi, W.listF, nlistF, W.cF, lane);
+        else sp_first_columns(frF, m, n, SE, rlo, rhi, W.cF, lane);
+        if (nlistR >= 0) sp_first_columns_list(frR, m, SE, m - rhi, m - rlo, W.listR, nlistR, W.cR, lane);
+        else sp_first_columns(frR, m, n, SE, m - rhi, m - rlo, W.cR, lane);
       }
 #ifdef DH_LR_TIMING
       O.t[1] = wall_clock64();
@@ -845,13 +894,12 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
       const int eR = bestD - dsel;
       // refRight: last t <= n - refLeft with rev[consRight][t] at deficit eR (needle.h:119-123)
       int rright = 0;
-      const int16_t* lv = W.frR + (size_t)eR * W.ndp;
       if (nlistR >= 0) {   // (row consRight >= m - rhi: every diagonal that reaches it is listed)
         for (int i0 = 0; i0 < nlistR; i0 += WAVE) {
           const int i = i0 + lane;
           if (i < nlistR) {
             const int q = sp_ld32(W.listR + i), k = q - m, t = cr_ + k;
-            if (t >= 0 && t <= n - O.refLeft && sp_ld16(lv + q) >= cr_) rright = max(rright, t);
+            if (t >= 0 && t <= n - O.refLeft && frR.get(eR, q) >= cr_) rright = max(rright, t);
           }
         }
       } else {
@@ -859,7 +907,7 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
           const int q = q0 + lane;
           if (q < ND) {
             const int k = q - m, t = cr_ + k;
-            if (t >= 0 && t <= n - O.refLeft && sp_ld16(lv + q) >= cr_) rright = max(rright, t);
+            if (t >= 0 && t <= n - O.refLeft && frR.get(eR, q) >= cr_) rright = max(rright, t);
           }
         }
       }
@@ -869,8 +917,8 @@ __device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const 
 #ifdef DH_LR_TIMING
       O.t[3] = wall_clock64();
 #endif
-      O.nrunsF = sp_trace(W.frF, W.ndp, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF);
-      O.nrunsR = sp_trace(W.frR, W.ndp, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR);
+      O.nrunsF = sp_trace(frF, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF);
+      O.nrunsR = sp_trace(frR, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR);
 #ifdef DH_LR_TIMING
       O.t[4] = wall_clock64();
 #endif

@@ -49,7 +49,7 @@ struct __attribute__((aligned(16))) SpsLds {
 // bytes of per-wavefront global scratch the kernel needs
 __host__ __device__ inline uint64_t sps_scratch_bytes() {
   const uint64_t ndp = (SPS_ND + 2 + 63) & ~63;
-  return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp * 2 + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
+  return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
 }
 
 __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
@@ -80,9 +80,10 @@ __device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* s
   W.listF = W.runsR + SPS_LIST;
   W.listR = W.listF + SPS_LIST;
   sp += 4ull * SPS_LIST * 4;
+  // byte tables (row + 1, 0 = none), level stride ndp: what the tile spills (sparse_needle.hpp, FrTile8)
   W.frF = reinterpret_cast<int16_t*>(sp);
-  W.frR = W.frF + (size_t)(SPS_SMAX + 1) * W.ndp;
-  W.cF = reinterpret_cast<int32_t*>(W.frR + (size_t)(SPS_SMAX + 1) * W.ndp);
+  W.frR = reinterpret_cast<int16_t*>(sp + (size_t)(SPS_SMAX + 1) * W.ndp);
+  W.cF = reinterpret_cast<int32_t*>(sp + 2 * (size_t)(SPS_SMAX + 1) * W.ndp);
   W.cR = W.cF + (size_t)(SPS_SMAX + 1) * (m + 1);
   __syncthreads();
 #ifdef DH_LR_TIMING

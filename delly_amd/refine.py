@@ -34,7 +34,7 @@ EXPORTS = [
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
     "dellyhip_create_shared", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
-    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats",
+    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left",
 ]
 
 
@@ -432,6 +432,12 @@ class ResidentBatch:
         self.ctx._check(self.ctx.lib.dellyhip_batch_dp_kernel_ms(self.ctx._ctx, self._b, C.byref(a)))
         return a.value
 
+    def sparse_left(self):
+        """junctions of the last run that split_sparse_kernel left to the dense kernels"""
+        v = C.c_int32(0)
+        self.ctx._check(self.ctx.lib.dellyhip_batch_sparse_left(self.ctx._ctx, self._b, C.byref(v)))
+        return v.value
+
     def device_results(self):
         """(device pointer, bytes) of the n result records in HBM."""
         ptr, nbytes = C.c_void_p(), C.c_uint64(0)
@@ -464,6 +470,22 @@ class ResidentBatch:
         if not is_root:
             return None, None, None
         return res[:n_res.value], out[:used.value], counts
+
+    def gather_into(self, comm, root, pinned):
+        """dellyhip_gather_results into preallocated (pinned) host buffers: pinned = (records bytes, blob bytes) as torch uint8
+        tensors on the root, None elsewhere -> (records gathered, blob bytes gathered).  Collective."""
+        is_root = comm.rank == root
+        n_res, used = C.c_uint64(0), C.c_uint64(0)
+        if is_root:
+            rec, blob = pinned
+            ncap = rec.numel() // abi.result_dtype().itemsize
+            self.ctx._check(self.ctx.lib.dellyhip_gather_results(
+                self.ctx._ctx, comm._c, self._b, int(root), C.c_void_p(rec.data_ptr()), C.c_uint64(ncap), C.byref(n_res),
+                C.c_void_p(blob.data_ptr()), C.c_uint64(blob.numel()), C.byref(used), None))
+        else:
+            self.ctx._check(self.ctx.lib.dellyhip_gather_results(self.ctx._ctx, comm._c, self._b, int(root), None, C.c_uint64(0), C.byref(n_res),
+                                                                 None, C.c_uint64(0), C.byref(used), None))
+        return n_res.value, used.value
 
     def gather_device(self, comm, root=0):
         """dellyhip_gather_results_device: the same exchange, results left in the root's HBM -> (records, blob bytes) gathered"""

@@ -1,9 +1,7 @@
-"""-m gpu: bit-compare of the HIP path with the reference itself (oracle/_ref, all host threads) on EXACTLY the
-batches bench.py times -- the 10 000-junction C2 headline batch and the side measurements of bench.SIDE_PLAN
-(U_full N = 20 / 5, insertions, long-read alignConsensus, long-read msaEdlib + alignConsensus with 15 reads of
-2.2 kb at 6 % error).  The long-read CPU legs are bounded to what the reference finishes in seconds
-(>= 256 / >= 64 junctions, the prefix of the benched batch: synth batches are counter-based, junction j does
-not depend on the batch size)."""
+"""-m gpu: bit-compare of the HIP path with the reference itself (oracle/_ref, the host's threads) on EXACTLY the
+batches bench.py times, each in FULL -- the RESIDENT_BATCHES headline batches of 10 000 C2 junctions, every point of
+the deficit sweep (bench.SWEEP_PLAN), and the side measurements of bench.SIDE_PLAN (40 000 C2 junctions, U_full N = 20 /
+5, insertions, long-read alignConsensus, msaEdlib and msaWfa loop bodies)."""
 import os
 import sys
 
@@ -19,25 +17,53 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (SIDE_PLAN only; main() is not run)
 
 THREADS = os.cpu_count() or 1
-# junctions compared per workload (None = the whole benched batch)
-COMPARE_N = {"u_full_n20": None, "u_full_n20_10k_junctions": 1000, "u_full_n5": None, "ins_svt4": None, "lr_c4_align_consensus": 256,
-             "lr_c4_msaedlib_n15": 64, "lr_ins_msawfa_n15": 64}
+# junctions compared per workload (None = the whole benched batch); long-read legs use at most 64 reference threads (each
+# holds four int32 matrices of ~60 MB, src/needle.h:52-103)
+COMPARE_N = {"u_c2_40k_junctions": None, "u_full_n20": None, "u_full_n20_10k_junctions": None, "u_full_n5": None, "ins_svt4": None,
+             "lr_c4_align_consensus": None, "lr_c4_msaedlib_n15": None, "lr_ins_msawfa_n15": None}
 
 
 def _check(ctx, ref, b, params, label, n_cmp=None):
     ctx.set_chromosomes(b.chroms)
     gr, gb = ctx.refine(b, want_alignment=False)
     sub = b if n_cmp is None or n_cmp >= b.n else bench._subbatch(b, n_cmp)
-    rr, rb = ref.refine_batch(sub, want_alignment=False, n_threads=THREADS, params=params)
+    lr = params is not None and (params.reserved & 1)
+    rr, rb = ref.refine_batch(sub, want_alignment=False, n_threads=min(THREADS, 64) if lr else THREADS, params=params)
     k = sub.n
     compare(gr[:k], gb, rr, rb, fields=CORE, blobs=("cons", "allele"), label=label)
     return gr
 
 
-def test_headline_batch_10000_c2_junctions_vs_reference(gpu_ctx, reference):
-    b = synth.make_batch(10000, mode="c2")
-    gr = _check(gpu_ctx, reference, b, None, "bench headline (10 000 C2)")
-    assert int(gr["ok"].sum()) == 9900   # bench.py's refined_ok
+@pytest.mark.parametrize("k", range(bench.RESIDENT_BATCHES))
+def test_headline_batches_10000_c2_junctions_vs_reference(gpu_ctx, reference, k):
+    """the resident batches bench.py's timed steps rotate through (rank 0 of a one-GPU run; the second one is also the
+    partner of u_c2_two_batches_in_flight)"""
+    b = synth.make_batch(10000, mode="c2", first=k * 10000)
+    gr = _check(gpu_ctx, reference, b, None, "bench headline batch %d (10 000 C2)" % k)
+    assert int(gr["ok"].sum()) >= 9890   # bench.py's refined_ok (1 % pure-reference junctions per batch)
+
+
+@pytest.mark.parametrize("name", [x[0] for x in bench.SWEEP_PLAN])
+def test_deficit_sweep_batches_vs_reference(gpu_ctx, reference, name):
+    kw = [x[1] for x in bench.SWEEP_PLAN if x[0] == name][0]
+    b = bench.sweep_batch(synth, kw)
+    _check(gpu_ctx, reference, b, None, "deficit sweep " + name)
+
+
+def test_host_inclusive_stream_results_vs_reference(gpu_ctx, reference):
+    """what bench.py's host_inclusive leg hands back (dellyhip_stream over the resident batches' host copies)"""
+    raw = [synth.make_batch(10000, mode="c2", first=k * 10000) for k in range(2)]
+    chroms, batches = bench.one_genome(synth, raw)
+    gpu_ctx.set_chromosomes(chroms)
+    st = refine.Stream(gpu_ctx, depth=3)
+    st.submit(batches[0], tag=0)
+    st.submit(batches[1], tag=1)
+    for k in range(2):
+        gr, gb, tag = st.collect()
+        assert tag == k
+        rr, rb = reference.refine_batch(batches[k], want_alignment=False, n_threads=THREADS)
+        compare(gr, gb, rr, rb, fields=CORE, blobs=("cons", "allele"), label="host-inclusive stream batch %d" % k)
+    st.close()
 
 
 @pytest.mark.parametrize("name", [x[0] for x in bench.SIDE_PLAN if x[0] in COMPARE_N])
