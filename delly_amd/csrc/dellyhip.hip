@@ -141,6 +141,7 @@ struct dellyhip_ctx {
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
   int msa_only = 0;          // env DELLYHIP_MSA_ONLY=1 (profiling builds): msa() batches stop after the MSA kernels
+  int msa_waves = 16;        // resident wavefronts of msa_kernel per CU (env DELLYHIP_MSA_WAVES; 128 VGPRs and 9.7 KB of LDS allow 16)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
@@ -992,6 +993,7 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_ONLY")) c->msa_only = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_MSA_WAVES")) c->msa_waves = std::max(1, std::min(16, atoi(t)));
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -1306,7 +1308,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       }
     } else {
       const dh::MsaPlan& mp = b->msa_plan;
-      if ((rc = b->msa_ws.reserve(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * 8))))) return bail(rc);
+      if ((rc = b->msa_ws.reserve(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * c->msa_waves))))) return bail(rc);
       // msa_big: as many resident wavefronts as junctions are expected there; a few stand by for the unpredictable
       // case (a node of the standard instance growing beyond its 512 columns)
       b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
@@ -1457,7 +1459,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.work_counter = c->counters.p;
     ma.defer_counter = c->counters.p + 8;
     ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
-    int grid = std::min(b->n, c->n_cu * 8);
+    int grid = std::min(b->n, c->n_cu * c->msa_waves);
     if ((rc = dh::msa_launch(ma, grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
                              b->msa_plan.big_nmax)))
       return fail(rc, "msa_launch");
@@ -1703,27 +1705,40 @@ void dellyhip_comm_destroy(dellyhip_comm* m) {
 }
 
 // the exchange itself: afterwards the root holds every rank's records (rank order) and compact blobs in HBM
+// A local failure must not leave the other ranks inside a collective: every rank ALWAYS takes part in the exchange of the
+// (count, bytes) pairs -- a rank whose batch could not be synchronised or compacted sends count = GATHER_ERR -- and in a second
+// one-word exchange after the root has sized its receive areas; all ranks then agree on whether the Send / Recv group runs.
+static const uint64_t GATHER_ERR = ~0ull;
+
 static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, std::vector<uint64_t>& all,
                          std::vector<uint64_t>& first_n, std::vector<uint64_t>& first_b, const void** d_rec, const void** d_blob) {
-  int rc = dellyhip_batch_sync(c, b);
-  if (rc) return rc;
   std::vector<uint64_t> off;
   uint64_t used = 0;
-  if ((rc = compact_batch(c, b, off, &used))) return rc;
+  int local_rc = dellyhip_batch_sync(c, b);
+  if (!local_rc) local_rc = compact_batch(c, b, off, &used);
+  const std::string local_err = local_rc ? g_err : std::string();
   const int W = m->world;
   const bool is_root = m->rank == root;
   all.assign(2 * (size_t)W, 0);
   if (!m->nccl) {   // one rank, no communicator
+    if (local_rc) return local_rc;
     all[0] = (uint64_t)b->n;
     all[1] = used;
   } else {
     dh::RcclApi& A = dh::rccl_api();
-    const uint64_t mine[2] = {(uint64_t)b->n, used};
+    const uint64_t mine[2] = {local_rc ? GATHER_ERR : (uint64_t)b->n, local_rc ? 0 : used};
     HIPCHK(hipMemcpyAsync(m->d_counts.p + 2 * W, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
     ncclResult_t r = A.AllGather(m->d_counts.p + 2 * W, m->d_counts.p, 2, ncclUint64, m->nccl, c->stream);
     if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
     HIPCHK(hipMemcpyAsync(all.data(), m->d_counts.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int r2 = 0; r2 < W; ++r2)
+      if (all[2 * r2] == GATHER_ERR) {
+        if (local_rc) return fail(local_rc, local_err.c_str());
+        char msg[96];
+        snprintf(msg, sizeof msg, "dellyhip_gather_results: rank %d failed before the exchange", r2);
+        return fail(DELLYHIP_E_RUNTIME, msg);
+      }
   }
   uint64_t tot_n = 0, tot_b = 0;
   first_n.assign(W + 1, 0);
@@ -1741,9 +1756,22 @@ static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, i
   *d_blob = b->blob_compact.p;
   if (W > 1) {
     dh::RcclApi& A = dh::rccl_api();
+    int root_rc = 0;
     if (is_root) {
-      if ((rc = m->rec_all.reserve(std::max<uint64_t>(tot_n * sizeof(dellyhip_result), 1))) || (rc = m->blob_all.reserve(std::max<uint64_t>(tot_b, 1))))
-        return rc;
+      if ((root_rc = m->rec_all.reserve(std::max<uint64_t>(tot_n * sizeof(dellyhip_result), 1)))) root_rc = DELLYHIP_E_NOMEM;
+      else if ((root_rc = m->blob_all.reserve(std::max<uint64_t>(tot_b, 1)))) root_rc = DELLYHIP_E_NOMEM;
+    }
+    // second exchange: is the root ready to receive?  (one word per rank; only the root's matters)
+    {
+      const uint64_t ready[2] = {(is_root && root_rc) ? GATHER_ERR : 0, 0};
+      std::vector<uint64_t> seen(2 * (size_t)W, 0);
+      HIPCHK(hipMemcpyAsync(m->d_counts.p + 2 * W, ready, sizeof ready, hipMemcpyHostToDevice, c->stream));
+      ncclResult_t r = A.AllGather(m->d_counts.p + 2 * W, m->d_counts.p, 2, ncclUint64, m->nccl, c->stream);
+      if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+      HIPCHK(hipMemcpyAsync(seen.data(), m->d_counts.p, seen.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (seen[2 * (size_t)root] == GATHER_ERR)
+        return fail(DELLYHIP_E_NOMEM, "dellyhip_gather_results: the root could not allocate its receive areas");
     }
     ncclResult_t r = A.GroupStart();
     if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
@@ -1788,6 +1816,26 @@ int dellyhip_gather_results_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_b
   return 0;
 }
 
+int dellyhip_rebase_gathered(dellyhip_result* results, uint64_t n_results, int32_t world, const uint64_t* counts, const uint64_t* bytes) {
+  if (world < 1 || !counts || !bytes || (n_results && !results)) return fail(DELLYHIP_E_ARG, "bad argument");
+  uint64_t k = 0, base = 0;
+  for (int r = 0; r < world; ++r) {
+    uint64_t at = base;
+    for (uint64_t q = 0; q < counts[r]; ++q, ++k) {
+      if (k >= n_results) return fail(DELLYHIP_E_ARG, "dellyhip_rebase_gathered: counts exceed the records");
+      dellyhip_result& R = results[k];
+      const uint64_t len = (uint64_t)std::max(R.cons_len, 0) + (uint64_t)std::max(R.allele_len, 0) + 2ull * (uint64_t)std::max(R.aln_len, 0);
+      rebase_offsets(R, at);
+      R.reserved = 0;
+      at += len;
+    }
+    if (at - base != bytes[r]) return fail(DELLYHIP_E_RUNTIME, "dellyhip_rebase_gathered: a rank's records do not add up to its blob bytes");
+    base += bytes[r];
+  }
+  if (k != n_results) return fail(DELLYHIP_E_ARG, "dellyhip_rebase_gathered: counts do not cover the records");
+  return 0;
+}
+
 int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, dellyhip_result* results,
                             uint64_t results_cap, uint64_t* n_results, char* out_blob, uint64_t out_blob_cap,
                             uint64_t* out_blob_len, int32_t* counts) {
@@ -1813,16 +1861,9 @@ int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b
     if (tot_b) HIPCHK(hipMemcpyAsync(out_blob, db, tot_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // blob offsets: each rank's pieces lie back to back in its compact blob in junction order
-    for (int r = 0; r < W; ++r) {
-      uint64_t at = first_b[r];
-      for (uint64_t k = first_n[r]; k < first_n[r + 1]; ++k) {
-        dellyhip_result& R = results[k];
-        const uint64_t len = (uint64_t)std::max(R.cons_len, 0) + (uint64_t)std::max(R.allele_len, 0) + 2ull * (uint64_t)std::max(R.aln_len, 0);
-        rebase_offsets(R, at);
-        R.reserved = 0;
-        at += len;
-      }
-    }
+    std::vector<uint64_t> cnt(W), byt(W);
+    for (int r = 0; r < W; ++r) { cnt[r] = first_n[r + 1] - first_n[r]; byt[r] = first_b[r + 1] - first_b[r]; }
+    if (dellyhip_rebase_gathered(results, tot_n, W, cnt.data(), byt.data())) return DELLYHIP_E_RUNTIME;
   }
   return 0;
 }
@@ -1990,6 +2031,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // may have changed the parent's since)
     S.ctx->sr_sparse = c->sr_sparse; S.ctx->use_sparse = c->use_sparse; S.ctx->use_quad = c->use_quad; S.ctx->quad_mix = c->quad_mix;
     S.ctx->sps_waves = c->sps_waves; S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
+    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only;
   }
   *out = st.release();
   return 0;

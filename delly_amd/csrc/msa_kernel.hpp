@@ -32,8 +32,9 @@ namespace dh {
 constexpr int GKMAX = 8;     // Gotoh rows per lane in one pass; longer nodes run in strips of 64*GKMAX rows (msa_big)
 constexpr int GINF = 1000000;  // DnaScore::inf, src/align.h:21
 constexpr int PROFW = 8;     // dwords per profile column: meta + 5 values (+2 pad)
-constexpr int TMAXC = 96;    // profile column types per alignment node the score table is built for
-constexpr int HSLOTS = 256;  // open-addressing table of column-type keys
+constexpr int TMAXC = 96;    // profile column types per alignment node the score table is built for ...
+constexpr int TABCAP = 4096; // ... with T1 x T2 <= TABCAP table entries (64 x 64, 96 x 42, ...): LDS per wavefront decides the occupancy
+constexpr int HSLOTS = 128;  // open-addressing table of column-type keys
 constexpr int FASTK = 5;      // rows per lane served by the score-table kernel (node length <= 319)
 constexpr int MSA_DEFER = 1; // merge_nodes: more column types than the table holds -> direct-float kernel
 
@@ -145,7 +146,7 @@ __device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_para
 }  // namespace dh
 
 #define DH_MSA_NS msa_std
-#define DH_MSA_NRMAX 32
+#define DH_MSA_NRMAX 24
 #define DH_MSA_RLMAX 256
 #define DH_MSA_LCAP 512
 #define DH_MSA_FAST 1

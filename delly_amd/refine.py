@@ -34,7 +34,7 @@ EXPORTS = [
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
     "dellyhip_create_shared", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
-    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left",
+    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
 ]
 
 

@@ -268,6 +268,12 @@ int dellyhip_gather_results(dellyhip_ctx* ctx, dellyhip_comm* comm, dellyhip_bat
                             dellyhip_result* results, uint64_t results_cap, uint64_t* n_results, char* out_blob,
                             uint64_t out_blob_cap, uint64_t* out_blob_len, int32_t* counts);
 
+/* What the root does to the gathered records after the exchange, exposed so that it can be verified without GPUs: the
+ * records of rank r (counts[r] of them, in rank order) point into a compact blob of bytes[r] bytes whose pieces lie back
+ * to back in record order; their cons_off / allele_off / aln_off become offsets into the concatenation of all ranks' blobs.
+ * Fails (DELLYHIP_E_RUNTIME) when a rank's records do not add up to its blob.  Pure host arithmetic. */
+int dellyhip_rebase_gathered(dellyhip_result* results, uint64_t n_results, int32_t world, const uint64_t* counts, const uint64_t* bytes);
+
 /* The same exchange, results left in the root's HBM (pipelined callers: the gather of batch k overlaps the refinement
  * of batch k+1; a later dellyhip_gather_results / hipMemcpy moves them to the host): *d_records = n_results records in
  * rank order, *d_blob = the ranks' compact blobs back to back (offsets inside the records are still per rank, as

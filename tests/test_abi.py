@@ -83,3 +83,63 @@ def test_compiled_cpp_caller_builds_and_fails_loudly_without_a_device():
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "nodevice"], capture_output=True, text=True)
         assert r.returncode == 0 and "loud failure" in r.stdout, r.stdout + r.stderr
+
+
+def test_rebase_of_gathered_records_multi_rank_on_the_host():
+    """dellyhip_rebase_gathered = what the root of dellyhip_gather_results does to the records of W ranks after the RCCL
+    exchange (offset rebasing across the concatenated per-rank blobs).  Pure host code: driven here with faked multi-rank
+    inputs, no GPU and no communicator needed."""
+    import ctypes as C
+
+    import numpy as np
+
+    from delly_amd import abi, refine
+    lib = refine.load_library()
+    rng = np.random.default_rng(5)
+    world = 5
+    recs, blobs, counts, nbytes, want = [], [], [], [], []
+    for r in range(world):
+        n = int(rng.integers(0, 40)) if r != 2 else 0          # one rank without junctions
+        rec = np.zeros(n, dtype=abi.result_dtype())
+        parts = []
+        at = 0
+        for k in range(n):
+            lens = [int(rng.integers(0, 300)), int(rng.integers(0, 900)) if rng.random() < 0.7 else 0, int(rng.integers(0, 200)) if rng.random() < 0.3 else 0]
+            rec[k]["cons_len"], rec[k]["allele_len"], rec[k]["aln_len"] = lens
+            rec[k]["svid"] = 1000 * r + k
+            rec[k]["reserved"] = 2                              # transient kernel state must not survive
+            pieces = [rng.integers(65, 90, lens[0], dtype=np.uint8), rng.integers(65, 90, lens[1], dtype=np.uint8),
+                      rng.integers(65, 90, 2 * lens[2], dtype=np.uint8)]
+            # what a rank's compaction leaves: offsets relative to ITS blob (any value where the length is 0)
+            rec[k]["cons_off"], rec[k]["allele_off"], rec[k]["aln_off"] = at, at + lens[0], at + lens[0] + lens[1]
+            at += lens[0] + lens[1] + 2 * lens[2]
+            parts.extend(pieces)
+            want.append([p.tobytes() for p in pieces])
+        recs.append(rec)
+        blobs.append(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+        counts.append(n)
+        nbytes.append(at)
+    allr = np.zeros(sum(counts), dtype=abi.result_dtype())   # (np.concatenate would re-pack the padded record layout)
+    at = 0
+    for rec in recs:
+        allr[at:at + rec.shape[0]] = rec
+        at += rec.shape[0]
+    blob = np.concatenate(blobs)
+    cnt = np.array(counts, dtype=np.uint64)
+    byt = np.array(nbytes, dtype=np.uint64)
+    rc = lib.dellyhip_rebase_gathered(allr.ctypes.data_as(C.c_void_p), C.c_uint64(allr.shape[0]), world,
+                                      cnt.ctypes.data_as(C.POINTER(C.c_uint64)), byt.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert rc == 0, lib.dellyhip_last_error()
+    assert (allr["reserved"] == 0).all()
+    for k in range(allr.shape[0]):
+        R = allr[k]
+        for off, ln, w in ((int(R["cons_off"]), int(R["cons_len"]), want[k][0]), (int(R["allele_off"]), int(R["allele_len"]), want[k][1]),
+                           (int(R["aln_off"]), 2 * int(R["aln_len"]), want[k][2])):
+            assert blob[off:off + ln].tobytes() == w, (k, off, ln)
+    # inconsistent inputs are refused: a blob size that does not match the records, counts that do not cover them
+    byt2 = byt.copy()
+    byt2[1] += 1
+    assert lib.dellyhip_rebase_gathered(allr.ctypes.data_as(C.c_void_p), C.c_uint64(allr.shape[0]), world,
+                                        cnt.ctypes.data_as(C.POINTER(C.c_uint64)), byt2.ctypes.data_as(C.POINTER(C.c_uint64))) != 0
+    assert lib.dellyhip_rebase_gathered(allr.ctypes.data_as(C.c_void_p), C.c_uint64(allr.shape[0] + 1), world,
+                                        cnt.ctypes.data_as(C.POINTER(C.c_uint64)), byt.ctypes.data_as(C.POINTER(C.c_uint64))) != 0
