@@ -145,7 +145,7 @@ struct dellyhip_ctx {
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
-struct SmallInv { int32_t j, full_len, offset; };   // long-read loop, small inversions (src/assemble.h:840-853)
+struct SmallInv { int32_t j, full_len, offset, take; };   // long-read loop, small inversions (src/assemble.h:840-853)
 
 struct dellyhip_batch {
   bool ever_run = false;
@@ -789,6 +789,15 @@ int route_after_msa(dellyhip_ctx* c, dellyhip_batch* b) {
 
 }  // namespace
 
+// long-read loop, small inversions (src/assemble.h:840-848): only the middle svSize letters of the consensus are aligned
+__global__ void small_inv_apply_kernel(uint64_t* cons_off, int32_t* cons_len, const SmallInv* list, int n, uint64_t out_stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SmallInv x = list[i];
+  cons_off[x.j] = (uint64_t)x.j * out_stride + (uint64_t)x.offset;
+  cons_len[x.j] = x.take;
+}
+
 // long-read loop, small inversions (src/assemble.h:850-853): the consensus is restored, consBp shifted
 __global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1413,8 +1422,6 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     // "take care of small inversions" (src/assemble.h:840-848): align only the middle svSize letters
     {
       std::vector<SmallInv> si;
-      std::vector<uint64_t> coffs;
-      std::vector<int32_t> takes;
       for (int i = 0; i < b->n; ++i) {
         const dellyhip_junction& J = b->h_junc[i];
         const int32_t svSize = J.sv_end - J.sv_start, m = b->h_cons_len[i];
@@ -1422,20 +1429,17 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
           const int32_t off = (int32_t)(((size_t)m - (size_t)svSize) / 2);
           if (off < 0 || off > m) continue;
           const int32_t take = std::min<int32_t>(std::max(svSize, 0), m - off);
-          si.push_back(SmallInv{i, m, off});
+          si.push_back(SmallInv{i, m, off, take});
           b->h_cons_len[i] = take;
-          coffs.push_back((uint64_t)i * b->out_stride + (uint64_t)off);
-          takes.push_back(take);
         }
       }
-      for (size_t k = 0; k < si.size(); ++k) {   // (sources stay alive until the synchronous copies return)
-        HIPCHK(hipMemcpy(b->cons_off.p + si[k].j, &coffs[k], sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(b->cons_len.p + si[k].j, &takes[k], sizeof(int32_t), hipMemcpyHostToDevice));
-      }
       b->small_inv_n = (int)si.size();
-      if (b->small_inv_n) {
+      if (b->small_inv_n) {   // one upload + one launch for all of them
         if ((rc = b->small_inv.reserve(si.size()))) return rc;
         HIPCHK(hipMemcpy(b->small_inv.p, si.data(), si.size() * sizeof(SmallInv), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(small_inv_apply_kernel, dim3((b->small_inv_n + 63) / 64), dim3(64), 0, s, b->cons_off.p, b->cons_len.p, b->small_inv.p,
+                           b->small_inv_n, b->out_stride);
+        HIPCHK(hipGetLastError());
       }
     }
     if ((rc = route_after_msa(c, b))) return rc;

@@ -143,6 +143,42 @@ __device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_para
 }
 
 
+// consensus (src/msa.h:111-173) from a node's column statistics (msa_body.inc): cover count, A / C / G / T counts, and the
+// bucket of everything else = cover - (A + C + G + T)
+__device__ __forceinline__ int consensus_stats(const unsigned long long* stats, int len, int rows, const dellyhip_params& P, uint8_t* cs,
+                                               int cap, int lane) {
+  const int thr = max(2, min(P.min_clique_size, rows));
+  int outn = 0;
+  for (int base = 0; base < len; base += WAVE) {
+    const int j = base + lane;
+    uint8_t letter = 0;
+    if (j < len) {
+      const unsigned long long st = stats[j];
+      const int cov = (int)((st >> 48) & 0xff);
+      int cnt[5];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cnt[q] = (int)((st >> (8 * q)) & 0xff);
+      cnt[4] = cov - (cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+      if (cov >= thr) {
+        int mi = 0, mc = cnt[0];
+#pragma unroll
+        for (int q = 1; q < 5; ++q)
+          if (cnt[q] > mc) {
+            mc = cnt[q];
+            mi = q;
+          }
+        if (mi < 4) letter = (uint8_t)("ACGT"[mi]);
+      }
+    }
+    const unsigned long long km = __ballot(letter != 0);
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int pos = outn + __popcll(km & below);
+    if (letter && pos < cap) cs[pos] = letter;
+    outn += __popcll(km);
+  }
+  return outn;
+}
+
 }  // namespace dh
 
 #define DH_MSA_NS msa_std

@@ -320,14 +320,15 @@ typedef struct dellyhip_align_result {
   int32_t dist_ref;    /* same for refProbe */
   uint8_t type;        /* 'R', 'A' or 'N' */
   uint8_t qual;
-  int16_t status;      /* 0, or DELLYHIP_E_LIMIT (probe > 256 bytes) */
+  int16_t status;      /* 0, or DELLYHIP_E_LIMIT (probe > 6144 bytes) */
 } dellyhip_align_result;
 
 /* The worker body of process_batch, src/coverage.h:418-434, for every job:
  *   scoreAlt = _editDistanceHW(c, consProbe, sequence); scoreRef = _editDistanceHW(c, refProbe, sequence)
  *   (src/coverage.h:107-115: edlib HW distance with k = (int)(2 * flankQuality * |probe|), score =
  *   (1 - flankQuality) * |probe| / (distance + 1) in double, 0 beyond k), then type / qual as in :424-432.
- * Uses params.flank_quality of the context.  Limits: probes <= 256 bytes (reads: any length).
+ * Uses params.flank_quality of the context.  Limits: probes <= 6144 bytes (<= 64: one job per lane; <= 256: four words per
+ * probe; beyond: one job per wavefront); reads: any length.
  * The merge into countMap (:438-449, order dependent) stays with the caller. */
 int dellyhip_classify_reads(dellyhip_ctx* ctx, uint64_t n_jobs, const dellyhip_align_job* jobs,
                             const char* blob, uint64_t blob_len, dellyhip_align_result* results);
