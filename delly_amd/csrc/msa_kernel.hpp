@@ -273,7 +273,7 @@ inline int msa_single_lcs(hipStream_t s, const char* s1, int m, const char* s2, 
   if (m > msa_big::RLMAX) return DELLYHIP_E_LIMIT;
   uint8_t *d1 = nullptr, *d2 = nullptr;
   int* dout = nullptr;
-  if (hipMalloc((void**)&d1, std::max(m, 1)) != hipSuccess || hipMalloc((void**)&d2, std::max(n, 1)) != hipSuccess ||
+  if (hipMalloc((void**)&d1, std::max(m, 1) + 8) != hipSuccess || hipMalloc((void**)&d2, std::max(n, 1) + 8) != hipSuccess ||   // (+8: quadword reads)
       hipMalloc((void**)&dout, 4) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(d1, s1, m, hipMemcpyHostToDevice);
@@ -345,7 +345,7 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_r
   uint64_t* doff = nullptr;
   dellyhip_result* dres = nullptr;
   int32_t *dlen = nullptr, *dcnt = nullptr;
-  if (hipMalloc((void**)&dj, sizeof J) != hipSuccess || hipMalloc((void**)&dblob, std::max<uint64_t>(blob_bytes, 1)) != hipSuccess ||
+  if (hipMalloc((void**)&dj, sizeof J) != hipSuccess || hipMalloc((void**)&dblob, std::max<uint64_t>(blob_bytes, 1) + 64) != hipSuccess ||   // (+64: quadword reads)
       hipMalloc((void**)&doff, (n_reads + 1) * 8) != hipSuccess || hipMalloc((void**)&dres, sizeof(dellyhip_result)) != hipSuccess ||
       hipMalloc((void**)&dout, ccap) != hipSuccess || hipMalloc((void**)&ws, plan.ws_stride) != hipSuccess ||
       hipMalloc((void**)&wsb, plan.big_ws_stride) != hipSuccess || hipMalloc((void**)&dlen, 4) != hipSuccess ||

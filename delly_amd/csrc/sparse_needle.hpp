@@ -25,6 +25,14 @@
 #pragma once
 #include <type_traits>
 
+// the helpers of the sparse procedure are folded into the kernels (-DDH_SP_CALLS: real functions -- measured 6 % slower, their
+// frames live in scratch memory)
+#ifndef DH_SP_CALLS
+#define DH_SP_FN __forceinline__
+#else
+#define DH_SP_FN __noinline__
+#endif
+
 #include "split_kernel.hpp"
 
 namespace dh {
@@ -278,7 +286,7 @@ __device__ __forceinline__ void sp_tile_levels(const uint8_t* aF, const uint8_t*
 }
 
 template <typename TILE>
-__device__ __noinline__ void sp_level_block2(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+__device__ DH_SP_FN void sp_level_block2(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
                                              int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
                                              int16_t* reachR, int lane) {
   constexpr int SP_TW = TILE::tw;
@@ -332,7 +340,7 @@ __device__ __noinline__ void sp_level_block2(const uint8_t* consF, const uint8_t
 // every chunk reads before it writes, so nothing is overwritten early.  The rows must be zero when d0 == 0 (done here);
 // index = diagonal + SP_LB + 1.
 template <typename TILE>
-__device__ __noinline__ void sps_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+__device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
                                              int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
                                              int16_t* reachR, int lane) {
   static_assert(TILE::narrow, "byte rows");
@@ -510,7 +518,7 @@ __device__ __forceinline__ void sp_offer_negative(const FRV& FR, int32_t* row, i
 
 // cT[d][r] = min over diagonals k with FR[d][k] >= r (and r on the diagonal) of r + k, for rows rlo .. rhi, levels 0 .. S
 template <typename FRV>
-__device__ __noinline__ void sp_first_columns(const FRV& FR, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
+__device__ DH_SP_FN void sp_first_columns(const FRV& FR, int m, int n, int S, int rlo, int rhi, int32_t* cT, int lane) {
   const int ND = n + m + 1;
   const int rows = rhi - rlo + 1;
   for (int d = 0; d <= S; ++d)
@@ -543,7 +551,7 @@ __device__ __noinline__ void sp_first_columns(const FRV& FR, int m, int n, int S
 // the diagonals that reach row rlo at level S (FR is non-decreasing in the level: no other diagonal can reach it at a lower
 // one), compacted into list[]; returns their number or -1 when the list overflows
 template <typename FRV>
-__device__ __noinline__ int sp_deep_list(const FRV& FR, int m, int n, int S, int rlo, int32_t* list, int cap, int lane) {
+__device__ DH_SP_FN int sp_deep_list(const FRV& FR, int m, int n, int S, int rlo, int32_t* list, int cap, int lane) {
   const int ND = n + m + 1;
   int cnt = 0;
   for (int q0 = 0; q0 < ND; q0 += WAVE) {
@@ -586,7 +594,7 @@ __device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo,
 
 // sp_first_columns restricted to the listed diagonals (ascending)
 template <typename FRV>
-__device__ __noinline__ void sp_first_columns_list(const FRV& FR, int m, int S, int rlo, int rhi, const int32_t* list,
+__device__ DH_SP_FN void sp_first_columns_list(const FRV& FR, int m, int S, int rlo, int rhi, const int32_t* list,
                                                    int cnt, int32_t* cT, int lane) {
   const int rows = rhi - rlo + 1;
   for (int d = 0; d <= S; ++d)
@@ -628,7 +636,7 @@ __device__ __noinline__ void sp_first_columns_list(const FRV& FR, int m, int S, 
 // stores that clear the tables and write the lists are waited for ONCE, the list entries and the table values of four
 // levels of BOTH matrices are in flight together -- two memory round trips instead of six.
 template <typename FRV>
-__device__ __noinline__ void sp_first_columns_both(const FRV& FRf, const FRV& FRr, int m, int S, int rloF, int rhiF,
+__device__ DH_SP_FN void sp_first_columns_both(const FRV& FRf, const FRV& FRr, int m, int S, int rloF, int rhiF,
                                                    const int32_t* listF, int cntF, int32_t* cF, int rloR, int rhiR,
                                                    const int32_t* listR, int cntR, int32_t* cR, int lane) {
   const int rows = rhiF - rloF + 1;   // (= rhiR - rloR + 1)
@@ -669,7 +677,7 @@ __device__ __noinline__ void sp_first_columns_both(const FRV& FRf, const FRV& FR
 // traceback from (r, c) with deficit D: the reference's rule (vertical, then horizontal, then diagonal; src/needle.h:154-192)
 // decided on the tables; runs in push order.  Returns the number of runs or -1 on overflow.  Wave-uniform.
 template <typename FRV>
-__device__ __noinline__ int sp_trace(const FRV& FR, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
+__device__ DH_SP_FN int sp_trace(const FRV& FR, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
                                      int* mismatches = nullptr) {
   const int ND = n + m + 1;
   const int D0 = rfl(D);
@@ -723,7 +731,7 @@ __device__ __noinline__ int sp_trace(const FRV& FR, int m, int n, int r, int c, 
 // The whole procedure for one junction (one wavefront).  cons / ref: clean letters; rcons / rref: their reverse
 // complements.  reach arrays in LDS (SP_LEVELS_MAX int16 each).
 template <typename TILE, bool LDSSTR>
-__device__ __noinline__ SparseRes sparse_long_needle(const uint8_t* cons, const uint8_t* rcons, const uint8_t* ref, const uint8_t* rref,
+__device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint8_t* rcons, const uint8_t* ref, const uint8_t* rref,
                                                     int m, int n, const SparseWs& W, TILE& T, int16_t* reachF, int16_t* reachR,
                                                     int s_first, int lane) {
   SparseRes O;

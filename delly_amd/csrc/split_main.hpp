@@ -7,6 +7,8 @@
 // The DP passes between setup and finish are either the one-junction-per-wave passes of
 // split_kernel.hpp or the packed two-junctions-per-wave passes of split_pk.hpp.
 #pragma once
+#include <cstddef>
+
 #include "split_kernel.hpp"
 
 namespace dh {
@@ -272,47 +274,58 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     int sBeg, sEnd, eBeg, eEnd;
     if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
-    for (int q = 0; q < nseg; ++q) n += seg[q].len;
+    // (the loops over the <= 3 segments are unrolled with constant indices: a dynamically indexed Seg array lives in
+    //  scratch memory -- every lane of every wavefront stored and re-loaded it through HBM)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (q < nseg) n += seg[q].len;
     if (go && (n > STR::ref_cap || (INS && n < 3))) {  // (splitAlign indexes distRev[n-2]: n < 3 is outside its domain)
       status = DELLYHIP_E_LIMIT;
       go = false;
     }
     if (go) {
       int o = 0;
-      for (int q = 0; q < nseg; ++q) {
-        if (FAST && !seg[q].rc) dirty |= copy_letters8<false>(S.ref + o, seg[q].base + seg[q].beg, seg[q].len, lane);
-        else {
-          fill_segment(S.ref + o, seg[q], lane);
-          if (FAST) {    // (a reverse-complemented piece keeps letters outside A, C, G, T, N: check what was written)
-            __syncthreads();
-            for (int i = lane; i < seg[q].len; i += WAVE) dirty |= comp_acgtn(S.ref[o + i]) ? 0 : 1;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (q < nseg) {
+          const Seg sg = seg[q];
+          if (FAST && !sg.rc) dirty |= copy_letters8<false>(S.ref + o, sg.base + sg.beg, sg.len, lane);
+          else {
+            fill_segment(S.ref + o, sg, lane);
+            if (FAST) {    // (a reverse-complemented piece keeps letters outside A, C, G, T, N: check what was written)
+              __syncthreads();
+              for (int i = lane; i < sg.len; i += WAVE) dirty |= comp_acgtn(S.ref[o + i]) ? 0 : 1;
+            }
           }
+          o += sg.len;
         }
-        o += seg[q].len;
       }
     }
   }
   X.n = n;
   X.go = go;
   X.dirty = FAST ? (__ballot(dirty != 0) != 0ull) : 0;
-  // result defaults (everything a later stage does not overwrite)
-  if (WRITE_DEFAULTS && lane == 0) {
-    dellyhip_result R;
-    int* rp = reinterpret_cast<int*>(&R);
-#pragma unroll
-    for (unsigned q = 0; q < sizeof(R) / 4; ++q) rp[q] = 0;
-    R.svid = J.svid;
-    R.sv_start = J.sv_start;
-    R.sv_end = J.sv_end;
-    R.ins_len = J.ins_len;
-    R.score_unsplit = R.score_best = R.cons_left = R.ref_left = R.ref_right = -1;
-    R.matches = R.mismatches = -1;
-    R.cons_len = mlimit ? 0 : m;
-    R.cons_off = X.ob_off;
-    R.sr_support = support;
-    R.status = status;
-    R.ref_len = n;
-    *X.out = R;
+  // result defaults (everything a later stage does not overwrite): lane q holds dword q of the record and ONE coalesced
+  // store writes it (a local dellyhip_result filled through a pointer lived in scratch memory)
+  if (WRITE_DEFAULTS) {
+    static_assert(sizeof(dellyhip_result) % 4 == 0 && sizeof(dellyhip_result) / 4 <= WAVE, "record layout");
+    auto at = [](size_t byte_offset) { return (int)(byte_offset / 4); };
+    int v = 0;
+    v = (lane == at(offsetof(dellyhip_result, svid))) ? J.svid : v;
+    v = (lane == at(offsetof(dellyhip_result, sv_start))) ? J.sv_start : v;
+    v = (lane == at(offsetof(dellyhip_result, sv_end))) ? J.sv_end : v;
+    v = (lane == at(offsetof(dellyhip_result, ins_len))) ? J.ins_len : v;
+    v = (lane == at(offsetof(dellyhip_result, score_unsplit)) || lane == at(offsetof(dellyhip_result, score_best)) ||
+         lane == at(offsetof(dellyhip_result, cons_left)) || lane == at(offsetof(dellyhip_result, ref_left)) ||
+         lane == at(offsetof(dellyhip_result, ref_right)) || lane == at(offsetof(dellyhip_result, matches)) ||
+         lane == at(offsetof(dellyhip_result, mismatches))) ? -1 : v;
+    v = (lane == at(offsetof(dellyhip_result, cons_len))) ? (mlimit ? 0 : m) : v;
+    v = (lane == at(offsetof(dellyhip_result, cons_off))) ? (int)(uint32_t)(X.ob_off & 0xffffffffull) : v;
+    v = (lane == at(offsetof(dellyhip_result, cons_off)) + 1) ? (int)(uint32_t)(X.ob_off >> 32) : v;
+    v = (lane == at(offsetof(dellyhip_result, sr_support))) ? support : v;
+    v = (lane == at(offsetof(dellyhip_result, status))) ? status : v;
+    v = (lane == at(offsetof(dellyhip_result, ref_len))) ? n : v;
+    if (lane < (int)(sizeof(dellyhip_result) / 4)) reinterpret_cast<int*>(X.out)[lane] = v;
   }
   __syncthreads();
   if constexpr (STR::has_rc) {
