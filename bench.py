@@ -452,6 +452,26 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     return out
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on fd 1 when a communicator is created; the bench contract is ONE JSON line on stdout"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)   # (the banner sits in the C library's buffer when stdout is not a terminal)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -478,7 +498,8 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
 
     from delly_amd import build as dbuild
     from delly_amd import abi, refine, synth
@@ -512,7 +533,10 @@ def main():
         ids = [refine.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
-        comm = refine.Comm(ctx, rank, world, ids[0])
+        with _StdoutToStderr():
+            comm = refine.Comm(ctx, rank, world, ids[0])
+            if world > 1:
+                dist.barrier()   # (torch's own communicator comes up here: its banner too)
         gather_kind = ("dellyhip_gather_results: RCCL ncclSend/ncclRecv of records + consensus/allele bytes to rank 0's HBM, then D2H into "
                        "its pinned host memory, all inside the step; gather of step k-1 overlaps the kernels of step k")
         if rank == 0:

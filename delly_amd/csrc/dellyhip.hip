@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1917,6 +1918,11 @@ struct dellyhip_stream {
   // compaction + download enqueue | waiting in collect | slow-path batches (leftovers routed at collect) | blob top-ups
   double t_stage = 0, t_launch = 0, t_down = 0, t_wait = 0;
   uint64_t n_slow = 0, n_topup = 0;
+  // DELLYHIP_LOG=1: a line per collected batch on stderr in the reference's "[timestamp] stage" style (src/shortpe.h:76-77):
+  // junctions, junctions/s since the stream was created, bytes up / down
+  int log = 0;
+  double t_created = 0;
+  uint64_t log_junctions = 0, log_up = 0, log_down = 0;
 };
 static inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -2001,6 +2007,8 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   st->with_msa = with_msa;
   st->want_alignment = want_alignment ? 1 : 0;
   st->slots = std::vector<StreamSlot>((size_t)depth);
+  if (const char* t = getenv("DELLYHIP_LOG")) st->log = atoi(t);
+  st->t_created = now_s();
   {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -2183,6 +2191,20 @@ int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results
     }
     const double per = (double)H->used / (double)S.n;
     st->blob_per_junction = (st->n_collect == 0) ? per : 0.75 * st->blob_per_junction + 0.25 * per;
+  }
+  if (st->log) {
+    const uint64_t down = (S.n > 0 ? H->used : 0) + (uint64_t)S.n * sizeof(dellyhip_result);
+    st->log_junctions += (uint64_t)S.n;
+    st->log_up += S.in.used;
+    st->log_down += down;
+    time_t tt = time(nullptr);
+    struct tm tmv;
+    localtime_r(&tt, &tmv);
+    char ts[32];
+    strftime(ts, sizeof ts, "%Y-%b-%d %H:%M:%S", &tmv);
+    fprintf(stderr, "[%s] dellyhip batch %llu: %d junctions, %.0f junctions/s overall, %llu B up, %llu B down (%llu / %llu B in all)\n", ts,
+            (unsigned long long)st->n_collect, S.n, (double)st->log_junctions / std::max(now_s() - st->t_created, 1e-9), (unsigned long long)S.in.used,
+            (unsigned long long)down, (unsigned long long)st->log_up, (unsigned long long)st->log_down);
   }
   if (results) *results = reinterpret_cast<const dellyhip_result*>(S.out.p + S.o_rec);
   if (blob) *blob = reinterpret_cast<const char*>(S.out.p + S.o_blob);

@@ -101,10 +101,11 @@ struct FrGlobal16 {
 struct FrTile8 {
   const uint8_t* base;     // [level][ndp] bytes, levels 0 .. S - 2
   int ndp;
-  const uint8_t* row[2];   // LDS rows of the even / odd newest level, indexed by q
+  const uint8_t* row0;     // LDS rows of the even / odd newest level, indexed by q (two members, not an array: a
+  const uint8_t* row1;     // dynamically indexed array of pointers would live in scratch memory)
   int S;                   // newest level computed
   __device__ __forceinline__ int get(int d, int q) const {
-    return (d >= S - 1) ? (int)row[d & 1][q] - 1 : sp_ld8(base + (size_t)d * ndp + q) - 1;
+    return (d >= S - 1) ? (int)((d & 1) ? row1 : row0)[q] - 1 : sp_ld8(base + (size_t)d * ndp + q) - 1;
   }
 };
 
@@ -757,8 +758,8 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
     typedef typename std::conditional<TILED8, FrTile8, FrGlobal16>::type FRV;
     FRV frF, frR;
     if constexpr (TILED8) {
-      frF = FrTile8{reinterpret_cast<const uint8_t*>(W.frF), W.ndp, {&T.row[0][0][0] + SP_LB + 1, &T.row[0][1][0] + SP_LB + 1}, S};
-      frR = FrTile8{reinterpret_cast<const uint8_t*>(W.frR), W.ndp, {&T.row[1][0][0] + SP_LB + 1, &T.row[1][1][0] + SP_LB + 1}, S};
+      frF = FrTile8{reinterpret_cast<const uint8_t*>(W.frF), W.ndp, &T.row[0][0][0] + SP_LB + 1, &T.row[0][1][0] + SP_LB + 1, S};
+      frR = FrTile8{reinterpret_cast<const uint8_t*>(W.frR), W.ndp, &T.row[1][0][0] + SP_LB + 1, &T.row[1][1][0] + SP_LB + 1, S};
     } else {
       frF = FrGlobal16{W.frF, W.ndp};
       frR = FrGlobal16{W.frR, W.ndp};

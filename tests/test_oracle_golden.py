@@ -237,3 +237,17 @@ def test_port_long_read_insertion_loop_vs_reference(port, reference):
     pr, pb = port.refine_batch(b, params=pl)
     compare(pr, pb, rr, rb, label="port-vs-reference LR INS")
     assert int(rr["ok"].sum()) == 2
+
+
+def test_c_restatement_under_address_and_undefined_behaviour_sanitizers():
+    """SURVEY.md 5 (sanitizers): oracle/delly_oracle.c compiled with -fsanitize=address,undefined and driven over seeded junction
+    batches (msa + alignConsensus, given-consensus path, primitives at their edges) by oracle/sanitize_selftest.c"""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    r = subprocess.run(["make", "-C", here, "sanitize"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 and ("cannot find -lasan" in r.stdout or "libasan" in r.stdout and "No such file" in r.stdout):
+        import pytest
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "sanitize_selftest: done rc=0" in r.stdout
