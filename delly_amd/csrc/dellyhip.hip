@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -49,19 +50,87 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     if (_e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, #x, _e); \
   } while (0)
 
-// Owning device allocation: freed by the destructor (every struct that holds one -- batches, job lists, the
-// function-local buffers of the single-item wrappers -- releases its HBM when it goes out of scope).
+// Device memory handed back by a DevBuf goes to a process-wide free list (per device) and is handed out again, never
+// hipFree'd while the process lives (dellyhip_trim_memory does it on request).  Besides the usual reason -- hipMalloc and
+// hipFree synchronise the device -- there is a measured one (tools/stream_matrix.sh, profiles/r03/README.md): device-to-host
+// copies out of allocations made AFTER earlier allocations were freed ran at 9-34 GB/s instead of 46-58 GB/s, which cost
+// every dellyhip_stream after the first of a process a third of its throughput (16.6 vs 23-24 M junctions/s).
+struct DevPool {
+  // dirty: handed back without a synchronisation -- work enqueued by the previous owner may still touch it (hipFree used
+  // to wait implicitly).  The first reuse of a dirty block waits for the device once and clears the flag on every block.
+  struct Block { void* p; size_t bytes; int device; bool dirty; };
+  std::mutex mu;
+  std::vector<Block> free_list;
+  static DevPool& get() { static DevPool* P = new DevPool(); return *P; }   // (never destroyed: the runtime may be gone at exit)
+  static size_t round_up(size_t b) { return b <= (1u << 20) ? ((b + 255) & ~(size_t)255) : ((b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1)); }
+  void* take(size_t want, size_t* got, hipError_t* err) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    want = round_up(std::max<size_t>(want, 1));
+    {
+      std::lock_guard<std::mutex> g(mu);
+      size_t best = free_list.size();
+      for (size_t i = 0; i < free_list.size(); ++i)
+        if (free_list[i].device == dev && free_list[i].bytes >= want && free_list[i].bytes <= 2 * want + (1u << 16) &&
+            (best == free_list.size() || free_list[i].bytes < free_list[best].bytes))
+          best = i;
+      if (best != free_list.size()) {
+        Block b = free_list[best];
+        free_list.erase(free_list.begin() + (long)best);
+        if (b.dirty) {
+          (void)hipDeviceSynchronize();
+          for (auto& f : free_list)
+            if (f.device == dev) f.dirty = false;
+        }
+        *got = b.bytes;
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    *err = hipMalloc(&p, want);
+    if (*err != hipSuccess) {   // out of memory with blocks parked here: give them back and try once more
+      (void)hipGetLastError();
+      if (trim(dev) == 0) return nullptr;
+      *err = hipMalloc(&p, want);
+      if (*err != hipSuccess) return nullptr;
+    }
+    *got = want;
+    return p;
+  }
+  void give(void* p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    free_list.push_back(Block{p, bytes, dev, true});
+  }
+  size_t trim(int dev) {   // -> bytes returned to the runtime
+    std::vector<Block> mine;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size();)
+        if (free_list[i].device == dev) { mine.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); }
+        else ++i;
+    }
+    size_t bytes = 0;
+    for (auto& b : mine) { (void)hipFree(b.p); bytes += b.bytes; }
+    return bytes;
+  }
+};
+
+// Owning device allocation: released by the destructor (every struct that holds one -- batches, job lists, the
+// function-local buffers of the single-item wrappers -- gives its HBM back when it goes out of scope).
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap_bytes = 0;
   bool owned = true;   // false: p points into another allocation (the staging block of a stream slot)
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), cap_bytes(o.cap_bytes), owned(o.owned) { o.p = nullptr; o.n = 0; o.cap_bytes = 0; o.owned = true; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; }
+    if (this != &o) { release(); p = o.p; n = o.n; cap_bytes = o.cap_bytes; owned = o.owned; o.p = nullptr; o.n = 0; o.cap_bytes = 0; o.owned = true; }
     return *this;
   }
   ~DevBuf() { release(); }
@@ -69,11 +138,12 @@ struct DevBuf {
     release();
     n = count;
     if (count == 0) return 0;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) { p = nullptr; n = 0; return fail(DELLYHIP_E_NOMEM, "hipMalloc", e); }
+    hipError_t e = hipSuccess;
+    p = static_cast<T*>(DevPool::get().take(count * sizeof(T), &cap_bytes, &e));
+    if (!p) { n = 0; cap_bytes = 0; return fail(DELLYHIP_E_NOMEM, "hipMalloc", e); }
     return 0;
   }
-  // keeps the allocation when it is already large enough (hipMalloc/hipFree synchronise the device)
+  // keeps the allocation when it is already large enough
   int reserve(size_t count) { return (p && owned && n >= count) ? 0 : alloc(count); }
   // like reserve(), but a growing buffer gets 25 % head room (recycled batches of a stream: sizes wobble from batch to batch)
   int reserve_grow(size_t count) { return (p && owned && n >= count) ? 0 : alloc(count + count / 4 + 64); }
@@ -84,9 +154,10 @@ struct DevBuf {
     owned = false;
   }
   void release() {
-    if (p && owned) (void)hipFree(p);
+    if (p && owned) DevPool::get().give(p, cap_bytes);
     p = nullptr;
     n = 0;
+    cap_bytes = 0;
     owned = true;
   }
 };
@@ -810,33 +881,32 @@ __global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list,
 
 // ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
 // off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
-__global__ void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
-  // one block of 1024 threads; round k handles records k * 1024 + t (independent loads), a block scan per round carries
-  // the running total (n = 10 000: ten rounds)
-  __shared__ uint64_t part[1024];
-  __shared__ uint64_t carry;
-  const int t = threadIdx.x;
-  if (t == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + t;
-    uint64_t len = 0;
-    if (i < n) len = (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
-    part[t] = len;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan
-      const uint64_t v = (t >= d) ? part[t - d] : 0;
-      __syncthreads();
-      part[t] += v;
-      __syncthreads();
-    }
-    const uint64_t c = carry;
-    if (i < n) off[i] = c + part[t] - len;
-    __syncthreads();
-    if (t == 1023) carry = c + part[1023];
-    __syncthreads();
+__global__ __launch_bounds__(1024) void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
+  // one block of 1024 threads, thread t owns the records [t * chunk, (t + 1) * chunk): its own sum, one scan over the
+  // wavefront (shuffles) and one over the 16 wavefront totals, then its offsets (one barrier; n = 10 000: chunk = 10)
+  __shared__ uint64_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int chunk = (n + 1023) / 1024;
+  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+  auto len_of = [&](int i) {
+    return (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
+  };
+  uint64_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += len_of(i);
+  uint64_t inc = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
   }
-  if (t == 0) off[n] = carry;
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint64_t at = inc - sum;
+  for (int k = 0; k < w; ++k) at += wsum[k];
+  for (int i = lo; i < hi; ++i) {
+    off[i] = at;
+    at += len_of(i);
+  }
+  if (t == 1023) off[n] = at;
 }
 // one wavefront per junction: its three pieces, back to back, at out + off[i]
 __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n) {
@@ -855,11 +925,59 @@ __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* bl
 
 namespace {
 
-// Pinned host memory, grown geometrically and kept (hipHostMalloc / hipHostFree synchronise the device).
+// Pinned host memory, grown geometrically and kept.  Released blocks go to a process-wide free list like the device
+// blocks of DevPool (hipHostMalloc / hipHostFree synchronise the device).
+struct PinPool {
+  struct Block { void* p; size_t bytes; int device; };
+  std::mutex mu;
+  std::vector<Block> free_list;
+  static PinPool& get() { static PinPool* P = new PinPool(); return *P; }   // (never destroyed: the runtime may be gone at exit)
+  void* take(size_t want, size_t* got) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      size_t best = free_list.size();
+      for (size_t i = 0; i < free_list.size(); ++i)
+        if (free_list[i].device == dev && free_list[i].bytes >= want && free_list[i].bytes <= 4 * want + (1u << 20) &&
+            (best == free_list.size() || free_list[i].bytes < free_list[best].bytes))
+          best = i;
+      if (best != free_list.size()) {
+        Block b = free_list[best];
+        free_list.erase(free_list.begin() + (long)best);
+        *got = b.bytes;
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *got = want;
+    return p;
+  }
+  void give(void* p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    free_list.push_back(Block{p, bytes, dev});
+  }
+  size_t trim(int dev) {
+    std::vector<Block> mine;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size();)
+        if (free_list[i].device == dev) { mine.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); }
+        else ++i;
+    }
+    size_t bytes = 0;
+    for (auto& b : mine) { (void)hipHostFree(b.p); bytes += b.bytes; }
+    return bytes;
+  }
+};
 template <typename T>
 struct PinBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t bytes_ = 0;
   PinBuf() = default;
   PinBuf(const PinBuf&) = delete;
   PinBuf& operator=(const PinBuf&) = delete;
@@ -868,15 +986,16 @@ struct PinBuf {
     if (p && n >= count) return 0;
     release();
     const size_t want = count + count / 4 + 64;
-    hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
-    if (e != hipSuccess) { p = nullptr; return fail(DELLYHIP_E_NOMEM, "hipHostMalloc", e); }
-    n = want;
+    p = static_cast<T*>(PinPool::get().take(want * sizeof(T), &bytes_));
+    if (!p) return fail(DELLYHIP_E_NOMEM, "hipHostMalloc", hipErrorOutOfMemory);
+    n = bytes_ / sizeof(T);
     return 0;
   }
   void release() {
-    if (p) (void)hipHostFree(p);
+    if (p) PinPool::get().give(p, bytes_);
     p = nullptr;
     n = 0;
+    bytes_ = 0;
   }
 };
 
@@ -936,27 +1055,38 @@ void batch_reset(dellyhip_batch* b) {
 // stream slots: the compaction also emits the records as the caller sees them -- blob offsets rebased to the compact blob,
 // transient kernel state (result.reserved) cleared -- so that the host only copies
 __global__ void blob_gather_records_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out,
-                                           dellyhip_result* rec_out, int n) {
+                                           dellyhip_result* rec_out, int n, uint64_t* hdr_used, int32_t* hdr_left, const int32_t* left_counter) {
+  // the record travels as 36 dwords, one per lane (one coalesced load and store); the three offsets, `reserved` and the
+  // padding word are replaced on the way
+  constexpr int RW = (int)(sizeof(dellyhip_result) / 4);
+  constexpr int W_CONS = (int)(offsetof(dellyhip_result, cons_off) / 4), W_ALLELE = (int)(offsetof(dellyhip_result, allele_off) / 4),
+                W_ALN = (int)(offsetof(dellyhip_result, aln_off) / 4), W_RESERVED = (int)(offsetof(dellyhip_result, reserved) / 4),
+                W_PAD = (int)(offsetof(dellyhip_result, ref_len) / 4) + 1;
+  static_assert(sizeof(dellyhip_result) % 4 == 0 && RW <= dh::WAVE && W_PAD + 1 == W_CONS, "record layout");
   const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane == 0 && hdr_used) {   // head of the block the records travel in (StreamHeader): one D2H copy for both
+    *hdr_used = off[n];
+    hdr_left[0] = left_counter ? *left_counter : 0;
+    hdr_left[1] = 0;
+  }
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
-    dellyhip_result R = res[i];
+    const dellyhip_result& R = res[i];
+    uint32_t v = lane < RW ? reinterpret_cast<const uint32_t*>(res + i)[lane] : 0u;
     uint64_t at = off[i];
     uint8_t* dst = out + at;
     const uint64_t src[3] = {R.cons_off, R.allele_off, R.aln_off};
     const int len[3] = {max(R.cons_len, 0), max(R.allele_len, 0), 2 * max(R.aln_len, 0)};
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
       for (int q = lane; q < len[k]; q += dh::WAVE) dst[q] = blob[src[k] + q];
       dst += len[k];
     }
-    if (lane == 0) {
-      R.cons_off = len[0] ? at : 0;
-      at += len[0];
-      R.allele_off = len[1] ? at : 0;
-      at += len[1];
-      R.aln_off = len[2] ? at : 0;
-      R.reserved = 0;
-      rec_out[i] = R;
-    }
+    const uint64_t o0 = len[0] ? at : 0, o1 = len[1] ? at + len[0] : 0, o2 = len[2] ? at + len[0] + len[1] : 0;
+    v = lane == W_CONS ? (uint32_t)o0 : lane == W_CONS + 1 ? (uint32_t)(o0 >> 32) : v;
+    v = lane == W_ALLELE ? (uint32_t)o1 : lane == W_ALLELE + 1 ? (uint32_t)(o1 >> 32) : v;
+    v = lane == W_ALN ? (uint32_t)o2 : lane == W_ALN + 1 ? (uint32_t)(o2 >> 32) : v;
+    v = (lane == W_RESERVED || lane == W_PAD) ? 0u : v;
+    if (lane < RW) reinterpret_cast<uint32_t*>(rec_out + i)[lane] = v;
   }
 }
 
@@ -978,7 +1108,11 @@ void dellyhip_default_params_lr(dellyhip_params* p) {
   *p = dellyhip_params{5, -4, -10, -1, 3, 100, 10000, 1000, 0.9f, 0};
 }
 
-int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** out) {
+static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** out, hipStream_t borrowed);
+int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** out) { return create_ctx(params, device, out, nullptr); }
+
+// `borrowed`: the context launches on that stream and does not own it (slots of a dellyhip_stream)
+static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** out, hipStream_t borrowed) {
   if (!params || !out) return fail(DELLYHIP_E_ARG, "null argument");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -1005,23 +1139,38 @@ int dellyhip_create(const dellyhip_params* params, int device, dellyhip_ctx** ou
   if (const char* t = getenv("DELLYHIP_MSA_ONLY")) c->msa_only = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_WAVES")) c->msa_waves = std::max(1, std::min(16, atoi(t)));
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
-  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    delete c;
-    return fail(DELLYHIP_E_RUNTIME, "hipStreamCreate", e);
+  if (borrowed) {
+    c->stream = borrowed;
+    c->owns_stream = false;
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return fail(DELLYHIP_E_RUNTIME, "hipStreamCreate", e);
+    }
   }
   *out = c;
   return 0;
 }
 
-int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out) {
+static int create_shared_on(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out, hipStream_t borrowed) {
   if (!share_with || !out) return fail(DELLYHIP_E_ARG, "null argument");
   dellyhip_ctx* c = nullptr;
-  int rc = dellyhip_create(params ? params : &share_with->params, share_with->device, &c);
+  int rc = create_ctx(params ? params : &share_with->params, share_with->device, &c, borrowed);
   if (rc) return rc;
   c->chrs = share_with->chrs;
   *out = c;
   return 0;
+}
+int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out) {
+  return create_shared_on(share_with, params, out, nullptr);
+}
+
+uint64_t dellyhip_trim_memory(dellyhip_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  return (uint64_t)DevPool::get().trim(c->device) + (uint64_t)PinPool::get().trim(c->device);
 }
 
 void dellyhip_destroy(dellyhip_ctx* c) {
@@ -1890,14 +2039,27 @@ struct StreamSlot {
   dellyhip_batch* b = nullptr;
   Arena in;
   PinBuf<uint8_t> out;
-  DevBuf<dellyhip_result> d_rec;
-  hipEvent_t done = nullptr, up_done = nullptr, comp_done = nullptr;
+  DevBuf<uint8_t> d_rec;   // StreamHeader (64 bytes) | rebased records: the image of the head of the pinned block
+  hipEvent_t done = nullptr, up_done = nullptr, run_done = nullptr, comp_done = nullptr;
   int state = 0;           // 0 free, 1 submitted, 2 collected (the caller still reads its output block)
   int32_t n = 0;
   uint64_t tag = 0;
   uint64_t blob_copied = 0, blob_cap = 0;
   size_t o_rec = 0, o_len = 0, o_blob = 0;
 };
+struct DeviceStreams {
+  std::mutex mu;
+  bool made = false;
+  hipStream_t up = nullptr, down = nullptr, pack = nullptr, comp[2] = {nullptr, nullptr};
+};
+static DeviceStreams& device_streams(int device) {
+  static std::mutex mu;
+  static std::map<int, std::unique_ptr<DeviceStreams>> all;
+  std::lock_guard<std::mutex> g(mu);
+  auto& p = all[device];
+  if (!p) p.reset(new DeviceStreams());
+  return *p;
+}
 struct dellyhip_stream {
   dellyhip_ctx* parent = nullptr;
   int with_msa = 0, want_alignment = 0;
@@ -1912,6 +2074,11 @@ struct dellyhip_stream {
   // (the tail of one sparse kernel -- 2.4 wavefronts per slot at 10 000 junctions -- under the head of the next) without
   // one stream per slot competing for the four hardware queues of the normal priority.
   hipStream_t s_comp[2] = {nullptr, nullptr};
+  // The compaction kernels of a slot (offsets, gather) run on a third stream of the uploads' priority: on the slot's compute
+  // stream they sat in front of the sparse kernel of the slot after next, and -- a 1024-thread block needs room the
+  // persistent wavefronts of the NEXT slot's sparse kernel only give up in their tail -- kept it from starting: one
+  // sparse kernel at a time, 0.6 ms per batch whatever the depth (profiles/r03/stream_depth_sweep.txt).
+  hipStream_t s_pack = nullptr;
   int held = -1;                    // slot whose output the caller holds since the last collect()
   double blob_per_junction = 0;     // running estimate: bytes of compact blob per junction (sizes the first D2H copy)
   // host seconds since creation / the last dellyhip_stream_stats(reset): validation + routing + staging | kernel launches |
@@ -1937,24 +2104,33 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
   const int n = b->n;
   int rc;
   if ((rc = b->blob_off.reserve_grow((size_t)n + 1)) || (rc = b->blob_compact.reserve_grow(std::max<uint64_t>((uint64_t)n * b->out_stride, 1))) ||
-      (rc = S.d_rec.reserve_grow((size_t)std::max(n, 1))))
+      (rc = S.d_rec.reserve_grow(64 + (size_t)std::max(n, 1) * sizeof(dellyhip_result))))
     return rc;
   hipStream_t s = c->stream;
   StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
   const bool split = st->s_down && S.comp_done && !all_blob;   // (the slow path stays on the slot's own stream)
+  if (split && st->s_pack && S.run_done) {
+    HIPCHK(hipEventRecord(S.run_done, s));
+    s = st->s_pack;
+    HIPCHK(hipStreamWaitEvent(s, S.run_done, 0));
+  }
   hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_records_kernel, dim3(std::min(n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p,
-                     b->blob_off.p, b->blob_compact.p, S.d_rec.p, n);
+                     b->blob_off.p, b->blob_compact.p, reinterpret_cast<dellyhip_result*>(S.d_rec.p + 64), n,
+                     reinterpret_cast<uint64_t*>(S.d_rec.p), reinterpret_cast<int32_t*>(S.d_rec.p + 8),
+                     c->counters.p ? c->counters.p + 31 : nullptr);
   HIPCHK(hipGetLastError());
   if (split) {
     HIPCHK(hipEventRecord(S.comp_done, s));
     s = st->s_down;
     HIPCHK(hipStreamWaitEvent(s, S.comp_done, 0));
   }
-  HIPCHK(hipMemcpyAsync(&H->used, b->blob_off.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-  if (c->counters.p) HIPCHK(hipMemcpyAsync(&H->sps_left, c->counters.p + 31, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p, (size_t)n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s));
+  // header (bytes of compact blob, junctions the sparse kernel left) and records in ONE copy: small copies are blit kernels,
+  // and a blit kernel on this stream waits for room on the chip behind the persistent wavefronts of the sparse kernels --
+  // two of them per batch made this stream the bottleneck of the pipeline (0.6 ms per batch, profiles/r03/README.md)
+  static_assert(sizeof(StreamHeader) <= 64 && offsetof(StreamHeader, sps_left) == 8, "StreamHeader layout");
+  HIPCHK(hipMemcpyAsync(S.out.p, S.d_rec.p, 64 + (size_t)n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, s));
   // the blob's size is only known on the device: copy what the previous batches predict (all of it after a slow path)
   uint64_t want = all_blob ? S.blob_cap : (uint64_t)(st->blob_per_junction * 1.06 * n) + 4096;
   want = std::min<uint64_t>(std::min<uint64_t>(want, S.blob_cap), (uint64_t)n * b->out_stride);
@@ -1973,6 +2149,7 @@ int grow_out_block(StreamSlot& S, uint64_t blob_bytes) {
   memcpy(bigger.p, S.out.p, S.o_blob);
   std::swap(bigger.p, S.out.p);
   std::swap(bigger.n, S.out.n);
+  std::swap(bigger.bytes_, S.out.bytes_);
   S.blob_cap = S.out.n - S.o_blob - 64;
   if (S.b) S.b->pin_cons_len = reinterpret_cast<int32_t*>(S.out.p + S.o_len);
   return 0;
@@ -2010,29 +2187,43 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   if (const char* t = getenv("DELLYHIP_LOG")) st->log = atoi(t);
   st->t_created = now_s();
   {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (least != greatest && !getenv("DELLYHIP_STREAM_ONE_QUEUE")) {   // (numerically lower = higher priority; normal = 0 lies between)
-      if (hipStreamCreateWithPriority(&st->s_up, hipStreamNonBlocking, greatest) != hipSuccess) st->s_up = nullptr;
-      if (hipStreamCreateWithPriority(&st->s_down, hipStreamNonBlocking, least) != hipSuccess) st->s_down = nullptr;
+    // The five HIP streams of the pipelined path exist once per device and process and are never destroyed: the runtime
+    // maps HIP streams onto a few hardware queues, commands of one hardware queue execute in order, and the mapping a
+    // stream gets depends on the streams created and destroyed before it.  Measured: the first dellyhip_stream of a
+    // process ran 24.5 M junctions/s, every later one 16.6 M/s -- its upload stream shared a hardware queue with the
+    // compaction stream, whose kernels wait for the previous slot's sparse kernel (profiles/r03/README.md).
+    DeviceStreams& D = device_streams(c->device);
+    std::lock_guard<std::mutex> g(D.mu);
+    if (!D.made) {
+      D.made = true;
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      for (auto& cs : D.comp)
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) cs = nullptr;
+      if (least != greatest) {   // (numerically lower = higher priority; normal = 0 lies between)
+        const char* pp = getenv("DELLYHIP_STREAM_PACK_PRIO");
+        if (hipStreamCreateWithPriority(&D.up, hipStreamNonBlocking, greatest) != hipSuccess) D.up = nullptr;
+        if (hipStreamCreateWithPriority(&D.down, hipStreamNonBlocking, least) != hipSuccess) D.down = nullptr;
+        if (hipStreamCreateWithPriority(&D.pack, hipStreamNonBlocking, (pp && atoi(pp) == 0) ? 0 : greatest) != hipSuccess) D.pack = nullptr;
+      }
     }
+    if (!getenv("DELLYHIP_STREAM_ONE_QUEUE")) {
+      st->s_up = D.up;
+      st->s_down = D.down;
+      if (depth > 2 && !getenv("DELLYHIP_STREAM_NO_PACK")) st->s_pack = D.pack;
+    }
+    for (int q = 0; q < 2; ++q) st->s_comp[q] = D.comp[q];
   }
-  for (int q = 0; q < std::min(depth, 2); ++q)
-    if (hipStreamCreateWithFlags(&st->s_comp[q], hipStreamNonBlocking) != hipSuccess) st->s_comp[q] = nullptr;
   int slot_index = 0;
   for (auto& S : st->slots) {
-    int rc = dellyhip_create_shared(c, &c->params, &S.ctx);
-    if (!rc && st->s_comp[slot_index & 1]) {
-      (void)hipStreamDestroy(S.ctx->stream);
-      S.ctx->stream = st->s_comp[slot_index & 1];
-      S.ctx->owns_stream = false;
-    }
+    int rc = create_shared_on(c, &c->params, &S.ctx, st->s_comp[slot_index & 1]);
     ++slot_index;
     if (!rc) {
       S.b = new dellyhip_batch();
       hipError_t e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&S.up_done, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&S.comp_done, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&S.run_done, hipEventDisableTiming);
       if (e != hipSuccess) rc = fail(DELLYHIP_E_RUNTIME, "hipEventCreate", e);
     }
     if (rc) {
@@ -2053,6 +2244,7 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
   if (!st) return;
   if (st->s_up) (void)hipStreamSynchronize(st->s_up);
   if (st->s_down) (void)hipStreamSynchronize(st->s_down);
+  if (st->s_pack) (void)hipStreamSynchronize(st->s_pack);
   for (auto& S : st->slots) {
     if (S.ctx) {
       (void)hipSetDevice(S.ctx->device);
@@ -2062,15 +2254,12 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
     if (S.done) (void)hipEventDestroy(S.done);
     if (S.up_done) (void)hipEventDestroy(S.up_done);
     if (S.comp_done) (void)hipEventDestroy(S.comp_done);
+    if (S.run_done) (void)hipEventDestroy(S.run_done);
     S.in.d.release();
     S.d_rec.release();
     if (S.ctx) dellyhip_destroy(S.ctx);
   }
-  if (st->s_up) (void)hipStreamDestroy(st->s_up);
-  if (st->s_down) (void)hipStreamDestroy(st->s_down);
-  for (auto& cs : st->s_comp)
-    if (cs) (void)hipStreamDestroy(cs);
-  delete st;
+  delete st;   // (the HIP streams belong to the device: device_streams)
 }
 
 int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_junction* junc, const char* seq_blob, const uint64_t* seq_off,
@@ -2181,7 +2370,7 @@ int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results
         if (rc2) return rc2;
         H = reinterpret_cast<StreamHeader*>(S.out.p);
         S.blob_copied = 0;   // (the block moved: records and blob again)
-        HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p, (size_t)S.n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(S.out.p + S.o_rec, S.d_rec.p + 64, (size_t)S.n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
         H->used = used;
       }
       HIPCHK(hipMemcpyAsync(S.out.p + S.o_blob + S.blob_copied, b->blob_compact.p + S.blob_copied, H->used - S.blob_copied,

@@ -33,7 +33,7 @@ EXPORTS = [
     "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
-    "dellyhip_create_shared", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
+    "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
     "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
 ]
 
@@ -63,6 +63,8 @@ def load_library():
         lib.dellyhip_stream_destroy.restype = None
         lib.dellyhip_stream_release.restype = None
         lib.dellyhip_stream_stats.restype = None
+        lib.dellyhip_trim_memory.restype = C.c_uint64
+        lib.dellyhip_trim_memory.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -146,6 +148,10 @@ class Context:
         if self._ctx:
             self.lib.dellyhip_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def trim_memory(self):
+        """returns the device / pinned blocks the library keeps parked to the HIP runtime (dellyhip_trim_memory) -> bytes"""
+        return int(self.lib.dellyhip_trim_memory(self._ctx))
 
     def __del__(self):
         try:

@@ -132,6 +132,14 @@ void dellyhip_default_params_lr(dellyhip_params* p);
  * context per thread, ONE copy of the genome per GPU. */
 int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out);
 
+/* Memory policy: device and pinned host blocks the library releases (freed batches, destroyed contexts and streams)
+ * are parked in a process-wide free list per device and handed out again -- they are not returned to the HIP runtime
+ * while the process lives, so the footprint is the high-water mark of what was alive at once.  (hipMalloc / hipFree
+ * synchronise the device, and allocations made after earlier ones were freed were measured to download at a fraction
+ * of the PCIe rate: DESIGN.md 1b.)  dellyhip_trim_memory waits for the device, returns every parked block of ctx's
+ * device to the runtime and reports the bytes released. */
+uint64_t dellyhip_trim_memory(dellyhip_ctx* ctx);
+
 /* Keeps chromosome `chr` resident in HBM.  Replaces the per-chromosome
  * faidx_fetch_seq() buffer `seq` that src/shortpe.h:88 hands to
  * alignConsensus(c, hdr, seq, sndSeq, sv), and hdr->target_len[chr]

@@ -105,3 +105,36 @@ def test_rccl_communicator_of_one_rank(gpu_ctx):
     assert r.shape[0] == 16 and counts.tolist() == [16] and int(r["ok"].sum()) >= 14
     comm.close()
     rb.free()
+
+
+def test_parked_memory_is_reused_and_can_be_returned():
+    """the library parks released device / pinned blocks (include/dellyhip.h, memory policy): a second stream of the same
+    shape allocates nothing new, dellyhip_trim_memory hands everything back"""
+    b = synth.make_batch(400, mode="c2", seed=11)
+    ctx = refine.Context()
+    ctx.set_chromosomes(b.chroms)
+    ctx.trim_memory()
+
+    def lap():
+        st = refine.Stream(ctx, depth=2)
+        st.submit(b)
+        st.submit(b)
+        r0 = st.collect()[0]
+        r1 = st.collect()[0]
+        st.close()
+        return r0, r1
+
+    r0, r1 = lap()
+    after_first = _free_bytes()
+    r2, r3 = lap()
+    after_second = _free_bytes()
+    assert after_first - after_second < (1 << 20), "the second stream allocated %d new bytes" % (after_first - after_second)
+    for r in (r1, r2, r3):
+        assert all(np.array_equal(r0[f], r[f]) for f in r0.dtype.names)
+    released = ctx.trim_memory()
+    assert released > (64 << 20)              # (two slots: scratch areas, output blocks, staging arenas)
+    assert _free_bytes() - after_second > (64 << 20)
+    assert ctx.trim_memory() == 0
+    r4, _ = ctx.refine(b)                     # and the library works on after a trim
+    assert all(np.array_equal(r0[f], r4[f]) for f in r0.dtype.names)
+    ctx.close()

@@ -92,17 +92,23 @@ def test_long_read_sparse_vs_dense_strips():
 def test_unsplit_score_is_known_and_exact_when_there_is_no_split(port):
     """needle.h:152: a consensus that aligns without a split (the false-positive candidate) makes longNeedle return false
     BECAUSE bestScore == mat[m][n] -- on the sparse path that value comes from the first level whose furthest row reaches m,
-    so for these junctions score_unsplit must be reported (not DELLYHIP_SCORE_UNKNOWN) and equal the dense matrices' value"""
+    so for these junctions score_unsplit must be reported (not DELLYHIP_SCORE_UNKNOWN) and equal the dense matrices' value.
+    (A pure-reference consensus with a substitution near one end can still split at a smaller deficit than it aligns
+    whole -- a three-base tail matching somewhere downstream; longNeedle returns true there, the later filters reject it,
+    and score_unsplit may stay unknown: the level that reaches row m was never needed.)"""
     from util import SCORE_UNKNOWN
     b = synth.make_batch(3000, mode="c2", seed=9)
     noref = np.array([t["kind"] == "noref" for t in b.truth])
     sub = synth.subset(b, np.nonzero(noref)[0])
     assert sub.n >= 25
-    sub = _noisy(sub, 0.01, 3)                      # (half of them with a few substitutions: deficit > 0, still no split)
+    sub = _noisy(sub, 0.01, 3)                      # (most of them with a few substitutions: deficit > 0)
     gs, bs = _refine(sub, {"DELLYHIP_SR_SPARSE": "1"}, False)
     pr, pb = port.refine_batch(sub)
     assert (pr["ok"] == 0).all() and (gs["ok"] == 0).all()
-    assert (gs["score_unsplit"] != SCORE_UNKNOWN).all()
-    assert (gs["score_unsplit"] == pr["score_unsplit"]).all()
+    nosplit = pr["score_best"] == pr["score_unsplit"]          # longNeedle returned false (needle.h:152)
+    assert int(nosplit.sum()) >= sub.n // 2 and int((pr["score_unsplit"][nosplit] < pr["cons_len"][nosplit]).sum()) >= 5
+    assert (gs["score_unsplit"][nosplit] == pr["score_unsplit"][nosplit]).all()
+    known = gs["score_unsplit"] != SCORE_UNKNOWN
+    assert (gs["score_unsplit"][known] == pr["score_unsplit"][known]).all()
     assert (gs["score_best"] == pr["score_best"]).all()
     compare(gs, bs, pr, pb, fields=_fields(False), blobs=("cons", "allele"), label="no-split junctions")

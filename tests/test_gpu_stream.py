@@ -163,3 +163,70 @@ def test_stream_slot_discipline_and_shared_chromosomes():
     assert int(r3["ok"].sum()) == ok0
     c2.close()
     ctx.close()
+
+
+def _same(a, b):
+    """record arrays equal field by field (numpy does not carry the padding bytes of the record through .copy())"""
+    return a.shape == b.shape and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def test_stream_survives_a_rejected_batch_and_an_empty_one():
+    good = synth.make_batch(300, mode="c2", seed=21)
+    ctx = refine.Context()
+    ctx.set_chromosomes(good.chroms)
+    want_res, want_blob = ctx.refine(good)
+    bad_j = good.junctions.copy()
+    bad_j["sv_start"][5] = -3                # malformed record: rejected before any kernel sees the batch
+    bad = synth.Batch(good.chroms, bad_j, good.seq_blob, good.seq_off, good.with_msa, good.truth)
+    empty = synth.Batch(good.chroms, good.junctions[:0].copy(), good.seq_blob[:0].copy(), good.seq_off[:1].copy(),
+                        good.with_msa, None)
+    st = refine.Stream(ctx, depth=2)
+    st.submit(good, tag=1)
+    with pytest.raises(refine.DellyHipError) as e:
+        st.submit(bad, tag=2)
+    assert e.value.code == abi.E_ARG
+    assert st.pending() == 1                 # the rejected batch took no slot
+    st.submit(empty, tag=3)
+    st_res, st_blob, tag = st.collect()
+    assert tag == 1 and _same(st_res, want_res) and st_blob.tobytes() == want_blob.tobytes()
+    r, b, tag = st.collect()
+    assert tag == 3 and r.size == 0 and b.size == 0
+    st.submit(good, tag=4)                   # and the stream goes on
+    st_res, st_blob, tag = st.collect()
+    assert tag == 4 and _same(st_res, want_res) and st_blob.tobytes() == want_blob.tobytes()
+    st.close()
+    ctx.close()
+
+
+def test_stream_holds_its_memory_over_many_batches_of_changing_size():
+    import torch
+    sizes = [900, 40, 2500, 1, 700, 1800]
+    batches = [synth.make_batch(n, mode="c2", seed=30 + i) for i, n in enumerate(sizes)]
+    chroms, batches = _one_genome(batches)
+    ctx = refine.Context()
+    ctx.set_chromosomes(chroms)
+    classic = [ctx.refine(b) for b in batches]
+    st = refine.Stream(ctx, depth=3)
+
+    def lap():
+        got = []
+        for k in range(len(batches) + 2):
+            if k < len(batches):
+                st.submit(batches[k], tag=k)
+            if k >= 2:
+                got.append(st.collect())
+        return got
+
+    for _ in range(2):                       # slots reach their high-water sizes
+        lap()
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        got = lap()
+    torch.cuda.synchronize()
+    after = torch.cuda.mem_get_info()[0]
+    assert before - after < (4 << 20), "stream grew by %d bytes over 36 batches" % (before - after)
+    for k, (r, bl, tag) in enumerate(got):
+        assert tag == k and _same(r, classic[k][0]) and bl.tobytes() == classic[k][1].tobytes()
+    st.close()
+    ctx.close()

@@ -27,6 +27,9 @@ def one_genome(batches):
     return chroms, out
 
 
+KEPT = []
+
+
 def stream_rate(ctx, batches, with_msa, depth, total, want_alignment=False):
     """-> dict: junctions/s over `total` submitted batches (cycling through `batches`), host-inclusive"""
     st = refine.Stream(ctx, depth=depth, with_msa=with_msa, want_alignment=want_alignment)
@@ -60,7 +63,10 @@ def stream_rate(ctx, batches, with_msa, depth, total, want_alignment=False):
     nj, nb = run(total)
     dt = time.perf_counter() - t0
     stats = st.stats()
-    st.close()
+    if os.environ.get("BENCH_STREAM_KEEP"):
+        KEPT.append(st)
+    else:
+        st.close()
     up = sum(a[5][0].nbytes + a[5][1].nbytes + a[5][2].nbytes for a in args) / len(args)
     return {"junctions_per_s": nj / dt, "batches": total, "junctions_per_batch": nj / total, "wall_s": dt, "ms_per_batch": dt / total * 1e3,
             "host_ms_per_batch": {k: (v / total * 1e3 if k.endswith("_s") else v) for k, v in stats.items()},
@@ -77,6 +83,7 @@ def main():
     ap.add_argument("--n-reads", type=int, default=0)
     ap.add_argument("--sub-rate", type=float, default=0.005)
     ap.add_argument("--only-depth", type=int, default=0)
+    ap.add_argument("--depths", default="", help="comma-separated list of depths instead of 1,2,3,--depth")
     args = ap.parse_args()
     lr = args.mode.startswith("lr")
     params = abi.params_lr(realign=True) if lr else abi.params_sr()
@@ -85,8 +92,9 @@ def main():
     ctx = refine.Context(params=params)
     ctx.set_chromosomes(chroms)
     out = {}
-    for depth in ([args.only_depth] if args.only_depth else sorted(set([1, 2, 3, args.depth]))):
-        out["depth_%d" % depth] = stream_rate(ctx, batches, raw[0].with_msa, depth, args.batches)
+    depths = [int(x) for x in args.depths.split(",")] if args.depths else ([args.only_depth] if args.only_depth else sorted(set([1, 2, 3, args.depth])))
+    for depth in depths:
+        out["depth_%d%s" % (depth, "" if ("depth_%d" % depth) not in out else "_again")] = stream_rate(ctx, batches, raw[0].with_msa, depth, args.batches)
     print(json.dumps(out))
     ctx.close()
 

@@ -3,6 +3,6 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/trace_stream
 cd /tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/trace_stream -o t -- python $R/tools/bench_stream.py --batches 40 --only-depth ${DEPTH:-4} "$@" > $R/gpurun_out/trace_stream/run.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/trace_stream -o t -- python $R/tools/bench_stream.py --batches ${BATCHES:-40} ${DEPTHS:---only-depth ${DEPTH:-4}} "$@" > $R/gpurun_out/trace_stream/run.log 2>&1
 cd $R
 python tools/trace_overlap.py gpurun_out/trace_stream
