@@ -57,7 +57,7 @@ SIDE_PLAN_BIG = (("lr_c4_align_consensus_8k", 8192, 0, dict(mode="lr", sub_rate=
 
 RESIDENT_BATCHES = 4          # distinct resident batches the timed steps rotate through
 HOST_INCLUSIVE_SECONDS = 1.0  # wall time of the pipelined host-buffer measurement
-STREAM_DEPTH = 4
+STREAM_DEPTH = 6
 
 # deficit sweep: the C2 shape under different consensus / genome content.  The sparse longNeedle's cost
 # grows with a junction's deficit (errors between consensus and reference); the reference's does not (src/needle.h:64-115

@@ -115,6 +115,30 @@ struct DevPool {
     for (auto& b : mine) { (void)hipFree(b.p); bytes += b.bytes; }
     return bytes;
   }
+  // hipMalloc / hipFree shaped front end (dev_pool.hpp): the block sizes are remembered here
+  std::map<void*, size_t> live;
+  hipError_t raw_alloc(void** out, size_t bytes) {
+    hipError_t e = hipSuccess;
+    size_t got = 0;
+    void* p = take(bytes, &got, &e);
+    if (!p) { *out = nullptr; return e == hipSuccess ? hipErrorOutOfMemory : e; }
+    std::lock_guard<std::mutex> g(mu);
+    live[p] = got;
+    *out = p;
+    return hipSuccess;
+  }
+  void raw_free(void* p) {
+    if (!p) return;
+    size_t bytes = 0;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = live.find(p);
+      if (it == live.end()) return;
+      bytes = it->second;
+      live.erase(it);
+    }
+    give(p, bytes);
+  }
 };
 
 // Owning device allocation: released by the destructor (every struct that holds one -- batches, job lists, the
@@ -164,6 +188,11 @@ struct DevBuf {
 
 }  // namespace
 
+namespace dh {
+hipError_t dev_alloc(void** p, size_t bytes) { return DevPool::get().raw_alloc(p, bytes); }
+void dev_free(void* p) { DevPool::get().raw_free(p); }
+}  // namespace dh
+
 // The resident chromosomes of one device.  Shared (ref-counted) by every context created with dellyhip_create_shared:
 // the worker threads of the reference's ThreadPool (src/shortpe.h:175-201) and the slots of a dellyhip_stream all see ONE
 // copy of the genome (3.1 GB), not one per context.
@@ -176,7 +205,7 @@ struct ChrTable {
   ~ChrTable() {
     (void)hipSetDevice(device);
     for (auto p : dev)
-      if (p) (void)hipFree(p);
+      if (p) dh::dev_free(p);
   }
 };
 
@@ -1194,11 +1223,11 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
   if (!c || chr < 0 || len < 0 || (!seq && len)) return fail(DELLYHIP_E_ARG, "bad chromosome");
   HIPCHK(hipSetDevice(c->device));
   uint8_t* d = nullptr;   // allocate and fill the new buffer first: a failure leaves the old chromosome in place
-  hipError_t e = hipMalloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
+  hipError_t e = dh::dev_alloc((void**)&d, (size_t)std::max<int64_t>(len, 1));
   if (e != hipSuccess) return fail(DELLYHIP_E_NOMEM, "hipMalloc(chromosome)", e);
   if (len) {
     e = hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(d); return fail(DELLYHIP_E_RUNTIME, "H2D chromosome", e); }
+    if (e != hipSuccess) { dh::dev_free(d); return fail(DELLYHIP_E_RUNTIME, "H2D chromosome", e); }
   }
   {
     std::lock_guard<std::mutex> g(c->chrs->mu);
@@ -1209,7 +1238,7 @@ int dellyhip_set_chromosome(dellyhip_ctx* c, int32_t chr, const char* seq, int64
     }
     if (T.dev[chr]) {
       (void)hipDeviceSynchronize();   // (a kernel of any context sharing the table may still read the old copy)
-      (void)hipFree(T.dev[chr]);
+      dh::dev_free(T.dev[chr]);
     }
     T.dev[chr] = d;
     T.len[chr] = len;
@@ -2040,17 +2069,42 @@ struct StreamSlot {
   Arena in;
   PinBuf<uint8_t> out;
   DevBuf<uint8_t> d_rec;   // StreamHeader (64 bytes) | rebased records: the image of the head of the pinned block
-  hipEvent_t done = nullptr, up_done = nullptr, run_done = nullptr, comp_done = nullptr;
+  hipEvent_t done = nullptr, up_done = nullptr, comp_done = nullptr;
   int state = 0;           // 0 free, 1 submitted, 2 collected (the caller still reads its output block)
+  bool down_pending = false;   // compaction enqueued, D2H copies not yet (slot_pump enqueues them once comp_done has fired)
   int32_t n = 0;
   uint64_t tag = 0;
   uint64_t blob_copied = 0, blob_cap = 0;
   size_t o_rec = 0, o_len = 0, o_blob = 0;
 };
+// ---- do two HIP streams run concurrently?  (they do not when the runtime mapped them onto one hardware queue) --------------
+__global__ void probe_wait_kernel(int* flag, int* out, long long max_ticks) {
+  const long long t0 = wall_clock64();   // 100 MHz
+  int seen = 0;
+  while (!seen && wall_clock64() - t0 < max_ticks) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *out = seen;
+}
+__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// a waits (at most 0.5 ms) for a flag that only a kernel on b sets: true = b's kernel ran while a's was running
+static bool streams_run_concurrently(hipStream_t a, hipStream_t b, int* scratch2) {
+  if (hipMemsetAsync(scratch2, 0, 2 * sizeof(int), a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) return false;
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, a, scratch2, scratch2 + 1, 50000ll);
+  hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, b, scratch2);
+  int seen = 0;
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+      hipMemcpy(&seen, scratch2 + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return seen != 0;
+}
+
 struct DeviceStreams {
   std::mutex mu;
   bool made = false;
-  hipStream_t up = nullptr, down = nullptr, pack = nullptr, comp[2] = {nullptr, nullptr};
+  hipStream_t up = nullptr, down = nullptr, comp[2] = {nullptr, nullptr};
+  int probed_pairs = 0;   // candidate streams created until two ran concurrently
 };
 static DeviceStreams& device_streams(int device) {
   static std::mutex mu;
@@ -2074,11 +2128,9 @@ struct dellyhip_stream {
   // (the tail of one sparse kernel -- 2.4 wavefronts per slot at 10 000 junctions -- under the head of the next) without
   // one stream per slot competing for the four hardware queues of the normal priority.
   hipStream_t s_comp[2] = {nullptr, nullptr};
-  // The compaction kernels of a slot (offsets, gather) run on a third stream of the uploads' priority: on the slot's compute
-  // stream they sat in front of the sparse kernel of the slot after next, and -- a 1024-thread block needs room the
-  // persistent wavefronts of the NEXT slot's sparse kernel only give up in their tail -- kept it from starting: one
-  // sparse kernel at a time, 0.6 ms per batch whatever the depth (profiles/r03/stream_depth_sweep.txt).
-  hipStream_t s_pack = nullptr;
+  // (The compaction kernels of a slot stay on its compute stream.  A third stream for them was tried in round 3 --
+  // so that the sparse kernel of the slot after next need not wait for them -- and lost: 24 M junctions/s against 29.5,
+  // tools/stream_matrix.sh.)
   int held = -1;                    // slot whose output the caller holds since the last collect()
   double blob_per_junction = 0;     // running estimate: bytes of compact blob per junction (sizes the first D2H copy)
   // host seconds since creation / the last dellyhip_stream_stats(reset): validation + routing + staging | kernel launches |
@@ -2097,6 +2149,8 @@ static inline double now_s() {
 
 namespace {
 
+int slot_download(dellyhip_stream* st, StreamSlot& S, bool all_blob, hipStream_t s);
+
 // offsets + gather + rebased records of slot S on its stream, then the D2H copies into the pinned block
 int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob) {
   dellyhip_ctx* c = S.ctx;
@@ -2107,13 +2161,7 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
       (rc = S.d_rec.reserve_grow(64 + (size_t)std::max(n, 1) * sizeof(dellyhip_result))))
     return rc;
   hipStream_t s = c->stream;
-  StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
   const bool split = st->s_down && S.comp_done && !all_blob;   // (the slow path stays on the slot's own stream)
-  if (split && st->s_pack && S.run_done) {
-    HIPCHK(hipEventRecord(S.run_done, s));
-    s = st->s_pack;
-    HIPCHK(hipStreamWaitEvent(s, S.run_done, 0));
-  }
   hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_records_kernel, dim3(std::min(n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p,
@@ -2123,9 +2171,27 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
   HIPCHK(hipGetLastError());
   if (split) {
     HIPCHK(hipEventRecord(S.comp_done, s));
-    s = st->s_down;
-    HIPCHK(hipStreamWaitEvent(s, S.comp_done, 0));
+    // The copies are NOT enqueued here: the runtime hands a copy and the signal it waits for to an SDMA ring, a waiting
+    // copy stalls every copy behind it in that ring -- the uploads of the following slots included (traced: each H2D
+    // started 10-16 us after the previous slot's D2H had finished, so one sparse kernel ran at a time whatever the depth).
+    // slot_pump() enqueues them once comp_done has fired: nothing in the ring ever waits.
+    static const bool eager = getenv("DELLYHIP_STREAM_EAGER_DOWN") != nullptr;   // (measurement knob: the round-3a behaviour)
+    if (eager) {
+      HIPCHK(hipStreamWaitEvent(st->s_down, S.comp_done, 0));
+      return slot_download(st, S, false, st->s_down);
+    }
+    S.down_pending = true;
+    return 0;
   }
+  return slot_download(st, S, all_blob, s);
+}
+
+// the D2H copies of slot S into its pinned block
+int slot_download(dellyhip_stream* st, StreamSlot& S, bool all_blob, hipStream_t s) {
+  dellyhip_batch* b = S.b;
+  const int n = b->n;
+  StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
+  S.down_pending = false;
   // header (bytes of compact blob, junctions the sparse kernel left) and records in ONE copy: small copies are blit kernels,
   // and a blit kernel on this stream waits for room on the chip behind the persistent wavefronts of the sparse kernels --
   // two of them per batch made this stream the bottleneck of the pipeline (0.6 ms per batch, profiles/r03/README.md)
@@ -2138,6 +2204,23 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
   S.blob_copied = want;
   if (want) HIPCHK(hipMemcpyAsync(S.out.p + S.o_blob, b->blob_compact.p, want, hipMemcpyDeviceToHost, s));
   HIPCHK(hipEventRecord(S.done, s));
+  return 0;
+}
+
+// enqueues the downloads of every submitted slot whose compaction has finished (oldest first); `must` = this slot's
+// download is needed now: wait for its compaction
+int slot_pump(dellyhip_stream* st, StreamSlot* must) {
+  for (uint64_t k = st->n_collect; k < st->n_submit; ++k) {
+    StreamSlot& S = st->slots[k % st->slots.size()];
+    if (!S.down_pending) continue;
+    if (&S == must) HIPCHK(hipEventSynchronize(S.comp_done));
+    else if (hipEventQuery(S.comp_done) != hipSuccess) {
+      (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+      continue;
+    }
+    int rc = slot_download(st, S, false, st->s_down);
+    if (rc) return rc;
+  }
   return 0;
 }
 
@@ -2187,30 +2270,51 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   if (const char* t = getenv("DELLYHIP_LOG")) st->log = atoi(t);
   st->t_created = now_s();
   {
-    // The five HIP streams of the pipelined path exist once per device and process and are never destroyed: the runtime
+    // The four HIP streams of the pipelined path exist once per device and process and are never destroyed: the runtime
     // maps HIP streams onto a few hardware queues, commands of one hardware queue execute in order, and the mapping a
-    // stream gets depends on the streams created and destroyed before it.  Measured: the first dellyhip_stream of a
-    // process ran 24.5 M junctions/s, every later one 16.6 M/s -- its upload stream shared a hardware queue with the
-    // compaction stream, whose kernels wait for the previous slot's sparse kernel (profiles/r03/README.md).
+    // stream gets depends on the streams created and destroyed before it.
     DeviceStreams& D = device_streams(c->device);
     std::lock_guard<std::mutex> g(D.mu);
     if (!D.made) {
       D.made = true;
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      for (auto& cs : D.comp)
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) cs = nullptr;
+      // Two compute streams that really run side by side: with more HIP streams alive than hardware queues
+      // (GPU_MAX_HW_QUEUES, 4 by default -- a torch.cuda.Stream() alone creates a pool of 32) two consecutively created
+      // streams can share a queue, and the sparse kernels of consecutive slots then run one after the other: 19.4 instead of
+      // 32.5 M junctions/s (tools/stream_matrix.sh).  Candidates are probed pairwise; the spare ones stay allocated
+      // (destroying them would shift the mapping of streams created later).
+      {
+        hipStream_t cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        int ncand = 0;
+        for (; ncand < 2; ++ncand)
+          if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
+        int* probe = nullptr;
+        int a = 0, b = 1;
+        if (ncand == 2 && !getenv("DELLYHIP_STREAM_NO_PROBE") && dh::dev_alloc((void**)&probe, 2 * sizeof(int)) == hipSuccess) {
+          bool ok = streams_run_concurrently(cand[0], cand[1], probe);
+          while (!ok && ncand < 8) {
+            if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
+            ++ncand;
+            for (int i = 0; i + 1 < ncand && !ok; ++i)
+              if (streams_run_concurrently(cand[i], cand[ncand - 1], probe)) { ok = true; a = i; b = ncand - 1; }
+          }
+          if (!ok) { a = 0; b = 1; }
+          (void)hipDeviceSynchronize();
+          dh::dev_free(probe);
+        }
+        D.comp[0] = cand[a];
+        D.comp[1] = ncand >= 2 ? cand[b] : nullptr;
+        D.probed_pairs = ncand;
+      }
       if (least != greatest) {   // (numerically lower = higher priority; normal = 0 lies between)
-        const char* pp = getenv("DELLYHIP_STREAM_PACK_PRIO");
         if (hipStreamCreateWithPriority(&D.up, hipStreamNonBlocking, greatest) != hipSuccess) D.up = nullptr;
         if (hipStreamCreateWithPriority(&D.down, hipStreamNonBlocking, least) != hipSuccess) D.down = nullptr;
-        if (hipStreamCreateWithPriority(&D.pack, hipStreamNonBlocking, (pp && atoi(pp) == 0) ? 0 : greatest) != hipSuccess) D.pack = nullptr;
       }
     }
     if (!getenv("DELLYHIP_STREAM_ONE_QUEUE")) {
       st->s_up = D.up;
       st->s_down = D.down;
-      if (depth > 2 && !getenv("DELLYHIP_STREAM_NO_PACK")) st->s_pack = D.pack;
     }
     for (int q = 0; q < 2; ++q) st->s_comp[q] = D.comp[q];
   }
@@ -2223,7 +2327,6 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
       hipError_t e = hipEventCreateWithFlags(&S.done, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&S.up_done, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&S.comp_done, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&S.run_done, hipEventDisableTiming);
       if (e != hipSuccess) rc = fail(DELLYHIP_E_RUNTIME, "hipEventCreate", e);
     }
     if (rc) {
@@ -2233,7 +2336,11 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // the tuning knobs of the parent (they are read from the environment at dellyhip_create: same values, but a caller
     // may have changed the parent's since)
     S.ctx->sr_sparse = c->sr_sparse; S.ctx->use_sparse = c->use_sparse; S.ctx->use_quad = c->use_quad; S.ctx->quad_mix = c->quad_mix;
-    S.ctx->sps_waves = c->sps_waves; S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
+    // 12 of the 16 wavefront slots of a CU for a slot's persistent sparse kernel: the next slot's kernel (the other compute
+    // stream), the compaction kernels and the memsets find room at once instead of in the kernel's tail -- 32.4 against
+    // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
+    S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
+    S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
     S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only;
   }
   *out = st.release();
@@ -2244,7 +2351,6 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
   if (!st) return;
   if (st->s_up) (void)hipStreamSynchronize(st->s_up);
   if (st->s_down) (void)hipStreamSynchronize(st->s_down);
-  if (st->s_pack) (void)hipStreamSynchronize(st->s_pack);
   for (auto& S : st->slots) {
     if (S.ctx) {
       (void)hipSetDevice(S.ctx->device);
@@ -2254,7 +2360,6 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
     if (S.done) (void)hipEventDestroy(S.done);
     if (S.up_done) (void)hipEventDestroy(S.up_done);
     if (S.comp_done) (void)hipEventDestroy(S.comp_done);
-    if (S.run_done) (void)hipEventDestroy(S.run_done);
     S.in.d.release();
     S.d_rec.release();
     if (S.ctx) dellyhip_destroy(S.ctx);
@@ -2277,7 +2382,9 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   o.up_done = S.up_done;
   dellyhip_batch* b = nullptr;
   const double t0 = now_s();
-  int rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, st->with_msa, st->want_alignment, &b, &o);
+  int rc = slot_pump(st, nullptr);
+  if (rc) return rc;
+  rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, st->with_msa, st->want_alignment, &b, &o);
   if (rc) return rc;
   // pinned output block: header | records | consensus lengths (msa) | compact blob (at most every slot full)
   S.n = n;
@@ -2302,12 +2409,13 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
     t2 = now_s();
     if ((rc = slot_compact_and_download(st, S, false))) return rc;
   }
+  S.state = 1;
+  ++st->n_submit;
+  if ((rc = slot_pump(st, nullptr))) return rc;
   const double t3 = now_s();
   st->t_stage += t1 - t0;
   st->t_launch += t2 - t1;
   st->t_down += t3 - t2;
-  S.state = 1;
-  ++st->n_submit;
   return 0;
 }
 
@@ -2342,6 +2450,10 @@ int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results
   StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
   if (S.n > 0) {
     const double tw0 = now_s();
+    {
+      int rcp = slot_pump(st, &S);
+      if (rcp) return rcp;
+    }
     HIPCHK(hipEventSynchronize(S.done));
     st->t_wait += now_s() - tw0;
     int rc = dellyhip_batch_sync(c, b);

@@ -16,6 +16,7 @@
 // so only the non-zero entries are visited (in the same order).  Built with
 // -ffp-contract=off: no FMA contraction, like the reference's x86-64 build.
 #pragma once
+#include "dev_pool.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -273,8 +274,8 @@ inline int msa_single_lcs(hipStream_t s, const char* s1, int m, const char* s2, 
   if (m > msa_big::RLMAX) return DELLYHIP_E_LIMIT;
   uint8_t *d1 = nullptr, *d2 = nullptr;
   int* dout = nullptr;
-  if (hipMalloc((void**)&d1, std::max(m, 1) + 8) != hipSuccess || hipMalloc((void**)&d2, std::max(n, 1) + 8) != hipSuccess ||   // (+8: quadword reads)
-      hipMalloc((void**)&dout, 4) != hipSuccess)
+  if (dev_alloc((void**)&d1, std::max(m, 1) + 8) != hipSuccess || dev_alloc((void**)&d2, std::max(n, 1) + 8) != hipSuccess ||   // (+8: quadword reads)
+      dev_alloc((void**)&dout, 4) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(d1, s1, m, hipMemcpyHostToDevice);
   (void)hipMemcpy(d2, s2, n, hipMemcpyHostToDevice);
@@ -282,9 +283,9 @@ inline int msa_single_lcs(hipStream_t s, const char* s1, int m, const char* s2, 
   else hipLaunchKernelGGL(msa_big::lcs_single_kernel, dim3(1), dim3(WAVE), 0, s, d1, m, d2, n, dout);
   hipError_t e = hipStreamSynchronize(s);
   (void)hipMemcpy(out, dout, 4, hipMemcpyDeviceToHost);
-  (void)hipFree(d1);
-  (void)hipFree(d2);
-  (void)hipFree(dout);
+  dev_free(d1);
+  dev_free(d2);
+  dev_free(dout);
   return e == hipSuccess ? 0 : DELLYHIP_E_RUNTIME;
 }
 
@@ -297,9 +298,9 @@ inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, int tmax, c
   uint8_t *d1 = nullptr, *d2 = nullptr, *dout = nullptr, *ws = nullptr;
   int* dinfo = nullptr;
   size_t wsb = big ? msa_big::MsaWs::bytes(2) : MsaWs::bytes(2);
-  if (hipMalloc((void**)&d1, std::max(r1 * m, 1)) != hipSuccess || hipMalloc((void**)&d2, std::max(r2 * n, 1)) != hipSuccess ||
-      hipMalloc((void**)&dout, (size_t)2 * (r1 + r2) * LC) != hipSuccess || hipMalloc((void**)&ws, wsb) != hipSuccess ||
-      hipMalloc((void**)&dinfo, 32) != hipSuccess)
+  if (dev_alloc((void**)&d1, std::max(r1 * m, 1)) != hipSuccess || dev_alloc((void**)&d2, std::max(r2 * n, 1)) != hipSuccess ||
+      dev_alloc((void**)&dout, (size_t)2 * (r1 + r2) * LC) != hipSuccess || dev_alloc((void**)&ws, wsb) != hipSuccess ||
+      dev_alloc((void**)&dinfo, 32) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(d1, a1, (size_t)r1 * m, hipMemcpyHostToDevice);
   (void)hipMemcpy(d2, a2, (size_t)r2 * n, hipMemcpyHostToDevice);
@@ -326,7 +327,7 @@ inline int msa_single_gotoh(hipStream_t s, const dellyhip_params& P, int tmax, c
       for (int i = 0; i < r1 + r2; ++i) memcpy(out + (size_t)i * cap, tmp.data() + (size_t)i * LC, info[0]);
     }
   }
-  (void)hipFree(d1); (void)hipFree(d2); (void)hipFree(dout); (void)hipFree(ws); (void)hipFree(dinfo);
+  dev_free(d1); dev_free(d2); dev_free(dout); dev_free(ws); dev_free(dinfo);
   return rc;
 }
 
@@ -345,11 +346,11 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_r
   uint64_t* doff = nullptr;
   dellyhip_result* dres = nullptr;
   int32_t *dlen = nullptr, *dcnt = nullptr;
-  if (hipMalloc((void**)&dj, sizeof J) != hipSuccess || hipMalloc((void**)&dblob, std::max<uint64_t>(blob_bytes, 1) + 64) != hipSuccess ||   // (+64: quadword reads)
-      hipMalloc((void**)&doff, (n_reads + 1) * 8) != hipSuccess || hipMalloc((void**)&dres, sizeof(dellyhip_result)) != hipSuccess ||
-      hipMalloc((void**)&dout, ccap) != hipSuccess || hipMalloc((void**)&ws, plan.ws_stride) != hipSuccess ||
-      hipMalloc((void**)&wsb, plan.big_ws_stride) != hipSuccess || hipMalloc((void**)&dlen, 4) != hipSuccess ||
-      hipMalloc((void**)&dcnt, 64) != hipSuccess)
+  if (dev_alloc((void**)&dj, sizeof J) != hipSuccess || dev_alloc((void**)&dblob, std::max<uint64_t>(blob_bytes, 1) + 64) != hipSuccess ||   // (+64: quadword reads)
+      dev_alloc((void**)&doff, (n_reads + 1) * 8) != hipSuccess || dev_alloc((void**)&dres, sizeof(dellyhip_result)) != hipSuccess ||
+      dev_alloc((void**)&dout, ccap) != hipSuccess || dev_alloc((void**)&ws, plan.ws_stride) != hipSuccess ||
+      dev_alloc((void**)&wsb, plan.big_ws_stride) != hipSuccess || dev_alloc((void**)&dlen, 4) != hipSuccess ||
+      dev_alloc((void**)&dcnt, 64) != hipSuccess)
     return DELLYHIP_E_NOMEM;
   (void)hipMemcpy(dj, &J, sizeof J, hipMemcpyHostToDevice);
   (void)hipMemcpy(dblob, seq_blob, blob_bytes, hipMemcpyHostToDevice);
@@ -381,8 +382,8 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_r
       else if (L > 0) (void)hipMemcpy(cs, dout, L, hipMemcpyDeviceToHost);
     }
   }
-  (void)hipFree(dj); (void)hipFree(dblob); (void)hipFree(doff); (void)hipFree(dres); (void)hipFree(dout);
-  (void)hipFree(ws); (void)hipFree(wsb); (void)hipFree(dlen); (void)hipFree(dcnt);
+  dev_free(dj); dev_free(dblob); dev_free(doff); dev_free(dres); dev_free(dout);
+  dev_free(ws); dev_free(wsb); dev_free(dlen); dev_free(dcnt);
   return rc;
 }
 

@@ -83,14 +83,32 @@ def main():
     ap.add_argument("--n-reads", type=int, default=0)
     ap.add_argument("--sub-rate", type=float, default=0.005)
     ap.add_argument("--only-depth", type=int, default=0)
+    ap.add_argument("--torch", type=int, default=0, help="1: initialise torch.cuda first; 2: and create a torch stream; 3: and resident batches like bench.py")
     ap.add_argument("--depths", default="", help="comma-separated list of depths instead of 1,2,3,--depth")
     args = ap.parse_args()
+    keep = []
+    if args.torch >= 1:
+        import torch
+        torch.cuda.init()
+        torch.zeros(16, device="cuda:0")
+        if args.torch >= 2:
+            keep.append(torch.cuda.Stream(device="cuda:0"))
+            with torch.cuda.stream(keep[0]):
+                torch.zeros(16, device="cuda:0")
+            torch.cuda.synchronize()
     lr = args.mode.startswith("lr")
     params = abi.params_lr(realign=True) if lr else abi.params_sr()
     raw = [synth.make_batch(args.n, mode=args.mode, n_reads=args.n_reads, sub_rate=args.sub_rate, first=i * args.n) for i in range(args.distinct)]
     chroms, batches = one_genome(raw)
     ctx = refine.Context(params=params)
     ctx.set_chromosomes(chroms)
+    if args.torch >= 3:
+        for b in batches[:4]:
+            rb = ctx.upload(b)
+            rb.run(keep[0].cuda_stream)
+            keep.append(rb)
+        import torch
+        torch.cuda.synchronize()
     out = {}
     depths = [int(x) for x in args.depths.split(",")] if args.depths else ([args.only_depth] if args.only_depth else sorted(set([1, 2, 3, args.depth])))
     for depth in depths:
