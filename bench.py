@@ -5,7 +5,10 @@
 A "step" is one pass of the hot path (alignConsensus: window construction,
 longNeedle, split detection, coordinates) over one resident batch of synthetic
 junctions (BASELINE config 2: 10 000 junctions per GPU); the steps
-rotate through RESIDENT_BATCHES different batches.  Inputs are in HBM before the
+rotate through RESIDENT_BATCHES different batches and, at N = 1, alternate between
+two contexts on two HIP streams, so two launches are in flight and the tail of
+one runs under the head of the next (`roofline.one_launch_at_a_time` has the
+figures of a launch that has the chip to itself).  Inputs are in HBM before the
 timed region and result records stay in HBM: that is `value` (the bench
 contract).  The quantity SURVEY.md 8d defines -- host buffers in, host buffers out,
 marshalling + H2D + kernels + D2H -- is measured in the same run through the
@@ -294,42 +297,6 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     out = {}
     want = (lambda name: True) if not only else (lambda name: name in only)
     plan = tuple(x for x in SIDE_PLAN if want(x[0])) + tuple(x for x in SIDE_PLAN_BIG if only and x[0] in only)
-    # the headline batch size with two batches in flight (two contexts = two scratch areas, two HIP streams): one
-    # 10 000-junction step is 2500 DP wavefronts, fewer than three per SIMD; overlapping consecutive steps fills the chip
-    try:
-        if not want("u_c2_two_batches_in_flight"):
-            raise KeyError("skipped")
-        import torch
-        ctx2 = refine.Context(device=device)
-        pairs = []
-        for cx, first in ((ctx, 0), (ctx2, 10000)):
-            bb = synth.make_batch(10000, mode="c2", first=first)
-            cx.set_chromosomes(bb.chroms)
-            pairs.append((cx.upload(bb), torch.cuda.Stream(device=device)))
-        for _ in range(2):
-            for rb, st in pairs:
-                rb.run(st.cuda_stream)
-        for rb, _ in pairs:
-            rb.sync()
-        reps = 10
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            for rb, st in pairs:
-                rb.run(st.cuda_stream)
-        for rb, _ in pairs:
-            rb.sync()
-        dt = (time.perf_counter() - t0) / (2 * reps)
-        ok = sum(int(rb.fetch()[0]["ok"].sum()) for rb, _ in pairs)
-        out["u_c2_two_batches_in_flight"] = {"junctions": 10000, "junctions_per_s": 10000 / dt, "ms_per_step": dt * 1e3,
-                                             "refined_ok": ok,
-                                             "note": "two contexts, each with a resident 10 000-junction batch, alternating on two HIP streams"}
-        for rb, _ in pairs:
-            rb.free()
-        ctx2.close()
-    except KeyError:
-        pass
-    except Exception as e:  # side figure only
-        out["u_c2_two_batches_in_flight"] = {"error": repr(e)}
     for name, n, ncpu, kw in plan:
         b = synth.make_batch(n, **kw)
         lr = kw["mode"].startswith("lr")
@@ -525,9 +492,14 @@ def main():
     batch = batches[0]
     ctx = refine.Context(device=local)
     ctx.set_chromosomes(chroms)
-    side = torch.cuda.Stream(device=local)  # the kernels are launched on this stream
-    stream = side.cuda_stream
-    rbs = [ctx.upload(b) for b in batches]
+    # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
+    # streams the library verified to run side by side, so the tail of one step's launch runs under the head of the next
+    # (one 10 000-junction launch alone: 2.4 wavefronts per resident slot, a 50 us ramp and a 180 us tail of 0.40 ms).
+    # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: one context, the gather of step k - 1
+    # overlaps the kernels of step k.
+    ctxs = [ctx] if multi else [ctx, refine.Context(device=local, share_with=ctx)]
+    streams = list(ctx.compute_streams())[:len(ctxs)]
+    rbs = [ctxs[k % len(ctxs)].upload(b) for k, b in enumerate(batches)]
     comm = None
     gather_kind = "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"
     pinned = None
@@ -556,9 +528,9 @@ def main():
     k_step = [0]
 
     def step():
-        cur = rbs[k_step[0] % len(rbs)]
-        with torch.cuda.stream(side):
-            cur.run(stream)
+        i = k_step[0] % len(rbs)
+        cur = rbs[i]
+        cur.run(streams[i % len(streams)])
         if comm is not None and k_step[0] > 0:
             prev = rbs[(k_step[0] + 1) % 2]
             tg = time.perf_counter()
@@ -566,9 +538,8 @@ def main():
             gather_s[0] += time.perf_counter() - tg
         k_step[0] += 1
 
-    for x in rbs:         # set-up, not a step: every resident batch has run once (workspaces sized, results fetchable)
-        with torch.cuda.stream(side):
-            x.run(stream)
+    for i, x in enumerate(rbs):   # set-up, not a step: every resident batch has run once (workspaces sized, results fetchable)
+        x.run(streams[i % len(streams)])
     torch.cuda.synchronize()
     for _ in range(max(args.warmup, 1 if multi else 0)):
         step()
@@ -605,6 +576,27 @@ def main():
     # sanity: the timed work is the real work (every junction refined; tests/test_gpu_bench_shapes.py compares exactly these
     # batches with oracle/_ref)
     n_ok = [int(x.fetch()[0]["ok"].sum()) for x in rbs]
+
+    # the same launches ONE AT A TIME (rounds 1-2's headline mode): what a launch costs when it has the chip to itself
+    alone = None
+    if not multi:
+        for x in rbs:
+            x.kernel_ms()
+        reps = 12
+        ta = time.perf_counter()
+        for k in range(reps):
+            x = rbs[k % len(rbs)]
+            x.run(streams[0])
+            x.sync()
+        da = (time.perf_counter() - ta) / reps
+        kk = [x.kernel_ms() for x in rbs]
+        dd = [x.dp_kernel_ms() for x in rbs]
+        la = sum(k[2] for k in kk)
+        alone = {"alignments_per_s": n / da, "ms_per_step": da * 1e3,
+                 "kernel_ms": sum(d * k[2] for d, k in zip(dd, kk)) / max(la, 1), "launches": la,
+                 "note": "each launch waits for the previous one (sync in between)"}
+        alone["achieved"] = n * ALG_BYTES_PER_U / (alone["kernel_ms"] * 1e-3) / 1e9 if alone["kernel_ms"] > 0 else 0.0
+        alone["frac"] = alone["achieved"] / HBM_PEAK_GBS
 
     # the same junctions from host buffers to host buffers through the pipelined path (every rank its own share)
     hi = None
@@ -644,7 +636,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU and step, 150 bp consensus x 1 kb "
                                    "ref window, alignConsensus (longNeedle + split detection), bit-exact; steps rotate through %d "
-                                   "different resident batches" % (n, len(batches)),
+                                   "different resident batches%s" % (n, len(batches), "" if multi else
+                                                                     ", consecutive steps on two contexts / two HIP streams (two launches in flight)"),
+                       "launches_in_flight": 1 if multi else 2,
                        "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
                        "value_is": "inputs resident in HBM, results left in HBM (bench contract); host_inclusive = SURVEY.md 8d's definition",
                        "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if comm is not None else None),
@@ -655,6 +649,10 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "split_sparse_kernel (sparse longNeedle: furthest-reaching tables per deficit level, one junction per wavefront, alignment + split detection fused)",
                          "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split, "kernel_launches_timed": launches,
+                         "kernel_ms_is": ("HIP events around each launch on its stream over the timed region; two launches are in flight, "
+                                          "so a launch shares the chip for part of its life (one_launch_at_a_time has the isolated figure)"
+                                          if not multi else "HIP events around each launch on its stream over the timed region"),
+                         "one_launch_at_a_time": alone,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
                          "binding_roof": "integer VALU issue / latency, DP state on chip (SURVEY.md 8d); the HBM fraction is reported because BASELINE asks for it",
                          "valu_ceiling": VALU_CEILING,

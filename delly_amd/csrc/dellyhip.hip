@@ -2259,6 +2259,62 @@ int finish_lazy(StreamSlot& S) {
 
 }  // namespace
 
+// The four HIP streams of the pipelined path (upload, download, two compute streams) of a device: created on first use
+static DeviceStreams& ensure_device_streams(int device) {
+  DeviceStreams& D = device_streams(device);
+  std::lock_guard<std::mutex> g(D.mu);
+  // The four HIP streams of the pipelined path exist once per device and process and are never destroyed: the runtime
+  // maps HIP streams onto a few hardware queues, commands of one hardware queue execute in order, and the mapping a
+  // stream gets depends on the streams created and destroyed before it.
+  if (!D.made) {
+    D.made = true;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // Two compute streams that really run side by side: with more HIP streams alive than hardware queues
+    // (GPU_MAX_HW_QUEUES, 4 by default -- a torch.cuda.Stream() alone creates a pool of 32) two consecutively created
+    // streams can share a queue, and the sparse kernels of consecutive slots then run one after the other: 19.4 instead of
+    // 32.5 M junctions/s (tools/stream_matrix.sh).  Candidates are probed pairwise; the spare ones stay allocated
+    // (destroying them would shift the mapping of streams created later).
+    {
+      hipStream_t cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      int ncand = 0;
+      for (; ncand < 2; ++ncand)
+        if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
+      int* probe = nullptr;
+      int a = 0, b = 1;
+      if (ncand == 2 && !getenv("DELLYHIP_STREAM_NO_PROBE") && dh::dev_alloc((void**)&probe, 2 * sizeof(int)) == hipSuccess) {
+        bool ok = streams_run_concurrently(cand[0], cand[1], probe);
+        while (!ok && ncand < 8) {
+          if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
+          ++ncand;
+          for (int i = 0; i + 1 < ncand && !ok; ++i)
+            if (streams_run_concurrently(cand[i], cand[ncand - 1], probe)) { ok = true; a = i; b = ncand - 1; }
+        }
+        if (!ok) { a = 0; b = 1; }
+        (void)hipDeviceSynchronize();
+        dh::dev_free(probe);
+      }
+      D.comp[0] = cand[a];
+      D.comp[1] = ncand >= 2 ? cand[b] : nullptr;
+      D.probed_pairs = ncand;
+    }
+    if (least != greatest) {   // (numerically lower = higher priority; normal = 0 lies between)
+      if (hipStreamCreateWithPriority(&D.up, hipStreamNonBlocking, greatest) != hipSuccess) D.up = nullptr;
+      if (hipStreamCreateWithPriority(&D.down, hipStreamNonBlocking, least) != hipSuccess) D.down = nullptr;
+    }
+  }
+  return D;
+}
+
+int dellyhip_compute_streams(dellyhip_ctx* c, void* out[2]) {
+  if (!c || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  DeviceStreams& D = ensure_device_streams(c->device);
+  out[0] = D.comp[0];
+  out[1] = D.comp[1] ? D.comp[1] : D.comp[0];
+  return out[0] ? 0 : fail(DELLYHIP_E_RUNTIME, "no compute stream");
+}
+
 int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int32_t want_alignment, dellyhip_stream** out) {
   if (!c || !out || depth < 1 || depth > 8 || with_msa < 0 || with_msa > 2) return fail(DELLYHIP_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
@@ -2270,48 +2326,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   if (const char* t = getenv("DELLYHIP_LOG")) st->log = atoi(t);
   st->t_created = now_s();
   {
-    // The four HIP streams of the pipelined path exist once per device and process and are never destroyed: the runtime
-    // maps HIP streams onto a few hardware queues, commands of one hardware queue execute in order, and the mapping a
-    // stream gets depends on the streams created and destroyed before it.
-    DeviceStreams& D = device_streams(c->device);
-    std::lock_guard<std::mutex> g(D.mu);
-    if (!D.made) {
-      D.made = true;
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      // Two compute streams that really run side by side: with more HIP streams alive than hardware queues
-      // (GPU_MAX_HW_QUEUES, 4 by default -- a torch.cuda.Stream() alone creates a pool of 32) two consecutively created
-      // streams can share a queue, and the sparse kernels of consecutive slots then run one after the other: 19.4 instead of
-      // 32.5 M junctions/s (tools/stream_matrix.sh).  Candidates are probed pairwise; the spare ones stay allocated
-      // (destroying them would shift the mapping of streams created later).
-      {
-        hipStream_t cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        int ncand = 0;
-        for (; ncand < 2; ++ncand)
-          if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
-        int* probe = nullptr;
-        int a = 0, b = 1;
-        if (ncand == 2 && !getenv("DELLYHIP_STREAM_NO_PROBE") && dh::dev_alloc((void**)&probe, 2 * sizeof(int)) == hipSuccess) {
-          bool ok = streams_run_concurrently(cand[0], cand[1], probe);
-          while (!ok && ncand < 8) {
-            if (hipStreamCreateWithFlags(&cand[ncand], hipStreamNonBlocking) != hipSuccess) { cand[ncand] = nullptr; break; }
-            ++ncand;
-            for (int i = 0; i + 1 < ncand && !ok; ++i)
-              if (streams_run_concurrently(cand[i], cand[ncand - 1], probe)) { ok = true; a = i; b = ncand - 1; }
-          }
-          if (!ok) { a = 0; b = 1; }
-          (void)hipDeviceSynchronize();
-          dh::dev_free(probe);
-        }
-        D.comp[0] = cand[a];
-        D.comp[1] = ncand >= 2 ? cand[b] : nullptr;
-        D.probed_pairs = ncand;
-      }
-      if (least != greatest) {   // (numerically lower = higher priority; normal = 0 lies between)
-        if (hipStreamCreateWithPriority(&D.up, hipStreamNonBlocking, greatest) != hipSuccess) D.up = nullptr;
-        if (hipStreamCreateWithPriority(&D.down, hipStreamNonBlocking, least) != hipSuccess) D.down = nullptr;
-      }
-    }
+    DeviceStreams& D = ensure_device_streams(c->device);
     if (!getenv("DELLYHIP_STREAM_ONE_QUEUE")) {
       st->s_up = D.up;
       st->s_down = D.down;

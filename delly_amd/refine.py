@@ -33,7 +33,7 @@ EXPORTS = [
     "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
-    "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
+    "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
     "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
 ]
 
@@ -148,6 +148,12 @@ class Context:
         if self._ctx:
             self.lib.dellyhip_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+    def compute_streams(self):
+        """two hipStream_t handles (ints) of this device verified to run side by side (dellyhip_compute_streams)"""
+        out = (C.c_void_p * 2)()
+        self._check(self.lib.dellyhip_compute_streams(self._ctx, out))
+        return int(out[0] or 0), int(out[1] or 0)
 
     def trim_memory(self):
         """returns the device / pinned blocks the library keeps parked to the HIP runtime (dellyhip_trim_memory) -> bytes"""

@@ -132,6 +132,16 @@ void dellyhip_default_params_lr(dellyhip_params* p);
  * context per thread, ONE copy of the genome per GPU. */
 int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* params, dellyhip_ctx** out);
 
+/* Two HIP streams (hipStream_t) of ctx's device that were VERIFIED to run side by side.  The runtime maps HIP streams onto
+ * a few hardware queues and two streams that share one execute in order; with more streams alive than hardware queues
+ * (a torch.cuda.Stream() alone creates 32) two freshly created streams may well share.  The library probes candidates
+ * once per device and process (a kernel on one waits <= 0.5 ms for a flag only a kernel on the other sets) and keeps the
+ * pair for the slots of every dellyhip_stream.  A caller that keeps two resident batches in flight through
+ * dellyhip_batch_run (two contexts from dellyhip_create_shared, one per stream) should pass these two streams:
+ * 34 instead of 22.5 M alignments/s at 10 000 junctions per batch (the tail of one launch under the head of the next).
+ * The streams belong to the library; do not destroy them. */
+int dellyhip_compute_streams(dellyhip_ctx* ctx, void* out[2]);
+
 /* Memory policy: device and pinned host blocks the library releases (freed batches, destroyed contexts and streams)
  * are parked in a process-wide free list per device and handed out again -- they are not returned to the HIP runtime
  * while the process lives, so the footprint is the high-water mark of what was alive at once.  (hipMalloc / hipFree

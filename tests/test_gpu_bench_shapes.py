@@ -36,11 +36,35 @@ def _check(ctx, ref, b, params, label, n_cmp=None):
 
 @pytest.mark.parametrize("k", range(bench.RESIDENT_BATCHES))
 def test_headline_batches_10000_c2_junctions_vs_reference(gpu_ctx, reference, k):
-    """the resident batches bench.py's timed steps rotate through (rank 0 of a one-GPU run; the second one is also the
-    partner of u_c2_two_batches_in_flight)"""
+    """the resident batches bench.py's timed steps rotate through (rank 0 of a one-GPU run)"""
     b = synth.make_batch(10000, mode="c2", first=k * 10000)
     gr = _check(gpu_ctx, reference, b, None, "bench headline batch %d (10 000 C2)" % k)
     assert int(gr["ok"].sum()) >= 9890   # bench.py's refined_ok (1 % pure-reference junctions per batch)
+
+
+def test_headline_arrangement_two_launches_in_flight_gives_the_same_records(gpu_ctx):
+    """bench.py's N = 1 timed region: the resident batches alternate between two contexts that share one genome, on the two
+    compute streams of dellyhip_compute_streams, launched back to back without waiting -- every batch must come out as it
+    does alone (the batches themselves are compared with oracle/_ref above)"""
+    raw = [synth.make_batch(10000, mode="c2", first=k * 10000) for k in range(bench.RESIDENT_BATCHES)]
+    chroms, batches = bench.one_genome(synth, raw)
+    gpu_ctx.set_chromosomes(chroms)
+    alone = [gpu_ctx.refine(b) for b in batches]
+    other = refine.Context(share_with=gpu_ctx)
+    ctxs = [gpu_ctx, other]
+    streams = gpu_ctx.compute_streams()
+    assert streams[0] and streams[1] and streams[0] != streams[1]
+    rbs = [ctxs[k % 2].upload(b) for k, b in enumerate(batches)]
+    for lap in range(3):
+        for k, rb in enumerate(rbs):
+            rb.run(streams[k % 2])
+    for k, rb in enumerate(rbs):
+        rb.sync()
+        r, bl = rb.fetch()
+        assert all((r[f] == alone[k][0][f]).all() for f in r.dtype.names), "batch %d" % k
+        assert bl.tobytes() == alone[k][1].tobytes()
+        rb.free()
+    other.close()
 
 
 @pytest.mark.parametrize("name", [x[0] for x in bench.SWEEP_PLAN])
