@@ -455,6 +455,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pipelined host-buffer measurement")
+    ap.add_argument("--no-alone", action="store_true", help="skip the one-launch-at-a-time pass behind the timed region (profiling runs)")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
     ap.add_argument("--force-comm", action="store_true",
                     help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
@@ -579,7 +580,7 @@ def main():
 
     # the same launches ONE AT A TIME (rounds 1-2's headline mode): what a launch costs when it has the chip to itself
     alone = None
-    if not multi:
+    if not multi and not args.no_alone:
         for x in rbs:
             x.kernel_ms()
         reps = 12

@@ -11,7 +11,7 @@ for P in $PARTS; do
 case $P in
 stats)
   cd /tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_u -o u -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-host-inclusive > $R/$O/stats_u.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_u -o u -- python $R/bench.py --steps 20 --warmup 3 --no-alone --no-cpu-baseline --no-extras --no-host-inclusive > $R/$O/stats_u.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats_x -o x -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --only-extras $EXTRAS > $R/$O/stats_x.log 2>&1
   cd $R
   cp $(find $O/stats_u -name "*kernel_stats.csv" | head -1) $O/split_u_c2_kernel_stats.csv 2>/dev/null
@@ -20,7 +20,7 @@ stats)
 traffic)
   rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc_$C -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-host-inclusive > gpurun_out/pmc_$C.log 2>&1 < /dev/null
+    timeout 200 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc_$C -o p -- python bench.py --steps 3 --warmup 1 --no-alone --no-cpu-baseline --no-extras --no-host-inclusive > gpurun_out/pmc_$C.log 2>&1 < /dev/null
   done
   python - <<'PY' | tee $O/pmc_traffic_raw.txt
 import csv, glob, collections, json
@@ -48,11 +48,11 @@ if sp:
 PY
   ;;
 sq)
-  BENCH_ARGS="--no-extras --no-host-inclusive" bash tools/pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt $O/pmc_sq_summary.txt
+  BENCH_ARGS="--no-extras --no-host-inclusive --no-alone" bash tools/pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt $O/pmc_sq_summary.txt
   BENCH_ARGS="--no-host-inclusive --only-extras $EXTRAS" bash tools/pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq_summary.txt $O/pmc_sq_summary_extras.txt
   ;;
 wait)
-  BENCH_ARGS="--no-extras --no-host-inclusive" KERNEL=split_sparse bash tools/pmc_wait.sh > /dev/null 2>&1; cp gpurun_out/pmc_wait_summary.txt $O/pmc_wait_split_sparse.txt
+  BENCH_ARGS="--no-extras --no-host-inclusive --no-alone" KERNEL=split_sparse bash tools/pmc_wait.sh > /dev/null 2>&1; cp gpurun_out/pmc_wait_summary.txt $O/pmc_wait_split_sparse.txt
   BENCH_ARGS="--no-host-inclusive --only-extras u_full_n20_10k_junctions" KERNEL=msa_kernel bash tools/pmc_wait.sh > /dev/null 2>&1; cp gpurun_out/pmc_wait_summary.txt $O/pmc_wait_msa_kernel.txt
   ;;
 esac
