@@ -301,8 +301,9 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         b = synth.make_batch(n, **kw)
         lr = kw["mode"].startswith("lr")
         params = abi.params_lr(realign=True) if lr else abi.params_sr()
-        if lr and name == "lr_c4_align_consensus":  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
+        if lr and not getattr(ctx, "is_lr", False):  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
             ctx = refine.Context(params=params, device=device)
+            ctx.is_lr = True
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()
