@@ -318,7 +318,7 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
                      "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
         rb.free()
         try:   # the same batch from host buffers through the pipelined path
-            hi = host_inclusive_rate(ctx, [b], b.with_msa, seconds=0.5 if dt < 0.05 else 3 * dt, depth=3)
+            hi = host_inclusive_rate(ctx, [b], b.with_msa, seconds=0.5 if dt < 0.05 else 3 * dt, depth=5 if dt < 0.02 else 3)
             out[name]["host_inclusive"] = {k: hi[k] for k in ("value", "unit", "batches", "wall_s", "ms_per_batch", "depth", "bytes_up_per_batch", "bytes_down_per_batch")}
             out[name]["host_inclusive"]["vs_resident"] = hi["value"] / (n / dt)
         except Exception as e:

@@ -230,3 +230,45 @@ def test_stream_holds_its_memory_over_many_batches_of_changing_size():
         assert tag == k and _same(r, classic[k][0]) and bl.tobytes() == classic[k][1].tobytes()
     st.close()
     ctx.close()
+
+
+def test_two_host_threads_each_with_a_stream_on_one_genome():
+    """the worker-thread model of src/shortpe.h:175-201 on the pipelined path: one resident genome, one dellyhip_stream per
+    host thread (contexts from dellyhip_create_shared), submitting and collecting concurrently -- the library's pools of
+    parked memory and its per-device HIP streams are shared between them"""
+    import threading
+    raw = [synth.make_batch(700 + 150 * i, mode="mixed", seed=60 + i) for i in range(6)]
+    chroms, batches = _one_genome(raw)
+    root = refine.Context()
+    root.set_chromosomes(chroms)
+    classic = [root.refine(b) for b in batches]
+    errors, got = [], {}
+
+    def worker(tid):
+        try:
+            ctx = refine.Context(share_with=root)
+            st = refine.Stream(ctx, depth=3)
+            mine = [k for k in range(len(batches)) if k % 2 == tid]
+            for lap in range(4):
+                nxt = 0
+                for i in range(len(mine)):
+                    while nxt < len(mine) and nxt - i < 2:
+                        st.submit(batches[mine[nxt]], tag=mine[nxt])
+                        nxt += 1
+                    r, bl, tag = st.collect()
+                    got[(tid, lap, int(tag))] = (r, bl)
+            st.close()
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 (reported by the main thread)
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(got) == 2 * 4 * 3
+    for (tid, lap, k), (r, bl) in got.items():
+        assert _same(r, classic[k][0]) and bl.tobytes() == classic[k][1].tobytes(), (tid, lap, k)
+    root.close()
