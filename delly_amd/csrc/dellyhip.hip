@@ -97,11 +97,37 @@ struct DevPool {
     *got = want;
     return p;
   }
+  // Parked bytes per device are capped (half of the device's memory, DELLYHIP_POOL_LIMIT_MB overrides): beyond the cap the
+  // oldest parked blocks go back to the runtime -- a process that keeps changing its batch shapes cannot hoard HBM.
+  size_t limit_bytes(int dev) {
+    if (const char* t = getenv("DELLYHIP_POOL_LIMIT_MB")) return (size_t)std::max(0ll, atoll(t)) << 20;
+    static std::map<int, size_t> lim;   // (under mu)
+    auto it = lim.find(dev);
+    if (it != lim.end()) return it->second;
+    size_t fr = 0, tot = 0;
+    const size_t v = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? tot / 2 : ((size_t)64 << 30);
+    lim[dev] = v;
+    return v;
+  }
   void give(void* p, size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> g(mu);
-    free_list.push_back(Block{p, bytes, dev, true});
+    std::vector<Block> victims;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      free_list.push_back(Block{p, bytes, dev, true});
+      size_t parked = 0;
+      for (auto& f : free_list)
+        if (f.device == dev) parked += f.bytes;
+      const size_t lim = limit_bytes(dev);
+      for (size_t i = 0; parked > lim && i < free_list.size();)
+        if (free_list[i].device == dev) {
+          parked -= free_list[i].bytes;
+          victims.push_back(free_list[i]);
+          free_list.erase(free_list.begin() + (long)i);
+        } else ++i;
+    }
+    for (auto& b : victims) (void)hipFree(b.p);   // (hipFree waits for the device: safe for blocks with work in flight)
   }
   size_t trim(int dev) {   // -> bytes returned to the runtime
     std::vector<Block> mine;

@@ -144,7 +144,8 @@ int dellyhip_compute_streams(dellyhip_ctx* ctx, void* out[2]);
 
 /* Memory policy: device and pinned host blocks the library releases (freed batches, destroyed contexts and streams)
  * are parked in a process-wide free list per device and handed out again -- they are not returned to the HIP runtime
- * while the process lives, so the footprint is the high-water mark of what was alive at once.  (hipMalloc / hipFree
+ * while the process lives, so the footprint is the high-water mark of what was alive at once (parked blocks are capped
+ * at half of the device's memory -- DELLYHIP_POOL_LIMIT_MB overrides -- beyond which the oldest go back to the runtime).  (hipMalloc / hipFree
  * synchronise the device, and allocations made after earlier ones were freed were measured to download at a fraction
  * of the PCIe rate: DESIGN.md 1b.)  dellyhip_trim_memory waits for the device, returns every parked block of ctx's
  * device to the runtime and reports the bytes released. */

@@ -138,3 +138,25 @@ def test_parked_memory_is_reused_and_can_be_returned():
     r4, _ = ctx.refine(b)                     # and the library works on after a trim
     assert all(np.array_equal(r0[f], r4[f]) for f in r0.dtype.names)
     ctx.close()
+
+
+def test_parked_memory_is_capped(monkeypatch):
+    """DELLYHIP_POOL_LIMIT_MB: beyond the cap the oldest parked blocks go back to the runtime at once"""
+    b = synth.make_batch(400, mode="c2", seed=12)
+    ctx = refine.Context()
+    ctx.set_chromosomes(b.chroms)
+    ctx.trim_memory()
+    base = _free_bytes()
+    monkeypatch.setenv("DELLYHIP_POOL_LIMIT_MB", "32")
+    st = refine.Stream(ctx, depth=2)
+    st.submit(b)
+    r0 = st.collect()[0]
+    held = base - _free_bytes()
+    assert held > (256 << 20)                 # two slots' scratch areas alone are ~1.9 GB
+    st.close()
+    assert base - _free_bytes() < (40 << 20), "parked beyond the cap: %d bytes" % (base - _free_bytes())
+    monkeypatch.delenv("DELLYHIP_POOL_LIMIT_MB")
+    r1, _ = ctx.refine(b)
+    assert all(np.array_equal(r0[f], r1[f]) for f in r0.dtype.names)
+    ctx.trim_memory()
+    ctx.close()
