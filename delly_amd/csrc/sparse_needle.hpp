@@ -71,18 +71,21 @@ struct SparseRes {
 
 // The tables live in the wavefront's workspace, which it re-writes for every junction: table reads bypass the vector L1
 // (like ld_scratch, split_kernel.hpp), two int16 entries per aligned 32-bit load.
+// (the tables live in the wavefront's HBM workspace: the loads are issued as global_load -- a flat_load, which is what a
+//  pointer of unknown address space gets, also counts against the LDS counter and makes LDS reads wait for it)
+typedef const __attribute__((address_space(1))) uint32_t* sp_gu32;
 __device__ __forceinline__ int sp_ld16(const int16_t* p) {
   const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-  const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t*>(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t v = __hip_atomic_load((sp_gu32)(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (int)(int16_t)((u & 2) ? (v >> 16) : (v & 0xffffu));
 }
 __device__ __forceinline__ int sp_ld32(const int32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (int)__hip_atomic_load((sp_gu32) reinterpret_cast<uintptr_t>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ int sp_ld8(const uint8_t* p) {
   const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-  const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t*>(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t v = __hip_atomic_load((sp_gu32)(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (int)((v >> (8 * (u & 3))) & 0xffu);
 }
 

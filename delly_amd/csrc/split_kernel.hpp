@@ -79,6 +79,15 @@ constexpr int OUT_ALN_CAP = 2 * TRACE_CAP;
 
 // ---- small device helpers -------------------------------------------------
 
+// A pointer that was LOADED from memory (the chromosome table) has no address space the compiler can see: every access
+// through it becomes a flat_* instruction, which counts against the LDS counter as well as the memory counter, so that LDS
+// reads wait for outstanding global loads.  The round trip through address space 1 tells the compiler it is global memory.
+template <typename T>
+__device__ __forceinline__ const T* as_global(const T* p) {
+  typedef const __attribute__((address_space(1))) T* G;
+  return (const T*)(G)p;
+}
+
 __device__ __forceinline__ int dpp_from_prev(int src, int old) {  // lane l <- lane l-1
   return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }

@@ -52,7 +52,7 @@ __host__ __device__ inline uint64_t sps_scratch_bytes() {
   return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
 }
 
-__device__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
+__device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane) {
 #ifdef DH_LR_TIMING
   const unsigned long long tq0 = wall_clock64();
 #endif
