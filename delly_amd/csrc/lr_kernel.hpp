@@ -478,7 +478,7 @@ __device__ __forceinline__ int lr_dir_and_trace(const uint8_t* rowstr, const uin
 }
 
 // ---- one long-read junction per wavefront ------------------------------------------------
-__device__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane) {
+__device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane) {
   PostRef L{LL.u.post.mV, LL.u.post.mR, LL.u.post.mE, LL.u.post.cumV, LL.u.post.cumR};
   int maskw = LR_MASKW_LDS;
   auto pick_masks = [&](int m_, int n_) {   // (call once m and n are known, before the masks are built)
