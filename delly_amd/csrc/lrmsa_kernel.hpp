@@ -253,8 +253,12 @@ __device__ __forceinline__ uint32_t* lm_eq_lds() {
 }
 
 template <int NWORDS>
-__device__ __noinline__ void lm_last_row_myers(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen,
-                                               int32_t* row_out, int lane) {
+__device__ __noinline__ void lm_last_row_myers(const uint8_t* tp_, int tstep, int tlen, const uint8_t* qp_, int qstep, int qlen,
+                                               int32_t* row_out_, int lane) {
+  // (the strings and the output row live in HBM: said so, their loads are global_load and may pass the LDS updates of the
+  //  match-mask set-up instead of waiting for each of them -- a pointer argument of a called function is generic otherwise)
+  const gptr_cu8 tp = (gptr_cu8)tp_, qp = (gptr_cu8)qp_;
+  const gptr_i32 row_out = (gptr_i32)row_out_;
   uint32_t* E = lm_eq_lds();
   const int row0 = lane * 32 * NWORDS;
   uint32_t mk[NWORDS];   // rows of this lane at or beyond tlen (their vertical deltas are taken off the bottom score)
@@ -364,8 +368,9 @@ __device__ __noinline__ void lm_last_row_myers(const uint8_t* tp, int tstep, int
 // prefix sum of the vertical deltas of rows 1..r, which each lane rebuilds for its own rows from Pv / Mv behind a wave
 // prefix sum of the lanes' totals.  Keys as lm_pass: (E << LM_RBITS) | r and (E << LM_RBITS) | (LM_RMASK - r) over rows r0..tlen.
 template <int NWORDS>
-__device__ __noinline__ LmKeys lm_locate_myers(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, bool hw,
+__device__ __noinline__ LmKeys lm_locate_myers(const uint8_t* tp_, int tstep, int tlen, const uint8_t* qp_, int qstep, int qlen, bool hw,
                                                int r0, int lane) {
+  const gptr_cu8 tp = (gptr_cu8)tp_, qp = (gptr_cu8)qp_;   // (HBM: see lm_last_row_myers)
   uint32_t* E = lm_eq_lds();
   const int row0 = lane * 32 * NWORDS;
 #pragma unroll
@@ -518,8 +523,10 @@ __device__ __forceinline__ bool lm_pure_acgt(const uint8_t* sp, int step, int n,
 // Layout: word of (step s, word w, owner lane lo) at ((s * NW + w) * (nl + 1) + lo); lanes beyond the last owner
 // lane share the dummy slot nl.  Cell (r, c) (1-based): lo = (r-1) / (32 NW), w = ((r-1) >> 5) - lo NW, s = c - 1 + lo.
 template <int NWORDS>
-__device__ __noinline__ void lm_dirs_myers(const uint8_t* tp, int tlen, const uint8_t* qp, int qlen, uint32_t* planeH,
-                                           uint32_t* planeV, int lane) {
+__device__ __noinline__ void lm_dirs_myers(const uint8_t* tp_, int tlen, const uint8_t* qp_, int qlen, uint32_t* planeH_,
+                                           uint32_t* planeV_, int lane) {
+  const gptr_cu8 tp = (gptr_cu8)tp_, qp = (gptr_cu8)qp_;   // (HBM: see lm_last_row_myers)
+  const gptr_u32 planeH = (gptr_u32)planeH_, planeV = (gptr_u32)planeV_;
   uint32_t* E = lm_eq_lds();
   const int row0 = lane * 32 * NWORDS;
 #pragma unroll

@@ -79,14 +79,14 @@ constexpr int OUT_ALN_CAP = 2 * TRACE_CAP;
 
 // ---- small device helpers -------------------------------------------------
 
-// A pointer that was LOADED from memory (the chromosome table) has no address space the compiler can see: every access
-// through it becomes a flat_* instruction, which counts against the LDS counter as well as the memory counter, so that LDS
-// reads wait for outstanding global loads.  The round trip through address space 1 tells the compiler it is global memory.
-template <typename T>
-__device__ __forceinline__ const T* as_global(const T* p) {
-  typedef const __attribute__((address_space(1))) T* G;
-  return (const T*)(G)p;
-}
+// A pointer that was LOADED from memory (the chromosome table) or that arrives as the argument of a called function has no
+// address space the compiler can see: every access through it becomes a flat_* instruction, which counts against the LDS
+// counter as well as the memory counter (LDS reads wait for outstanding global loads) and may alias LDS (loads cannot pass
+// LDS stores).  Accesses made THROUGH a pointer of these types are global_* instructions.  (A round trip
+// generic -> global -> generic does not help: the pair of casts is folded away before address spaces are inferred.)
+typedef const __attribute__((address_space(1))) uint8_t* gptr_cu8;
+typedef __attribute__((address_space(1))) uint32_t* gptr_u32;
+typedef __attribute__((address_space(1))) int32_t* gptr_i32;
 
 __device__ __forceinline__ int dpp_from_prev(int src, int old) {  // lane l <- lane l-1
   return __builtin_amdgcn_update_dpp(old, src, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);

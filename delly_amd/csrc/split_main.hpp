@@ -137,8 +137,8 @@ __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyh
   const int boundary = m;
   const int svS = J.sv_start, svE = J.sv_end;
   const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
-  const uint8_t* c1 = as_global(A.chr_seq[J.chr]);
-  const uint8_t* c2 = as_global(A.chr_seq[J.chr2]);
+  const uint8_t* c1 = A.chr_seq[J.chr];
+  const uint8_t* c2 = A.chr_seq[J.chr2];
   if (INS) {
     // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
     const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
