@@ -269,9 +269,16 @@ __device__ __forceinline__ void myers_lut_init(uint16_t* lut, int lane) {
   }
 }
 
+typedef unsigned int dh_u32x4 __attribute__((ext_vector_type(4)));
+typedef dh_u32x4 __attribute__((aligned(1))) dh_u32x4_unaligned;   // (the strings of a blob start anywhere)
+
 template <int NWORDS>
-__device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pattern, int pn, const uint8_t* text, int tn,
+__device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pattern_, int pn, const uint8_t* text_, int tn,
                                              int lane) {
+  // pattern / text are in HBM for every caller (the pair lists of myers_pairs_kernel / nw_jobs_kernel): accessed through
+  // global-space pointers the text load of the next chunk does not hold up the LDS mask reads of the current one
+  // (a flat load counts against the LDS counter too; split_kernel.hpp, gptr_cu8)
+  const gptr_cu8 pattern = (gptr_cu8)pattern_, text = (gptr_cu8)text_;
   const int row0 = lane * 32 * NWORDS;
   bool foreign = false;
 #pragma unroll
@@ -281,10 +288,9 @@ __device__ __noinline__ int myers_nw_fast(MyersLds<NWORDS>& L, const uint8_t* pa
     for (int k = 0; k < 6; ++k) slot[k * WAVE] = 0;
     const int rbeg = row0 + w * 32;
     if (rbeg < pn) {   // the word's 32 pattern bytes in two loads (the blob is padded: reading past pn is harmless)
-      uint4 v[2];
-      __builtin_memcpy(&v[0], pattern + rbeg, 16);
-      __builtin_memcpy(&v[1], pattern + rbeg + 16, 16);
-      const uint32_t wd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+      const dh_u32x4 g0 = *reinterpret_cast<const __attribute__((address_space(1))) dh_u32x4_unaligned*>(pattern + rbeg);
+      const dh_u32x4 g1 = *reinterpret_cast<const __attribute__((address_space(1))) dh_u32x4_unaligned*>(pattern + rbeg + 16);
+      const uint32_t wd[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int code = (int)L.lut[(wd[q >> 2] >> ((q & 3) * 8)) & 0xff];
@@ -388,8 +394,8 @@ __device__ __noinline__ bool myers_nw_fast_x2(MyersLds<NWORDS>& L, const uint8_t
                                               const uint8_t* patB, int pnB, const uint8_t* txtB, int tnB, int lane, int& dA, int& dB) {
   const bool hiHalf = lane >= 32;
   const int hl = lane & 31;
-  const uint8_t* pattern = hiHalf ? patB : patA;
-  const uint8_t* text = hiHalf ? txtB : txtA;
+  const gptr_cu8 pattern = (gptr_cu8)(hiHalf ? patB : patA);   // (HBM for every caller: see myers_nw_fast)
+  const gptr_cu8 text = (gptr_cu8)(hiHalf ? txtB : txtA);
   const int pn = hiHalf ? pnB : pnA, tn = hiHalf ? tnB : tnA;
   const int row0 = hl * 32 * NWORDS;
   bool foreign = false;
@@ -400,10 +406,9 @@ __device__ __noinline__ bool myers_nw_fast_x2(MyersLds<NWORDS>& L, const uint8_t
     for (int k = 0; k < 6; ++k) slot[k * WAVE] = 0;
     const int rbeg = row0 + w * 32;
     if (rbeg < pn) {
-      uint4 v[2];
-      __builtin_memcpy(&v[0], pattern + rbeg, 16);
-      __builtin_memcpy(&v[1], pattern + rbeg + 16, 16);
-      const uint32_t wd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+      const dh_u32x4 g0 = *reinterpret_cast<const __attribute__((address_space(1))) dh_u32x4_unaligned*>(pattern + rbeg);
+      const dh_u32x4 g1 = *reinterpret_cast<const __attribute__((address_space(1))) dh_u32x4_unaligned*>(pattern + rbeg + 16);
+      const uint32_t wd[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const int code = (int)L.lut[(wd[q >> 2] >> ((q & 3) * 8)) & 0xff];
