@@ -14,8 +14,10 @@ contract).  The quantity SURVEY.md 8d defines -- host buffers in, host buffers o
 marshalling + H2D + kernels + D2H -- is measured in the same run through the
 pipelined path (dellyhip_stream) over >= 1 s of batches and reported beside it as
 `host_inclusive`.  For N > 1 junctions shard across ranks; the records and bytes
-of step k - 1 are gathered to rank 0 over RCCL AND copied to its host memory
-inside step k (`config.gather_ms_per_step`).
+of step k - 1 reach the host inside step k (`config.gather_ms_per_step`): by
+default every rank downloads its own share into a pinned POSIX shared-memory
+segment that rank 0 has mapped (no collective, every PCIe link used);
+`--gather rccl` gathers them to rank 0's HBM over RCCL and downloads there.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -458,6 +460,9 @@ def main():
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pipelined host-buffer measurement")
     ap.add_argument("--no-alone", action="store_true", help="skip the one-launch-at-a-time pass behind the timed region (profiling runs)")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
+    ap.add_argument("--gather", choices=("shm", "rccl"), default="shm",
+                    help="N > 1: how the results of a step reach rank 0 -- shm: every rank downloads its own share into a POSIX "
+                         "shared-memory segment rank 0 has mapped (no collective); rccl: dellyhip_gather_results to rank 0's HBM + D2H")
     ap.add_argument("--force-comm", action="store_true",
                     help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
                          "overlapping step k) on ONE GPU with a one-rank communicator")
@@ -492,6 +497,10 @@ def main():
     raw = [synth.make_batch(n, mode="c2", first=(k * world + rank) * n) for k in range(n_res)]
     chroms, batches = one_genome(synth, raw)
     batch = batches[0]
+    if multi:
+        # the download of step k - 1 (two small compaction kernels in front of it) runs while the persistent sparse kernel of
+        # step k holds the chip: 12 of its 16 wavefronts per CU leave them room (as in the slots of dellyhip_stream)
+        os.environ.setdefault("DELLYHIP_SPS_WAVES", "12")
     ctx = refine.Context(device=local)
     ctx.set_chromosomes(chroms)
     # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
@@ -505,8 +514,29 @@ def main():
     comm = None
     gather_kind = "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"
     pinned = None
-    if multi:
-        # N > 1: every rank alternates between TWO resident batches; the results of the batch refined in the previous step
+    seg = None
+    segs_all = []
+    if multi and args.gather == "shm":
+        # N > 1 (default): every rank alternates between TWO resident batches; the results of the batch refined in the
+        # previous step are compacted on the device and downloaded -- inside the step, while the kernels of the current step
+        # run -- into a POSIX shared-memory segment the rank owns and has pinned (dellyhip_host_register); rank 0, which would
+        # run mergeSort / write the VCF, maps every rank's segment and reads the records in place.  Every rank uses its OWN
+        # PCIe link and no collective carries results (the gather to one rank funnels all of them through
+        # rank 0's link).
+        from delly_amd import shmreturn
+        tag = "%s_%d" % (os.environ.get("MASTER_PORT", "0"), world)
+        rb_bytes = abi.result_dtype().itemsize
+        cap_n, cap_b = n + 64, n * 1400 + (1 << 20)
+        seg = shmreturn.Segment(tag, rank, cap_n, rb_bytes, cap_b, create=True)
+        seg.pin(ctx)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            segs_all = [seg] + [shmreturn.Segment(tag, r, cap_n, rb_bytes, cap_b, create=False) for r in range(1, world)]
+        gather_kind = ("per-rank D2H (dellyhip_batch_fetch) into a pinned POSIX shared-memory segment mapped by rank 0, inside the "
+                       "step; download of step k-1 overlaps the kernels of step k; no collective")
+    elif multi:
+        # --gather rccl: every rank alternates between TWO resident batches; the results of the batch refined in the previous step
         # are gathered to rank 0 -- dellyhip_gather_results in the host library: RCCL called directly (ncclAllGather of
         # the counts, grouped ncclSend / ncclRecv of the records + consensus / allele bytes) -- AND copied
         # into rank 0's pinned host memory (VCF emission needs them there) while the kernels of the current step run on
@@ -537,6 +567,13 @@ def main():
             prev = rbs[(k_step[0] + 1) % 2]
             tg = time.perf_counter()
             gathered_n[0], gathered_n[1] = prev.gather_into(comm, 0, pinned)   # (waits for prev's kernels, not for cur's)
+            gather_s[0] += time.perf_counter() - tg
+        elif seg is not None and k_step[0] > 0:
+            prev = rbs[(k_step[0] + 1) % 2]
+            tg = time.perf_counter()
+            seg.begin()
+            used = prev.fetch_into(seg.records_view(), seg.blob_view())        # (waits for prev's kernels, not for cur's)
+            seg.commit(prev.n, used)
             gather_s[0] += time.perf_counter() - tg
         k_step[0] += 1
 
@@ -578,6 +615,18 @@ def main():
     # sanity: the timed work is the real work (every junction refined; tests/test_gpu_bench_shapes.py compares exactly these
     # batches with oracle/_ref)
     n_ok = [int(x.fetch()[0]["ok"].sum()) for x in rbs]
+    shm_seen = None
+    if seg is not None:
+        if world > 1:
+            dist.barrier()   # every rank has committed its last download
+        if rank == 0:        # what the merging process sees: every rank's last batch, read in place
+            shm_seen = []
+            for sg in segs_all:
+                got = sg.read(abi.result_dtype())
+                shm_seen.append(None if got is None else {"rank": sg.rank, "batches_committed": int(got[0]), "records": int(got[1].shape[0]),
+                                                          "refined_ok": int(got[1]["ok"].sum()), "blob_bytes": int(got[2].shape[0])})
+            gathered_n[0] = sum(x["records"] for x in shm_seen if x)
+            gathered_n[1] = sum(x["blob_bytes"] for x in shm_seen if x)
 
     # the same launches ONE AT A TIME (rounds 1-2's headline mode): what a launch costs when it has the chip to itself
     alone = None
@@ -643,8 +692,9 @@ def main():
                        "launches_in_flight": 1 if multi else 2,
                        "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
                        "value_is": "inputs resident in HBM, results left in HBM (bench contract); host_inclusive = SURVEY.md 8d's definition",
-                       "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if comm is not None else None),
-                       "gather_ms_per_step": (gather_s[0] / max(args.steps, 1) * 1e3 if comm is not None else None),
+                       "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if (comm is not None or seg is not None) else None),
+                       "shared_memory_segments_seen_by_rank0": shm_seen,
+                       "gather_ms_per_step": (gather_s[0] / max(args.steps, 1) * 1e3 if (comm is not None or seg is not None) else None),
                        "ms_per_step_per_rank": per_rank_ms, "kernels_ms_per_step_rank0": ms_split},
             "host_inclusive": hi,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -677,6 +727,12 @@ def main():
         x.free()
     if comm is not None:
         comm.close()
+    for sg in segs_all[1:]:
+        sg.close()
+    if world > 1 and seg is not None:
+        dist.barrier()       # (readers unmap before the owners unlink)
+    if seg is not None:
+        seg.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

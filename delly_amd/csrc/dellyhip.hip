@@ -1221,6 +1221,23 @@ int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* para
   return create_shared_on(share_with, params, out, nullptr);
 }
 
+int dellyhip_host_register(dellyhip_ctx* c, void* p, uint64_t bytes) {
+  if (!c || !p || !bytes) return fail(DELLYHIP_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
+  if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "hipHostRegister", e);
+  return 0;
+}
+
+int dellyhip_host_unregister(dellyhip_ctx* c, void* p) {
+  if (!c || !p) return fail(DELLYHIP_E_ARG, "null argument");
+  HIPCHK(hipSetDevice(c->device));
+  (void)hipDeviceSynchronize();   // (a copy into the range may still be in flight)
+  hipError_t e = hipHostUnregister(p);
+  if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "hipHostUnregister", e);
+  return 0;
+}
+
 uint64_t dellyhip_trim_memory(dellyhip_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);

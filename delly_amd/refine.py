@@ -33,7 +33,7 @@ EXPORTS = [
     "dellyhip_nwjobs_free", "dellyhip_nwjobs_kernel_ms", "dellyhip_generate_probes_batch", "dellyhip_batch_probes",
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
-    "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
+    "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_host_register", "dellyhip_host_unregister", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
     "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
 ]
 
@@ -154,6 +154,13 @@ class Context:
         out = (C.c_void_p * 2)()
         self._check(self.lib.dellyhip_compute_streams(self._ctx, out))
         return int(out[0] or 0), int(out[1] or 0)
+
+    def host_register(self, address, nbytes):
+        """pins caller memory (e.g. a shared-memory segment) for fetch / gather destinations (dellyhip_host_register)"""
+        self._check(self.lib.dellyhip_host_register(self._ctx, C.c_void_p(address), C.c_uint64(nbytes)))
+
+    def host_unregister(self, address):
+        self._check(self.lib.dellyhip_host_unregister(self._ctx, C.c_void_p(address)))
 
     def trim_memory(self):
         """returns the device / pinned blocks the library keeps parked to the HIP runtime (dellyhip_trim_memory) -> bytes"""
@@ -455,6 +462,15 @@ class ResidentBatch:
         ptr, nbytes = C.c_void_p(), C.c_uint64(0)
         self.ctx._check(self.ctx.lib.dellyhip_batch_device_results(self.ctx._ctx, self._b, C.byref(ptr), C.byref(nbytes)))
         return ptr.value, nbytes.value
+
+    def fetch_into(self, records, blob):
+        """dellyhip_batch_fetch into caller memory: records = uint8 array of >= n * sizeof(record) bytes, blob = uint8 array
+        (both e.g. views of a pinned shared-memory segment) -> bytes of blob used"""
+        assert records.dtype == np.uint8 and blob.dtype == np.uint8 and records.nbytes >= self.n * abi.result_dtype().itemsize
+        used = C.c_uint64(0)
+        self.ctx._check(self.ctx.lib.dellyhip_batch_fetch(self.ctx._ctx, self._b, C.c_void_p(records.ctypes.data), C.c_void_p(blob.ctypes.data),
+                                                          C.c_uint64(blob.nbytes), C.byref(used)))
+        return int(used.value)
 
     def fetch(self):
         res = np.zeros(self.n, dtype=abi.result_dtype())

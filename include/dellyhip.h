@@ -142,6 +142,13 @@ int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* para
  * The streams belong to the library; do not destroy them. */
 int dellyhip_compute_streams(dellyhip_ctx* ctx, void* out[2]);
 
+/* Pins [p, p + bytes) of the CALLER's host memory for the device (hipHostRegister), so that dellyhip_batch_fetch /
+ * dellyhip_gather_results write into it at the PCIe rate -- e.g. a POSIX shared-memory segment that the process which
+ * writes the VCF has mapped too: on one node every rank then returns its results over its OWN PCIe link and no
+ * collective carries them.  For bindings that do not link the HIP runtime themselves. */
+int dellyhip_host_register(dellyhip_ctx* ctx, void* p, uint64_t bytes);
+int dellyhip_host_unregister(dellyhip_ctx* ctx, void* p);
+
 /* Memory policy: device and pinned host blocks the library releases (freed batches, destroyed contexts and streams)
  * are parked in a process-wide free list per device and handed out again -- they are not returned to the HIP runtime
  * while the process lives, so the footprint is the high-water mark of what was alive at once (parked blocks are capped

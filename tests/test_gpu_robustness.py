@@ -1,6 +1,8 @@
 """-m gpu: host-side robustness of the C-ABI (round-1 advisor findings): device memory is returned by every
 entry point, a resident batch gives the same records on every run, malformed junction records are rejected
 with DELLYHIP_E_ARG before any kernel sees them."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,30 @@ def test_parked_memory_is_capped(monkeypatch):
     assert all(np.array_equal(r0[f], r1[f]) for f in r0.dtype.names)
     ctx.trim_memory()
     ctx.close()
+
+
+def test_fetch_into_a_pinned_shared_memory_segment(gpu_ctx):
+    """the no-collective return path of bench.py --gpus N: dellyhip_host_register over a POSIX shared-memory segment,
+    dellyhip_batch_fetch straight into it, a second mapping of the segment (the merging process) reads the same records"""
+    from delly_amd import shmreturn
+    b = synth.make_batch(500, mode="mixed", seed=4)
+    gpu_ctx.set_chromosomes(b.chroms)
+    rb = gpu_ctx.upload(b)
+    rb.run(); rb.sync()
+    want_r, want_b = rb.fetch()
+    rbytes = abi.result_dtype().itemsize
+    seg = shmreturn.Segment("pytest_%d" % os.getpid(), 0, 600, rbytes, 500 * 3100 + 64, create=True)
+    seg.pin(gpu_ctx)
+    for lap in range(2):
+        seg.begin()
+        used = rb.fetch_into(seg.records_view(), seg.blob_view())
+        seg.commit(rb.n, used)
+    reader = shmreturn.Segment("pytest_%d" % os.getpid(), 0, 600, rbytes, 500 * 3100 + 64, create=False)
+    seqno, rec, blob = reader.read(abi.result_dtype())
+    assert seqno == 2 and rec.shape[0] == 500
+    assert all(np.array_equal(rec[f], want_r[f]) for f in want_r.dtype.names)
+    assert blob.tobytes() == want_b.tobytes()
+    del rec, blob
+    reader.close()
+    rb.free()
+    seg.close()

@@ -176,3 +176,70 @@ def test_shard_range_partitions():
                 f, c = shard.shard_range(n, r, w)
                 seen.extend(range(f, f + c))
             assert seen == list(range(n))
+
+
+def _shm_worker(rank, world, port, n_total, out_dir):
+    """every rank writes its own results into its shared-memory segment (what dellyhip_batch_fetch does on the GPU box:
+    bench.py --gpus N), rank 0 maps all of them and merges in place -- no collective carries results"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import abi, shard, shmreturn, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rb = abi.result_dtype().itemsize
+    seg = shmreturn.Segment("t%d" % port, rank, 64, rb, 1 << 20, create=True)
+    dist.barrier()
+    others = [shmreturn.Segment("t%d" % port, r, 64, rb, 1 << 20, create=False) for r in range(world) if r != rank] if rank == 0 else []
+    first, count = shard.shard_range(n_total, rank, world)
+    for lap in range(3):   # three batches through the same segment; the last one is what rank 0 merges
+        b = synth.make_batch(count, mode="mixed", seed=9 + 2 - lap, first=first)
+        res, blob = pyoracle.Oracle("port").refine_batch(b, want_alignment=False)
+        seg.begin()
+        assert seg.read(abi.result_dtype()) is None            # a reader never sees a half-written batch
+        seg.records_view()[:res.nbytes] = np.frombuffer(res.tobytes(), dtype=np.uint8)
+        seg.blob_view()[:blob.nbytes] = blob
+        seg.commit(count, blob.nbytes)
+    dist.barrier()
+    if rank == 0:
+        parts = []
+        for sg in [seg] + others:
+            seqno, rec, bl = sg.read(abi.result_dtype())
+            assert seqno == 3
+            parts.append((rec.copy(), bl.copy()))
+        np.save(os.path.join(out_dir, "shm_records.npy"), np.concatenate([p[0].view(np.uint8) for p in parts]))
+        np.save(os.path.join(out_dir, "shm_blob_sizes.npy"), np.array([p[1].nbytes for p in parts]))
+        np.save(os.path.join(out_dir, "shm_blob.npy"), np.concatenate([p[1] for p in parts]))
+    for sg in others:
+        sg.close()
+    dist.barrier()
+    seg.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_return_through_shared_memory_segments(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from delly_amd import abi, shard, synth
+    n_total = 29
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_shm_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    rec = np.load(os.path.join(str(tmp_path), "shm_records.npy")).view(abi.result_dtype())
+    sizes = np.load(os.path.join(str(tmp_path), "shm_blob_sizes.npy"))
+    blob = np.load(os.path.join(str(tmp_path), "shm_blob.npy"))
+    at, base = 0, 0
+    for r in (0, 1):
+        first, count = shard.shard_range(n_total, r, 2)
+        b = synth.make_batch(count, mode="mixed", seed=9, first=first)
+        ref, rblob = pyoracle.Oracle("port").refine_batch(b, want_alignment=False)
+        mine = rec[at:at + count]
+        for f in ref.dtype.names:
+            assert np.array_equal(mine[f], ref[f]), (r, f)
+        assert blob[base:base + sizes[r]].tobytes() == rblob.tobytes()
+        at += count
+        base += int(sizes[r])
+    assert at == rec.shape[0]
