@@ -108,6 +108,21 @@ def test_port_vs_reference_fresh_seeds(port, reference, mode, n_reads, n):
     compare(pr, pb, rr, rb, label="port-vs-reference")
 
 
+@pytest.mark.parametrize("genome", ["lowcx", "real"])
+@pytest.mark.parametrize("mode,n_reads,n,extra", [("c2", 0, 240, {}), ("mixed", 0, 120, dict(junction_ins=6)), ("mixed", 5, 36, dict(dup_reads=True)),
+                                                  ("ins", 0, 60, {})])
+def test_port_vs_reference_where_the_tie_breaks_decide(port, reference, genome, mode, n_reads, n, extra):
+    """the restatement against the reference's own code on the sequence of the round-3 GPU suite (tests/test_gpu_lowcx.py):
+    homopolymers, STRs, tandem duplications, repeated segments (every low-complexity kind twenty times at n = 240), and windows
+    of the real chromosome -- join, refRight, traceback and UPGMA ties (src/needle.h:107-123,160-191, src/msa.h:46-89)"""
+    real = synth.load_real_chromosome() if genome == "real" else None
+    b = synth.make_batch(n, mode=mode, n_reads=n_reads, seed=4242, genome=genome, real=real, **extra)
+    rr, rb = reference.refine_batch(b)
+    pr, pb = port.refine_batch(b)
+    compare(pr, pb, rr, rb, label="port-vs-reference %s %s" % (genome, mode))
+    assert int(rr["ok"].sum()) >= n // 4
+
+
 @pytest.mark.parametrize("kw", [dict(mode="lr", n_reads=5, sub_rate=0.05, seed=91), dict(mode="lr", sub_rate=0.02, seed=92),
                                 dict(mode="lr", n_reads=4, sub_rate=0.03, seed=93, first=4)])
 def test_port_vs_reference_long_read_fresh(port, reference, kw):
