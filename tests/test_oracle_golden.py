@@ -123,6 +123,19 @@ def test_port_vs_reference_where_the_tie_breaks_decide(port, reference, genome, 
     assert int(rr["ok"].sum()) >= n // 4
 
 
+@pytest.mark.parametrize("kw", [dict(mode="lr", sub_rate=0.02, seed=171), dict(mode="lr", n_reads=5, sub_rate=0.06, seed=172),
+                                dict(mode="lrins", n_reads=5, sub_rate=0.06, seed=173)])
+def test_port_vs_reference_long_read_low_complexity(port, reference, kw):
+    """the long-read loop bodies (msaEdlib / msaWfa + alignConsensus) on low-complexity windows: edlib's co-optimal paths
+    (src/edlib.cpp:1021-1086) and the progressive consensus on repeats"""
+    b = synth.make_batch(8, genome="lowcx", real=synth.load_real_chromosome(), **kw)
+    p = abi.params_lr(realign=True)
+    pr, pb = port.refine_batch(b, params=p, n_threads=8)
+    rr, rb = reference.refine_batch(b, params=p, n_threads=8)
+    compare(pr, pb, rr, rb, label="lr lowcx")
+    assert int(rr["ok"].sum()) >= 3
+
+
 @pytest.mark.parametrize("kw", [dict(mode="lr", n_reads=5, sub_rate=0.05, seed=91), dict(mode="lr", sub_rate=0.02, seed=92),
                                 dict(mode="lr", n_reads=4, sub_rate=0.03, seed=93, first=4)])
 def test_port_vs_reference_long_read_fresh(port, reference, kw):
