@@ -449,38 +449,83 @@ class _StdoutToStderr:
         return False
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly as the driver's
+    command line does (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), and become that launcher."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.gpus > have and not args.oversubscribe:
+        raise SystemExit("bench.py: --gpus %d but this node has %d GPU(s); a run that would print n_gpus=%d without using them is "
+                         "refused (development: --oversubscribe puts every rank on device 0)" % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--junctions", type=int, default=10000, help="junctions per GPU per step")
+    ap.add_argument("--repeats", type=int, default=25, help="N = 1: how often the K-step region is timed (value = the median region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the U_full / insertion side measurements")
     ap.add_argument("--no-host-inclusive", action="store_true", help="skip the pipelined host-buffer measurement")
     ap.add_argument("--no-alone", action="store_true", help="skip the one-launch-at-a-time pass behind the timed region (profiling runs)")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
-    ap.add_argument("--gather", choices=("shm", "rccl"), default="shm",
-                    help="N > 1: how the results of a step reach rank 0 -- shm: every rank downloads its own share into a POSIX "
-                         "shared-memory segment rank 0 has mapped (no collective); rccl: dellyhip_gather_results to rank 0's HBM + D2H")
+    ap.add_argument("--gather", choices=("both", "shm", "rccl"), default="both",
+                    help="N > 1: how the results of a step reach rank 0 -- rccl: dellyhip_gather_results to rank 0's HBM (RCCL "
+                         "ncclSend / ncclRecv over xGMI) + D2H there, the all-gatherv BASELINE's north_star names: this is `value`; shm: "
+                         "every rank downloads its own share into a POSIX shared-memory segment rank 0 has mapped (no collective): "
+                         "`config.shm_return_*`; both (default): the two timed regions one after the other in the same run")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="development / the two-process test on a one-GPU box: every rank drives device 0, torch.distributed runs on gloo, "
+                         "and the gather protocol runs on the shared-memory transport (dellyhip_comm_create_hostlink) because RCCL "
+                         "refuses a communicator whose ranks share a device")
     ap.add_argument("--force-comm", action="store_true",
                     help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
                          "overlapping step k) on ONE GPU with a one-rank communicator")
+    ap.add_argument("--dump-rank0-view", default="", help="N > 1: rank 0 writes what it holds after the last step of each return path "
+                                                          "(records + blob per path) to this .npz (tests compare it with the checker)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _launch_ranks(args)        # (does not return)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to print a line whose n_gpus is not "
+                         "the number of ranks that ran" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.oversubscribe:
+        local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device %d (%d visible); --oversubscribe shares device 0" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+            dist.init_process_group("gloo" if args.oversubscribe else "nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+    dev = torch.device("cpu") if args.oversubscribe else torch.device("cuda:%d" % local)   # where the control-plane tensors live
 
     from delly_amd import build as dbuild
     from delly_amd import abi, refine, synth
@@ -506,26 +551,52 @@ def main():
     # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
     # streams the library verified to run side by side, so the tail of one step's launch runs under the head of the next
     # (one 10 000-junction launch alone: 2.4 wavefronts per resident slot, a 50 us ramp and a 180 us tail of 0.40 ms).
-    # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: one context, the gather of step k - 1
-    # overlaps the kernels of step k.
+    # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: one context, the return of step k - 1's
+    # results overlaps the kernels of step k.
     ctxs = [ctx] if multi else [ctx, refine.Context(device=local, share_with=ctx)]
     streams = list(ctx.compute_streams())[:len(ctxs)]
     rbs = [ctxs[k % len(ctxs)].upload(b) for k, b in enumerate(batches)]
+
+    # ---- the return paths of an N > 1 step -------------------------------------------------------------------------------
+    paths = []
+    if multi:
+        paths = ["rccl", "shm"] if args.gather == "both" else [args.gather]
     comm = None
-    gather_kind = "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"
+    comm_info = None
     pinned = None
     seg = None
     segs_all = []
-    if multi and args.gather == "shm":
-        # N > 1 (default): every rank alternates between TWO resident batches; the results of the batch refined in the
-        # previous step are compacted on the device and downloaded -- inside the step, while the kernels of the current step
-        # run -- into a POSIX shared-memory segment the rank owns and has pinned (dellyhip_host_register); rank 0, which would
-        # run mergeSort / write the VCF, maps every rank's segment and reads the records in place.  Every rank uses its OWN
-        # PCIe link and no collective carries results (the gather to one rank funnels all of them through
-        # rank 0's link).
+    rb_bytes = abi.result_dtype().itemsize
+    if "rccl" in paths:
+        # every rank alternates between TWO resident batches; the results of the batch refined in the previous step are gathered to
+        # rank 0 -- dellyhip_gather_results in the host library: the transport called directly (one all-gather of the (count, bytes)
+        # pairs, one of the root's readiness, grouped sends / receives of the records + consensus / allele bytes)
+        # -- AND copied into rank 0's pinned host memory (VCF emission needs them there) while the kernels of the current step
+        # run on their own stream.  The 128-byte RCCL id travels through torch.distributed.
+        with _StdoutToStderr():
+            if args.oversubscribe:
+                comm = refine.Comm(ctx, rank, world, hostlink="bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), world))
+            else:
+                ids = [refine.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(ids, src=0)
+                comm = refine.Comm(ctx, rank, world, ids[0])
+            if world > 1:
+                dist.barrier()   # (torch's own communicator comes up here: its banner too)
+        comm_info = comm.info()
+        if comm_info["transport_ranks"] != world:
+            raise SystemExit("bench.py: the %s transport reports %d ranks, %d were launched" % (comm_info["kind"], comm_info["transport_ranks"], world))
+        if rank == 0:
+            cap_n = world * n + 64
+            cap_b = world * n * 1400 + (1 << 20)
+            pinned = (torch.empty(cap_n * rb_bytes, dtype=torch.uint8).pin_memory(), torch.empty(cap_b, dtype=torch.uint8).pin_memory())
+    if "shm" in paths:
+        # every rank downloads the results of the previous step -- compacted on the device, inside the step, while the kernels of
+        # the current step run -- into a POSIX shared-memory segment it owns and has pinned (dellyhip_host_register); rank 0, which
+        # would run mergeSort / write the VCF, maps every rank's segment and reads the records in place.  Every rank uses its OWN
+        # PCIe link and no collective carries results (the gather funnels all of them through rank 0's link).
         from delly_amd import shmreturn
         tag = "%s_%d" % (os.environ.get("MASTER_PORT", "0"), world)
-        rb_bytes = abi.result_dtype().itemsize
         cap_n, cap_b = n + 64, n * 1400 + (1 << 20)
         seg = shmreturn.Segment(tag, rank, cap_n, rb_bytes, cap_b, create=True)
         seg.pin(ctx)
@@ -533,42 +604,28 @@ def main():
             dist.barrier()
         if rank == 0:
             segs_all = [seg] + [shmreturn.Segment(tag, r, cap_n, rb_bytes, cap_b, create=False) for r in range(1, world)]
-        gather_kind = ("per-rank D2H (dellyhip_batch_fetch) into a pinned POSIX shared-memory segment mapped by rank 0, inside the "
-                       "step; download of step k-1 overlaps the kernels of step k; no collective")
-    elif multi:
-        # --gather rccl: every rank alternates between TWO resident batches; the results of the batch refined in the previous step
-        # are gathered to rank 0 -- dellyhip_gather_results in the host library: RCCL called directly (ncclAllGather of
-        # the counts, grouped ncclSend / ncclRecv of the records + consensus / allele bytes) -- AND copied
-        # into rank 0's pinned host memory (VCF emission needs them there) while the kernels of the current step run on
-        # their own stream.  One run + one gather per step.  The 128-byte RCCL id travels through torch.distributed.
-        ids = [refine.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        with _StdoutToStderr():
-            comm = refine.Comm(ctx, rank, world, ids[0])
-            if world > 1:
-                dist.barrier()   # (torch's own communicator comes up here: its banner too)
-        gather_kind = ("dellyhip_gather_results: RCCL ncclSend/ncclRecv of records + consensus/allele bytes to rank 0's HBM, then D2H into "
-                       "its pinned host memory, all inside the step; gather of step k-1 overlaps the kernels of step k")
-        if rank == 0:
-            cap_n = world * n + 64
-            cap_b = world * n * 1400 + (1 << 20)
-            pinned = (torch.empty(cap_n * abi.result_dtype().itemsize, dtype=torch.uint8).pin_memory(),
-                      torch.empty(cap_b, dtype=torch.uint8).pin_memory())
+    path_text = {
+        "rccl": ("dellyhip_gather_results: %s of records + consensus/allele bytes to rank 0's HBM, then D2H into its pinned host memory, all "
+                 "inside the step; gather of step k-1 overlaps the kernels of step k"
+                 % ("shared-memory transport (hostlink; RCCL refuses ranks that share a device)" if args.oversubscribe else "RCCL ncclSend/ncclRecv over xGMI")),
+        "shm": ("per-rank D2H (dellyhip_batch_fetch) into a pinned POSIX shared-memory segment mapped by rank 0, inside the step; download of "
+                "step k-1 overlaps the kernels of step k; no collective"),
+        None: "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"}
     gathered_n = [0, 0]
     gather_s = [0.0]
     k_step = [0]
+    mode = [paths[0] if paths else None]
 
     def step():
         i = k_step[0] % len(rbs)
         cur = rbs[i]
         cur.run(streams[i % len(streams)])
-        if comm is not None and k_step[0] > 0:
+        if mode[0] == "rccl" and k_step[0] > 0:
             prev = rbs[(k_step[0] + 1) % 2]
             tg = time.perf_counter()
             gathered_n[0], gathered_n[1] = prev.gather_into(comm, 0, pinned)   # (waits for prev's kernels, not for cur's)
             gather_s[0] += time.perf_counter() - tg
-        elif seg is not None and k_step[0] > 0:
+        elif mode[0] == "shm" and k_step[0] > 0:
             prev = rbs[(k_step[0] + 1) % 2]
             tg = time.perf_counter()
             seg.begin()
@@ -577,63 +634,109 @@ def main():
             gather_s[0] += time.perf_counter() - tg
         k_step[0] += 1
 
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_region(warm):
+        """`warm` untimed steps, then EXACTLY args.steps steps bracketed by barrier + synchronize -> (seconds, gather seconds)"""
+        k_step[0] = 0
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        gather_s[0] = 0.0
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        return time.perf_counter() - t0, gather_s[0]
+
     for i, x in enumerate(rbs):   # set-up, not a step: every resident batch has run once (workspaces sized, results fetchable)
         x.run(streams[i % len(streams)])
     torch.cuda.synchronize()
-    for _ in range(max(args.warmup, 1 if multi else 0)):
-        step()
-    torch.cuda.synchronize()
-    for x in rbs:
-        x.kernel_ms()  # reset the kernel timers
-    gather_s[0] = 0.0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kms = [x.kernel_ms() for x in rbs]          # (sync + averages over each batch's launches)
+
+    def max_over_ranks(sec):
+        t = torch.tensor([sec], dtype=torch.float64, device=dev)
+        per = [sec]
+        if world > 1:
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per = [float(x.item()) for x in allt]
+        return max(per), per
+
+    region = {}          # per return path: seconds (max over ranks), per-rank seconds, gather seconds on rank 0, what rank 0 holds
+    rank0_view = {}
+    if not multi:
+        for x in rbs:
+            x.kernel_ms()  # reset the kernel timers
+        dts = []
+        for rep in range(max(1, args.repeats)):
+            d, _ = timed_region(args.warmup if rep == 0 else 0)
+            dts.append(d)
+        order = sorted(dts)
+        dt = order[(len(order) - 1) // 2]        # the median region: a region that was actually timed, K steps between two synchronisations
+        region[None] = {"dt": dt, "per_rank": [dt], "dts": dts}
+    else:
+        for pth in paths:
+            mode[0] = pth
+            for x in rbs:
+                x.kernel_ms()
+            d, gs = timed_region(max(args.warmup, 1))
+            mx, per = max_over_ranks(d)
+            region[pth] = {"dt": mx, "per_rank": per, "gather_s": gs, "records": gathered_n[0], "blob_bytes": gathered_n[1]}
+            if pth == "shm":
+                if world > 1:
+                    dist.barrier()   # every rank has committed its last download
+                if rank == 0:        # what the merging process sees: every rank's last batch, read in place
+                    seen, recs, blobs = [], [], []
+                    for sg in segs_all:
+                        got = sg.read(abi.result_dtype())
+                        seen.append(None if got is None else {"rank": sg.rank, "batches_committed": int(got[0]), "records": int(got[1].shape[0]),
+                                                              "refined_ok": int(got[1]["ok"].sum()), "blob_bytes": int(got[2].shape[0])})
+                        if got is not None and args.dump_rank0_view:
+                            recs.append(np.array(got[1])); blobs.append(np.array(got[2]))
+                    region[pth]["segments"] = seen
+                    region[pth]["records"] = sum(x["records"] for x in seen if x)
+                    region[pth]["blob_bytes"] = sum(x["blob_bytes"] for x in seen if x)
+                    if args.dump_rank0_view:
+                        rank0_view["shm"] = (recs, blobs)
+            elif rank == 0 and args.dump_rank0_view:
+                nr, nb = gathered_n
+                rank0_view["rccl"] = (np.frombuffer(pinned[0].numpy()[:nr * rb_bytes].tobytes(), dtype=abi.result_dtype()), pinned[1].numpy()[:nb].copy())
+    first = paths[0] if paths else None
+    dt = region[first]["dt"]
+    per_rank_ms = [x / args.steps * 1e3 for x in region[first]["per_rank"]]
+    kms = [x.kernel_ms() for x in rbs]          # (sync + averages over each batch's launches; N > 1: of the last return path)
     dps = [x.dp_kernel_ms() for x in rbs]
     used = [i for i, k in enumerate(kms) if k[2] > 0]
     launches = sum(kms[i][2] for i in used)
     ms_split = sum(kms[i][0] * kms[i][2] for i in used) / max(launches, 1)
     ms_dp = sum(dps[i] * kms[i][2] for i in used) / max(launches, 1)
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local)
-    per_rank_ms = [dt / args.steps * 1e3]
+    ran = torch.tensor([1 if launches > 0 else 0], dtype=torch.int64, device=dev)
     if world > 1:
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        dist.all_reduce(ran)
+    ranks_that_ran = int(ran.item())
 
     # sanity: the timed work is the real work (every junction refined; tests/test_gpu_bench_shapes.py compares exactly these
     # batches with oracle/_ref)
     n_ok = [int(x.fetch()[0]["ok"].sum()) for x in rbs]
-    shm_seen = None
-    if seg is not None:
-        if world > 1:
-            dist.barrier()   # every rank has committed its last download
-        if rank == 0:        # what the merging process sees: every rank's last batch, read in place
-            shm_seen = []
-            for sg in segs_all:
-                got = sg.read(abi.result_dtype())
-                shm_seen.append(None if got is None else {"rank": sg.rank, "batches_committed": int(got[0]), "records": int(got[1].shape[0]),
-                                                          "refined_ok": int(got[1]["ok"].sum()), "blob_bytes": int(got[2].shape[0])})
-            gathered_n[0] = sum(x["records"] for x in shm_seen if x)
-            gathered_n[1] = sum(x["blob_bytes"] for x in shm_seen if x)
+    if rank == 0 and args.dump_rank0_view:
+        dump = {"world": np.int64(world), "junctions": np.int64(n), "steps": np.int64(args.steps), "warmup": np.int64(max(args.warmup, 1))}
+        if "rccl" in rank0_view:
+            dump["rccl_records"], dump["rccl_blob"] = rank0_view["rccl"]
+        for r, (rec, bl) in enumerate(zip(*rank0_view.get("shm", ([], [])))):
+            dump["shm_records_%d" % r], dump["shm_blob_%d" % r] = rec, bl
+        np.savez(args.dump_rank0_view, **dump)
 
     # the same launches ONE AT A TIME (rounds 1-2's headline mode): what a launch costs when it has the chip to itself
     alone = None
     if not multi and not args.no_alone:
         for x in rbs:
             x.kernel_ms()
-        reps = 12
+        reps = 24
         ta = time.perf_counter()
         for k in range(reps):
             x = rbs[k % len(rbs)]
@@ -658,7 +761,7 @@ def main():
             rbs = []
             hi = host_inclusive_rate(ctx, batches, 0)
             if world > 1:
-                hv = torch.tensor([hi["value"], hi["wall_s"]], dtype=torch.float64, device="cuda:%d" % local)
+                hv = torch.tensor([hi["value"], hi["wall_s"]], dtype=torch.float64, device=dev)
                 allh = [torch.zeros_like(hv) for _ in range(world)]
                 dist.all_gather(allh, hv)
                 hi["per_rank_junctions_per_s"] = [float(x[0].item()) for x in allh]
@@ -672,44 +775,84 @@ def main():
         value = total_units / dt
         ach = n * ALG_BYTES_PER_U / (ms_dp * 1e-3) / 1e9 if ms_dp > 0 else 0.0
         traffic = _measured_traffic()
+        cfg = {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU and step, 150 bp consensus x 1 kb ref window" % n,
+               "workload_detail": "alignConsensus (longNeedle + split detection), bit-exact; steps rotate through %d different resident batches%s"
+                                  % (len(batches), "" if multi else ", consecutive steps on two contexts / two HIP streams (two launches in flight)"),
+               "launches_in_flight": 1 if multi else 2,
+               "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok_min": min(n_ok), "parallelism": "junction-sharded x%d" % world,
+               "ranks_launched": world, "ranks_that_ran_kernels": ranks_that_ran,
+               "value_is": "inputs resident in HBM, results left in HBM (bench contract)" if not multi else
+                           "inputs resident in HBM; the previous step's results reach rank 0's host memory inside every step (return path: config.return_path)",
+               "kernels_ms_per_step_rank0": ms_split}
+        if not multi:
+            dts = region[None]["dts"]
+            rates = sorted(world * n * args.steps / d for d in dts)
+            cfg.update({"timed_regions": len(dts), "value_is_region": "median of the timed K-step regions",
+                        "value_min": rates[0], "value_max": rates[-1], "value_median": rates[(len(rates) - 1) // 2],
+                        "timed_seconds_total": sum(dts)})
+            if alone:   # flat copies: the driver's record keeps scalars of `config` / `roofline` only
+                cfg.update({"one_launch_at_a_time_alignments_per_s": alone["alignments_per_s"], "one_launch_at_a_time_ms_per_step": alone["ms_per_step"],
+                            "one_launch_at_a_time_kernel_ms": alone["kernel_ms"]})
+        else:
+            cfg["return_path"] = path_text[first]
+            cfg["gather_ms_per_step"] = region[first]["gather_s"] / max(args.steps, 1) * 1e3
+            cfg["gathered_records_on_rank0"] = region[first]["records"]
+            cfg["gathered_blob_bytes_on_rank0"] = region[first]["blob_bytes"]
+            cfg["ms_per_step_min_rank"] = min(per_rank_ms)
+            cfg["ms_per_step_max_rank"] = max(per_rank_ms)
+            if comm_info is not None:
+                cfg["rccl_ranks"] = comm_info["transport_ranks"]     # ncclCommCount (hostlink: attached processes)
+                cfg["gather_transport"] = comm_info["kind"]
+            cfg["oversubscribed_one_device"] = bool(args.oversubscribe)
+            for pth in paths[1:]:
+                r = region[pth]
+                cfg["%s_return_alignments_per_s" % pth] = total_units / r["dt"]
+                cfg["%s_return_ms_per_step" % pth] = r["dt"] / args.steps * 1e3
+                cfg["%s_return_gather_ms_per_step" % pth] = r["gather_s"] / max(args.steps, 1) * 1e3
+                cfg["%s_return_records_seen_by_rank0" % pth] = r["records"]
+                cfg["%s_return_blob_bytes_seen_by_rank0" % pth] = r["blob_bytes"]
+                cfg["%s_return_path" % pth] = path_text[pth]
+        if isinstance(hi, dict) and "value" in hi:
+            cfg["host_inclusive_alignments_per_s"] = hi["value"]       # SURVEY.md 8d's definition: host buffers in -> host buffers out
+            cfg["host_inclusive_wall_s"] = hi["wall_s"]
+            cfg["host_inclusive_batches"] = hi["batches"]
+            cfg["host_inclusive_ms_per_batch"] = hi["ms_per_batch"]
         out = {
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,
             "unit": "alignments/s",
-            "n_gpus": world,
+            "n_gpus": ranks_that_ran if not args.oversubscribe else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int16",
+            "dtype": "int32-exact (uint8 / int16 storage)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU and step, 150 bp consensus x 1 kb "
-                                   "ref window, alignConsensus (longNeedle + split detection), bit-exact; steps rotate through %d "
-                                   "different resident batches%s" % (n, len(batches), "" if multi else
-                                                                     ", consecutive steps on two contexts / two HIP streams (two launches in flight)"),
-                       "launches_in_flight": 1 if multi else 2,
-                       "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok": n_ok, "parallelism": "junction-sharded x%d" % world,
-                       "value_is": "inputs resident in HBM, results left in HBM (bench contract); host_inclusive = SURVEY.md 8d's definition",
-                       "gather": gather_kind, "gathered_per_step_on_rank0": ({"records": gathered_n[0], "blob_bytes": gathered_n[1]} if (comm is not None or seg is not None) else None),
-                       "shared_memory_segments_seen_by_rank0": shm_seen,
-                       "gather_ms_per_step": (gather_s[0] / max(args.steps, 1) * 1e3 if (comm is not None or seg is not None) else None),
-                       "ms_per_step_per_rank": per_rank_ms, "kernels_ms_per_step_rank0": ms_split},
+            "config": cfg,
             "host_inclusive": hi,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "split_sparse_kernel (sparse longNeedle: furthest-reaching tables per deficit level, one junction per wavefront, alignment + split detection fused)",
+                         "kernel": "split_sparse_kernel (sparse longNeedle, one junction per wavefront, alignment + split detection fused)",
                          "kernel_ms": ms_dp, "all_split_kernels_ms": ms_split, "kernel_launches_timed": launches,
-                         "kernel_ms_is": ("HIP events around each launch on its stream over the timed region; two launches are in flight, "
-                                          "so a launch shares the chip for part of its life (one_launch_at_a_time has the isolated figure)"
+                         "kernel_ms_is": ("HIP events around each launch; two launches in flight share the chip (kernel_ms_alone: isolated)"
                                           if not multi else "HIP events around each launch on its stream over the timed region"),
+                         "kernel_ms_alone": alone["kernel_ms"] if alone else None,
+                         "achieved_alone": alone["achieved"] if alone else None,
+                         "frac_alone": alone["frac"] if alone else None,
                          "one_launch_at_a_time": alone,
                          "alg_bytes_per_launch": n * ALG_BYTES_PER_U,
                          "binding_roof": "integer VALU issue / latency, DP state on chip (SURVEY.md 8d); the HBM fraction is reported because BASELINE asks for it",
+                         "valu_cycles_per_wave64_instr_at_8_waves_per_simd": VALU_CEILING["cycles_per_wave64_valu_at_8_waves_per_simd"],
+                         "valu_cycles_per_instr_one_wave": VALU_CEILING["cycles_per_instruction_one_wave"],
+                         "sclk_mhz_measured": VALU_CEILING["sclk_mhz_measured"],
                          "valu_ceiling": VALU_CEILING,
-                         "note": "the kernel's cost depends on the junctions' deficits (extras.deficit_sweep); cells of the dense matrices are not computed, so no GCUPS figure"},
+                         "note": "the kernel's cost depends on the junctions' deficits (extras.deficit_sweep); no GCUPS figure"},
         }
+        if multi:
+            out["config"]["segments_seen_by_rank0"] = region.get("shm", {}).get("segments")
+            out["config"]["ms_per_step_per_rank"] = per_rank_ms
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch)
         elif not args.no_cpu_baseline:
@@ -722,6 +865,19 @@ def main():
                     out["extras"]["deficit_sweep"] = deficit_sweep(refine.Context(device=local), synth, local, with_cpu=not args.no_cpu_baseline)
                 except Exception as e:  # side figure only
                     out["extras"]["deficit_sweep"] = {"error": repr(e)}
+            # flat copies of the side rows the verdicts track (the driver's record keeps scalars of `config` only)
+            for name, key in (("u_c2_40k_junctions", "u_c2_40k_alignments_per_s"), ("u_full_n20", "u_full_n20_2k_junctions_per_s"),
+                              ("u_full_n20_10k_junctions", "u_full_n20_10k_junctions_per_s"), ("ins_svt4", "ins_svt4_junctions_per_s"),
+                              ("lr_c4_align_consensus", "lr_c4_align_consensus_junctions_per_s"),
+                              ("lr_c4_msaedlib_n15", "lr_c4_msaedlib_n15_junctions_per_s"), ("lr_ins_msawfa_n15", "lr_ins_msawfa_n15_junctions_per_s")):
+                row = out["extras"].get(name)
+                if isinstance(row, dict) and "junctions_per_s" in row:
+                    out["config"][key] = row["junctions_per_s"]
+            sw = out["extras"].get("deficit_sweep")
+            if isinstance(sw, dict):
+                for name, row in sw.items():
+                    if isinstance(row, dict) and "alignments_per_s" in row:
+                        out["config"]["deficit_sweep_%s_alignments_per_s" % name] = row["alignments_per_s"]
         print(json.dumps(out), flush=True)
     for x in rbs:
         x.free()

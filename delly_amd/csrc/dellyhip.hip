@@ -1867,8 +1867,7 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
 // ---- multi-GPU: cost-balanced sharding + RCCL gather of the results ---------------------------
 struct dellyhip_comm {
   int32_t rank = 0, world = 1;
-  ncclComm_t nccl = nullptr;
-  DevBuf<uint64_t> d_counts;   // (count, bytes) of every rank
+  std::unique_ptr<dh::Link> link;      // null: one rank, no transport
   DevBuf<uint8_t> rec_all, blob_all;   // root: receive areas
 };
 
@@ -1911,61 +1910,149 @@ int dellyhip_comm_create(dellyhip_ctx* c, const void* id128, int32_t rank, int32
   m->rank = rank;
   m->world = world;
   if (world > 1 || id128) {   // (world == 1 with an id: a real one-rank RCCL communicator -- exercises the RCCL path on one GPU)
-    dh::RcclApi& A = dh::rccl_api();
-    if (!A.error.empty()) return fail(DELLYHIP_E_RUNTIME, A.error.c_str());
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof id);
-    const ncclResult_t r = A.CommInitRank(&m->nccl, world, id, rank);
-    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
-    int rc = m->d_counts.alloc(2 * (size_t)world + 2);
-    if (rc) return rc;
+    std::unique_ptr<dh::RcclLink> L(new dh::RcclLink());
+    if (int rc = L->init(id128, rank, world)) return fail(rc, L->err.c_str());
+    m->link = std::move(L);
   }
   *out = m.release();
   return 0;
 }
 
+int dellyhip_comm_create_hostlink(dellyhip_ctx* c, const char* name, int32_t rank, int32_t world, dellyhip_comm** out) {
+  if (!out || !name || world < 1 || rank < 0 || rank >= world) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (c) HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<dellyhip_comm> m(new dellyhip_comm());
+  m->rank = rank;
+  m->world = world;
+  std::unique_ptr<dh::HostLink> L(new dh::HostLink());
+  if (int rc = L->init(name, rank, world, c != nullptr)) return fail(rc, L->err.c_str());
+  m->link = std::move(L);
+  *out = m.release();
+  return 0;
+}
+
+int dellyhip_comm_info(dellyhip_comm* m, int32_t* rank, int32_t* world, int32_t* transport_ranks, char* kind16) {
+  if (!m) return fail(DELLYHIP_E_ARG, "null argument");
+  if (rank) *rank = m->rank;
+  if (world) *world = m->world;
+  if (transport_ranks) *transport_ranks = m->link ? m->link->transport_ranks() : 1;
+  if (kind16) snprintf(kind16, 16, "%s", m->link ? m->link->kind() : "none");
+  return 0;
+}
+
 void dellyhip_comm_destroy(dellyhip_comm* m) {
   if (!m) return;
-  if (m->nccl) (void)dh::rccl_api().CommDestroy(m->nccl);
   delete m;
 }
 
-// the exchange itself: afterwards the root holds every rank's records (rank order) and compact blobs in HBM
 // A local failure must not leave the other ranks inside a collective: every rank ALWAYS takes part in the exchange of the
 // (count, bytes) pairs -- a rank whose batch could not be synchronised or compacted sends count = GATHER_ERR -- and in a second
 // one-word exchange after the root has sized its receive areas; all ranks then agree on whether the Send / Recv group runs.
 static const uint64_t GATHER_ERR = ~0ull;
 
+// first exchange: all[2 r] = records of rank r, all[2 r + 1] = bytes of its compact blob.  Every rank returns the same
+// verdict: 0, or an error if ANY rank reported a failure (the failing rank keeps its own message).
+static int exchange_sizes(dellyhip_comm* m, hipStream_t s, uint64_t count, uint64_t bytes, int local_rc, const std::string& local_err,
+                          std::vector<uint64_t>& all) {
+  const int W = m->world;
+  all.assign(2 * (size_t)W, 0);
+  if (!m->link) {
+    if (local_rc) return fail(local_rc, local_err.c_str());
+    all[0] = count;
+    all[1] = bytes;
+    return 0;
+  }
+  const uint64_t mine[2] = {local_rc ? GATHER_ERR : count, local_rc ? 0 : bytes};
+  if (int rc = m->link->allgather2(mine, all.data(), s)) return fail(rc, m->link->err.c_str());
+  for (int r2 = 0; r2 < W; ++r2)
+    if (all[2 * r2] == GATHER_ERR) {
+      if (local_rc) return fail(local_rc, local_err.c_str());
+      char msg[96];
+      snprintf(msg, sizeof msg, "dellyhip_gather_results: rank %d failed before the exchange", r2);
+      return fail(DELLYHIP_E_RUNTIME, msg);
+    }
+  return 0;
+}
+
+// second exchange: is the root ready to receive?  (one word per rank; only the root's matters)
+static int exchange_ready(dellyhip_comm* m, hipStream_t s, int32_t root, bool root_failed) {
+  if (!m->link) return root_failed ? fail(DELLYHIP_E_NOMEM, "dellyhip_gather_results: the root could not allocate its receive areas") : 0;
+  const int W = m->world;
+  const uint64_t ready[2] = {(m->rank == root && root_failed) ? GATHER_ERR : 0, 0};
+  std::vector<uint64_t> seen(2 * (size_t)W, 0);
+  if (int rc = m->link->allgather2(ready, seen.data(), s)) return fail(rc, m->link->err.c_str());
+  if (seen[2 * (size_t)root] == GATHER_ERR)
+    return fail(DELLYHIP_E_NOMEM, "dellyhip_gather_results: the root could not allocate its receive areas");
+  return 0;
+}
+
+int dellyhip_comm_exchange_sizes(dellyhip_ctx* c, dellyhip_comm* m, uint64_t count, uint64_t bytes, int32_t failed, uint64_t* all) {
+  if (!m || !all) return fail(DELLYHIP_E_ARG, "null argument");
+  if (c) HIPCHK(hipSetDevice(c->device));
+  else if (m->link && std::string(m->link->kind()) == "rccl") return fail(DELLYHIP_E_ARG, "an RCCL communicator needs its context");
+  std::vector<uint64_t> v;
+  const int rc = exchange_sizes(m, c ? c->stream : nullptr, count, bytes, failed ? DELLYHIP_E_RUNTIME : 0,
+                                "dellyhip_comm_exchange_sizes: this rank reported a failure", v);
+  for (size_t i = 0; i < v.size(); ++i) all[i] = v[i];
+  return rc;
+}
+
+int dellyhip_comm_exchange_ready(dellyhip_ctx* c, dellyhip_comm* m, int32_t root, int32_t root_failed) {
+  if (!m || root < 0 || root >= m->world) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (c) HIPCHK(hipSetDevice(c->device));
+  else if (m->link && std::string(m->link->kind()) == "rccl") return fail(DELLYHIP_E_ARG, "an RCCL communicator needs its context");
+  return exchange_ready(m, c ? c->stream : nullptr, root, root_failed != 0);
+}
+
+// gatherv of one opaque payload per rank: the protocol of gather_device (sizes, root readiness, one send / receive group)
+// on caller buffers -- device pointers with a context, host pointers on a device-less hostlink
+int dellyhip_comm_gather_bytes(dellyhip_ctx* c, dellyhip_comm* m, int32_t root, const void* mine, uint64_t bytes, void* out,
+                               uint64_t out_cap, uint64_t* sizes) {
+  if (!m || root < 0 || root >= m->world || (bytes && !mine)) return fail(DELLYHIP_E_ARG, "bad argument");
+  if (c) HIPCHK(hipSetDevice(c->device));
+  else if (m->link && std::string(m->link->kind()) == "rccl") return fail(DELLYHIP_E_ARG, "an RCCL communicator needs its context");
+  hipStream_t s = c ? c->stream : nullptr;
+  const int W = m->world;
+  const bool is_root = m->rank == root;
+  std::vector<uint64_t> all;
+  if (int rc = exchange_sizes(m, s, 1, bytes, 0, std::string(), all)) return rc;
+  uint64_t tot = 0;
+  std::vector<uint64_t> first(W + 1, 0);
+  for (int r = 0; r < W; ++r) { first[r] = tot; tot += all[2 * r + 1]; }
+  if (sizes)
+    for (int r = 0; r < W; ++r) sizes[r] = all[2 * r + 1];
+  const bool short_buf = is_root && (tot > out_cap || (tot && !out));
+  if (int rc = exchange_ready(m, s, root, short_buf)) return rc;
+  uint8_t* o = static_cast<uint8_t*>(out);
+  if (W > 1) {
+    dh::Link& L = *m->link;
+    if (int rc = L.group_begin()) return fail(rc, L.err.c_str());
+    if (!is_root) L.send(mine, bytes, root, s);
+    else
+      for (int q = 0; q < W; ++q)
+        if (q != root) L.recv(o + first[q], all[2 * q + 1], q, s);
+    if (int rc = L.group_end(s)) return fail(rc, L.err.c_str());
+  }
+  if (is_root && bytes) {
+    if (c) { HIPCHK(hipMemcpyAsync(o + first[root], mine, bytes, hipMemcpyDefault, s)); HIPCHK(hipStreamSynchronize(s)); }
+    else memcpy(o + first[root], mine, bytes);
+  }
+  return 0;
+}
+
+// the exchange itself: afterwards the root holds every rank's records (rank order) and compact blobs in HBM
 static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, std::vector<uint64_t>& all,
                          std::vector<uint64_t>& first_n, std::vector<uint64_t>& first_b, const void** d_rec, const void** d_blob) {
   std::vector<uint64_t> off;
   uint64_t used = 0;
   int local_rc = dellyhip_batch_sync(c, b);
   if (!local_rc) local_rc = compact_batch(c, b, off, &used);
+  if (!local_rc && getenv("DELLYHIP_TEST_FAIL_GATHER_RANK") && atoi(getenv("DELLYHIP_TEST_FAIL_GATHER_RANK")) == m->rank)
+    local_rc = fail(DELLYHIP_E_RUNTIME, "dellyhip_gather_results: failure injected by DELLYHIP_TEST_FAIL_GATHER_RANK");   // (tests of the abort protocol)
   const std::string local_err = local_rc ? g_err : std::string();
   const int W = m->world;
   const bool is_root = m->rank == root;
-  all.assign(2 * (size_t)W, 0);
-  if (!m->nccl) {   // one rank, no communicator
-    if (local_rc) return local_rc;
-    all[0] = (uint64_t)b->n;
-    all[1] = used;
-  } else {
-    dh::RcclApi& A = dh::rccl_api();
-    const uint64_t mine[2] = {local_rc ? GATHER_ERR : (uint64_t)b->n, local_rc ? 0 : used};
-    HIPCHK(hipMemcpyAsync(m->d_counts.p + 2 * W, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-    ncclResult_t r = A.AllGather(m->d_counts.p + 2 * W, m->d_counts.p, 2, ncclUint64, m->nccl, c->stream);
-    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
-    HIPCHK(hipMemcpyAsync(all.data(), m->d_counts.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    for (int r2 = 0; r2 < W; ++r2)
-      if (all[2 * r2] == GATHER_ERR) {
-        if (local_rc) return fail(local_rc, local_err.c_str());
-        char msg[96];
-        snprintf(msg, sizeof msg, "dellyhip_gather_results: rank %d failed before the exchange", r2);
-        return fail(DELLYHIP_E_RUNTIME, msg);
-      }
-  }
+  if (int rc = exchange_sizes(m, c->stream, (uint64_t)b->n, used, local_rc, local_err, all)) return rc;
   uint64_t tot_n = 0, tot_b = 0;
   first_n.assign(W + 1, 0);
   first_b.assign(W + 1, 0);
@@ -1981,39 +2068,26 @@ static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, i
   *d_rec = rec_src;
   *d_blob = b->blob_compact.p;
   if (W > 1) {
-    dh::RcclApi& A = dh::rccl_api();
+    dh::Link& L = *m->link;
     int root_rc = 0;
     if (is_root) {
       if ((root_rc = m->rec_all.reserve(std::max<uint64_t>(tot_n * sizeof(dellyhip_result), 1)))) root_rc = DELLYHIP_E_NOMEM;
       else if ((root_rc = m->blob_all.reserve(std::max<uint64_t>(tot_b, 1)))) root_rc = DELLYHIP_E_NOMEM;
+      if (!root_rc && getenv("DELLYHIP_TEST_FAIL_GATHER_ROOT")) root_rc = DELLYHIP_E_NOMEM;   // (tests of the abort protocol)
     }
-    // second exchange: is the root ready to receive?  (one word per rank; only the root's matters)
-    {
-      const uint64_t ready[2] = {(is_root && root_rc) ? GATHER_ERR : 0, 0};
-      std::vector<uint64_t> seen(2 * (size_t)W, 0);
-      HIPCHK(hipMemcpyAsync(m->d_counts.p + 2 * W, ready, sizeof ready, hipMemcpyHostToDevice, c->stream));
-      ncclResult_t r = A.AllGather(m->d_counts.p + 2 * W, m->d_counts.p, 2, ncclUint64, m->nccl, c->stream);
-      if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
-      HIPCHK(hipMemcpyAsync(seen.data(), m->d_counts.p, seen.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      if (seen[2 * (size_t)root] == GATHER_ERR)
-        return fail(DELLYHIP_E_NOMEM, "dellyhip_gather_results: the root could not allocate its receive areas");
-    }
-    ncclResult_t r = A.GroupStart();
-    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
+    if (int rc = exchange_ready(m, c->stream, root, is_root && root_rc)) return rc;
+    if (int rc = L.group_begin()) return fail(rc, L.err.c_str());
     if (!is_root) {
-      if (b->n) r = A.Send(rec_src, (size_t)b->n * sizeof(dellyhip_result), ncclUint8, root, m->nccl, c->stream);
-      if (r == ncclSuccess && used) r = A.Send(b->blob_compact.p, used, ncclUint8, root, m->nccl, c->stream);
+      if (b->n) L.send(rec_src, (uint64_t)b->n * sizeof(dellyhip_result), root, c->stream);
+      if (used) L.send(b->blob_compact.p, used, root, c->stream);
     } else {
-      for (int q = 0; q < W && r == ncclSuccess; ++q) {
+      for (int q = 0; q < W; ++q) {
         if (q == root) continue;
-        if (all[2 * q]) r = A.Recv(m->rec_all.p + first_n[q] * sizeof(dellyhip_result), all[2 * q] * sizeof(dellyhip_result), ncclUint8, q, m->nccl, c->stream);
-        if (r == ncclSuccess && all[2 * q + 1]) r = A.Recv(m->blob_all.p + first_b[q], all[2 * q + 1], ncclUint8, q, m->nccl, c->stream);
+        if (all[2 * q]) L.recv(m->rec_all.p + first_n[q] * sizeof(dellyhip_result), all[2 * q] * sizeof(dellyhip_result), q, c->stream);
+        if (all[2 * q + 1]) L.recv(m->blob_all.p + first_b[q], all[2 * q + 1], q, c->stream);
       }
     }
-    const ncclResult_t r2 = A.GroupEnd();
-    if (r != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r));
-    if (r2 != ncclSuccess) return fail(DELLYHIP_E_RUNTIME, A.GetErrorString(r2));
+    if (int rc = L.group_end(c->stream)) return fail(rc, L.err.c_str());
     if (is_root) {   // the root's own share, device to device
       if (b->n) HIPCHK(hipMemcpyAsync(m->rec_all.p + first_n[root] * sizeof(dellyhip_result), rec_src, (size_t)b->n * sizeof(dellyhip_result), hipMemcpyDeviceToDevice, c->stream));
       if (used) HIPCHK(hipMemcpyAsync(m->blob_all.p + first_b[root], b->blob_compact.p, used, hipMemcpyDeviceToDevice, c->stream));
@@ -2175,6 +2249,8 @@ struct dellyhip_stream {
   // so that the sparse kernel of the slot after next need not wait for them -- and lost: 24 M junctions/s against 29.5,
   // tools/stream_matrix.sh.)
   int held = -1;                    // slot whose output the caller holds since the last collect()
+  int test_fail_collect = 0;        // tests: the next n collects fail after their batch has finished (env DELLYHIP_TEST_FAIL_COLLECT)
+  int test_fail_submit = 0;         // tests: the next n submits fail after their upload has been enqueued (env DELLYHIP_TEST_FAIL_SUBMIT)
   double blob_per_junction = 0;     // running estimate: bytes of compact blob per junction (sizes the first D2H copy)
   // host seconds since creation / the last dellyhip_stream_stats(reset): validation + routing + staging | kernel launches |
   // compaction + download enqueue | waiting in collect | slow-path batches (leftovers routed at collect) | blob top-ups
@@ -2367,6 +2443,8 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
   st->want_alignment = want_alignment ? 1 : 0;
   st->slots = std::vector<StreamSlot>((size_t)depth);
   if (const char* t = getenv("DELLYHIP_LOG")) st->log = atoi(t);
+  if (const char* t = getenv("DELLYHIP_TEST_FAIL_COLLECT")) st->test_fail_collect = atoi(t);
+  if (const char* t = getenv("DELLYHIP_TEST_FAIL_SUBMIT")) st->test_fail_submit = atoi(t);
   st->t_created = now_s();
   {
     DeviceStreams& D = ensure_device_streams(c->device);
@@ -2425,6 +2503,19 @@ void dellyhip_stream_destroy(dellyhip_stream* st) {
   delete st;   // (the HIP streams belong to the device: device_streams)
 }
 
+// A submit / collect that fails after work has been enqueued must not leave copies or kernels in flight on buffers the next
+// submit overwrites, nor a slot that stays "submitted" forever: wait for the device, hand the slot back (the batch is
+// dropped; the error is the caller's to report), keep the message of the failure that got us here.
+static int slot_bail(StreamSlot& S, int rc) {
+  const std::string keep = g_err;
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
+  S.state = 0;
+  S.down_pending = false;
+  g_err = keep;
+  return rc;
+}
+
 int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_junction* junc, const char* seq_blob, const uint64_t* seq_off,
                            uint64_t n_seq, uint64_t tag) {
   if (!st) return fail(DELLYHIP_E_ARG, "null argument");
@@ -2443,7 +2534,7 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   int rc = slot_pump(st, nullptr);
   if (rc) return rc;
   rc = batch_upload_impl(c, n, junc, seq_blob, seq_off, n_seq, st->with_msa, st->want_alignment, &b, &o);
-  if (rc) return rc;
+  if (rc) return slot_bail(S, rc);   // (the upload may have enqueued part of its copies before it failed)
   // pinned output block: header | records | consensus lengths (msa) | compact blob (at most every slot full)
   S.n = n;
   S.tag = tag;
@@ -2453,7 +2544,8 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   if (st->blob_per_junction <= 0) st->blob_per_junction = st->with_msa ? 1400.0 : 1100.0;
   // capacity: what the estimate asks for with head room; a batch that needs more grows the block at collect time
   S.blob_cap = std::min<uint64_t>((uint64_t)n * b->out_stride, (uint64_t)(st->blob_per_junction * 2.0 * n) + (1u << 16));
-  if ((rc = S.out.reserve(S.o_blob + S.blob_cap + 64))) return rc;
+  if ((rc = S.out.reserve(S.o_blob + S.blob_cap + 64))) return slot_bail(S, rc);
+  if (st->test_fail_submit > 0) { --st->test_fail_submit; return slot_bail(S, fail(DELLYHIP_E_NOMEM, "dellyhip_stream_submit: failure injected by DELLYHIP_TEST_FAIL_SUBMIT")); }
   S.blob_cap = S.out.n - S.o_blob - 64;   // (use what the block has)
   S.blob_cap = std::min<uint64_t>(S.blob_cap, (uint64_t)n * b->out_stride);
   StreamHeader* H = reinterpret_cast<StreamHeader*>(S.out.p);
@@ -2463,9 +2555,9 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   const double t1 = now_s();
   double t2 = t1;
   if (n > 0) {
-    if ((rc = dellyhip_batch_run(c, b, nullptr))) return rc;
+    if ((rc = dellyhip_batch_run(c, b, nullptr))) return slot_bail(S, rc);
     t2 = now_s();
-    if ((rc = slot_compact_and_download(st, S, false))) return rc;
+    if ((rc = slot_compact_and_download(st, S, false))) return slot_bail(S, rc);
   }
   S.state = 1;
   ++st->n_submit;
@@ -2495,8 +2587,8 @@ int dellyhip_stream_pending(dellyhip_stream* st) {
   return st ? (int)(st->n_submit - st->n_collect) : 0;
 }
 
-int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results, const char** blob, uint64_t* blob_len, int32_t* n_out,
-                            uint64_t* tag) {
+static int stream_collect_impl(dellyhip_stream* st, const dellyhip_result** results, const char** blob, uint64_t* blob_len, int32_t* n_out,
+                               uint64_t* tag) {
   if (!st) return fail(DELLYHIP_E_ARG, "null argument");
   dellyhip_stream_release(st);   // the previous collect()'s output block is released now
   if (st->n_collect == st->n_submit) return fail(DELLYHIP_E_ARG, "dellyhip_stream_collect: nothing submitted");
@@ -2516,6 +2608,7 @@ int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results
     st->t_wait += now_s() - tw0;
     int rc = dellyhip_batch_sync(c, b);
     if (rc) return rc;
+    if (st->test_fail_collect > 0) { --st->test_fail_collect; return fail(DELLYHIP_E_NOMEM, "dellyhip_stream_collect: failure injected by DELLYHIP_TEST_FAIL_COLLECT"); }
     if (b->lazy_pending && H->sps_left > 0) {
       ++st->n_slow;
       // rare: junctions beyond the sparse kernel's shapes or level budget -> dense kernels now, then compact again
@@ -2576,6 +2669,21 @@ int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results
   return 0;
 }
 
+int dellyhip_stream_collect(dellyhip_stream* st, const dellyhip_result** results, const char** blob, uint64_t* blob_len, int32_t* n_out,
+                            uint64_t* tag) {
+  if (!st) return fail(DELLYHIP_E_ARG, "null argument");
+  const uint64_t before = st->n_collect;
+  const bool had = st->n_collect != st->n_submit;
+  const int rc = stream_collect_impl(st, results, blob, blob_len, n_out, tag);
+  if (rc && had && st->n_collect == before) {
+    // the oldest batch could not be completed (out of memory while growing the output block, a failed dense-kernel pass,
+    // a device error): it is dropped -- the slot is free again and the stream goes on with the next batch
+    slot_bail(st->slots[before % st->slots.size()], rc);
+    ++st->n_collect;
+  }
+  return rc;
+}
+
 // The host-buffer entry points run through a persistent one-slot stream per (mode, want_alignment): staging and device
 // buffers survive between calls, so a call costs the copies and the kernels, not hipMalloc / hipFree.
 static int run_host_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* junc, const char* seq_blob,
@@ -2588,7 +2696,7 @@ static int run_host_batch(dellyhip_ctx* c, int32_t n, const dellyhip_junction* j
   if (!c->host_streams[key] && (rc = dellyhip_stream_create(c, 1, with_msa, want_alignment, &c->host_streams[key]))) return rc;
   dellyhip_stream* st = c->host_streams[key];
   dellyhip_stream_release(st);
-  if ((rc = dellyhip_stream_submit(st, n, junc, seq_blob, seq_off, n_seq, 0))) return rc;
+  if ((rc = dellyhip_stream_submit(st, n, junc, seq_blob, seq_off, n_seq, 0))) return rc;   // (the slot is free again: slot_bail)
   const dellyhip_result* r = nullptr;
   const char* blob = nullptr;
   uint64_t len = 0;

@@ -35,6 +35,7 @@ EXPORTS = [
     "dellyhip_gather_results", "dellyhip_gather_results_device",
     "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_host_register", "dellyhip_host_unregister", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
     "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
+    "dellyhip_comm_create_hostlink", "dellyhip_comm_info", "dellyhip_comm_exchange_sizes", "dellyhip_comm_exchange_ready", "dellyhip_comm_gather_bytes",
 ]
 
 
@@ -65,6 +66,21 @@ def load_library():
         lib.dellyhip_stream_stats.restype = None
         lib.dellyhip_trim_memory.restype = C.c_uint64
         lib.dellyhip_trim_memory.argtypes = [C.c_void_p]
+        # explicit prototypes wherever a 64-bit integer or a pointer could otherwise travel as a default C int
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+        lib.dellyhip_stream_create.argtypes = [vp, i32, i32, i32, vp]
+        lib.dellyhip_stream_destroy.argtypes = [vp]
+        lib.dellyhip_stream_submit.argtypes = [vp, i32, vp, vp, vp, u64, u64]
+        lib.dellyhip_stream_collect.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.dellyhip_stream_pending.argtypes = [vp]
+        lib.dellyhip_stream_release.argtypes = [vp]
+        lib.dellyhip_host_register.argtypes = [vp, vp, u64]
+        lib.dellyhip_host_unregister.argtypes = [vp, vp]
+        lib.dellyhip_comm_create_hostlink.argtypes = [vp, C.c_char_p, i32, i32, vp]
+        lib.dellyhip_comm_info.argtypes = [vp, vp, vp, vp, vp]
+        lib.dellyhip_comm_exchange_sizes.argtypes = [vp, vp, u64, u64, i32, vp]
+        lib.dellyhip_comm_exchange_ready.argtypes = [vp, vp, i32, i32]
+        lib.dellyhip_comm_gather_bytes.argtypes = [vp, vp, i32, vp, u64, vp, u64, vp]
         _lib = lib
     return _lib
 
@@ -104,17 +120,62 @@ def comm_unique_id():
 
 
 class Comm:
-    """One RCCL communicator per process / GPU (dellyhip_comm_create); world == 1 needs no id."""
+    """One communicator per process (dellyhip_comm_create: RCCL, one process per GPU; world == 1 needs no id).
+    hostlink=<name>: the same communicator over POSIX shared memory (dellyhip_comm_create_hostlink) -- the ranks of one
+    node, also several per GPU; ctx=None gives a device-less one for the protocol exchanges only."""
 
-    def __init__(self, ctx, rank=0, world=1, unique_id=None):
+    def __init__(self, ctx, rank=0, world=1, unique_id=None, hostlink=None):
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.lib = ctx.lib if ctx is not None else load_library()
         self._c = C.c_void_p()
-        idbuf = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None
-        ctx._check(ctx.lib.dellyhip_comm_create(ctx._ctx, idbuf, self.rank, self.world, C.byref(self._c)))
+        cx = ctx._ctx if ctx is not None else None
+        if hostlink is not None:
+            rc = self.lib.dellyhip_comm_create_hostlink(cx, str(hostlink).encode(), self.rank, self.world, C.byref(self._c))
+        else:
+            idbuf = (C.c_ubyte * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+            rc = self.lib.dellyhip_comm_create(cx, idbuf, self.rank, self.world, C.byref(self._c))
+        self._check(rc)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DellyHipError(rc, self.lib.dellyhip_last_error().decode())
+
+    def info(self):
+        """-> dict(rank, world, transport_ranks = what RCCL / the hostlink itself reports, kind)"""
+        r, w, t = C.c_int32(), C.c_int32(), C.c_int32()
+        kind = C.create_string_buffer(16)
+        self._check(self.lib.dellyhip_comm_info(self._c, C.byref(r), C.byref(w), C.byref(t), kind))
+        return {"rank": r.value, "world": w.value, "transport_ranks": t.value, "kind": kind.value.decode()}
+
+    def exchange_sizes(self, count, nbytes, failed=False):
+        """first collective step of the gather (dellyhip_comm_exchange_sizes) -> [(count, bytes)] of every rank; raises on
+        EVERY rank if any rank reports a failure"""
+        out = (C.c_uint64 * (2 * self.world))()
+        cx = self.ctx._ctx if self.ctx is not None else None
+        self._check(self.lib.dellyhip_comm_exchange_sizes(cx, self._c, C.c_uint64(int(count)), C.c_uint64(int(nbytes)), int(bool(failed)), out))
+        return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(self.world)]
+
+    def exchange_ready(self, root=0, root_failed=False):
+        """second collective step (dellyhip_comm_exchange_ready): raises on every rank if the root could not size its buffers"""
+        cx = self.ctx._ctx if self.ctx is not None else None
+        self._check(self.lib.dellyhip_comm_exchange_ready(cx, self._c, int(root), int(bool(root_failed))))
+
+    def gather_bytes(self, payload, root=0, cap=None):
+        """dellyhip_comm_gather_bytes on HOST memory (device-less hostlink): payload = bytes-like -> (bytes on the root / None
+        elsewhere, sizes of every rank)"""
+        buf = np.frombuffer(bytes(payload), dtype=np.uint8)
+        cap = int(cap if cap is not None else 1 << 24)
+        out = np.zeros(cap if self.rank == root else 0, dtype=np.uint8)
+        sizes = (C.c_uint64 * self.world)()
+        cx = self.ctx._ctx if self.ctx is not None else None
+        self._check(self.lib.dellyhip_comm_gather_bytes(cx, self._c, int(root), buf.ctypes.data if buf.size else None, C.c_uint64(buf.size),
+                                                        out.ctypes.data if out.size else None, C.c_uint64(out.size), sizes))
+        sz = [int(x) for x in sizes]
+        return (out[:sum(sz)].tobytes() if self.rank == root else None), sz
 
     def close(self):
         if self._c:
-            self.ctx.lib.dellyhip_comm_destroy(self._c)
+            self.lib.dellyhip_comm_destroy(self._c)
             self._c = C.c_void_p()
 
     def __del__(self):

@@ -215,6 +215,10 @@ int dellyhip_stream_submit(dellyhip_stream* stream, int32_t n_junctions, const d
                            const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq, uint64_t tag);
 int dellyhip_stream_collect(dellyhip_stream* stream, const dellyhip_result** results, const char** blob,
                             uint64_t* blob_len, int32_t* n_junctions, uint64_t* tag);
+/* Errors: a submit that fails leaves the stream as it was before the call (anything it had enqueued has been waited for,
+ * the slot is free).  A collect that fails DROPS the batch it was waiting for -- the stream's pending count goes down by
+ * one, the slot is free again and the following collects return the following batches; the synchronous entry points
+ * (dellyhip_refine_batch, ...) therefore stay usable after a failed call. */
 /* Gives the output block of the last collect() back before the next collect() does (a caller that has copied what it
  * needs; with depth 1 this is what allows the next submit). */
 void dellyhip_stream_release(dellyhip_stream* stream);
@@ -285,6 +289,36 @@ typedef struct dellyhip_comm dellyhip_comm;
 int dellyhip_comm_unique_id(void* id128);
 int dellyhip_comm_create(dellyhip_ctx* ctx, const void* id128, int32_t rank, int32_t world, dellyhip_comm** out);
 void dellyhip_comm_destroy(dellyhip_comm* comm);
+
+/* The same communicator over POSIX shared memory instead of RCCL, for the ranks of ONE node: RCCL refuses a communicator
+ * whose ranks share a device, so this is the transport when several processes drive one GPU (oversubscribed runs, the
+ * two-process tests on a one-GPU box); device buffers are staged through the sender's pinned outbox segment.  `name`
+ * (<= 96 bytes, no '/') must be unique to the job -- rank 0 creates "/dellyhip_<name>_ctl", the others wait for it
+ * (DELLYHIP_LINK_TIMEOUT_S, default 120 s, bounds every wait: a dead peer is an error, not a hang).  ctx == NULL gives a
+ * device-less communicator on which only the two exchanges below can run (verification of the protocol without GPUs).
+ * dellyhip_gather_results(_device) run the same protocol code on either transport. */
+int dellyhip_comm_create_hostlink(dellyhip_ctx* ctx, const char* name, int32_t rank, int32_t world, dellyhip_comm** out);
+
+/* rank / world as created, transport_ranks = what the transport itself reports (ncclCommCount; attached processes of a
+ * hostlink; 1 without a transport), kind16 = "rccl" | "hostlink" | "none".  Any out pointer may be NULL. */
+int dellyhip_comm_info(dellyhip_comm* comm, int32_t* rank, int32_t* world, int32_t* transport_ranks, char* kind16);
+
+/* The two collective steps in front of the payload of dellyhip_gather_results, exposed so that the abort protocol can be
+ * verified on its own: (1) every rank contributes (count, bytes) -- or `failed` != 0 -- and receives all ranks' pairs in
+ * all[2 * world]; if ANY rank failed EVERY rank returns an error (the failing rank DELLYHIP_E_RUNTIME with its own message,
+ * the others naming the rank) and nobody goes on to the payload; (2) the root says whether it could size its receive
+ * areas; if not, every rank returns DELLYHIP_E_NOMEM.  Collective: all ranks call them in the same order.  ctx may be
+ * NULL for a device-less hostlink. */
+int dellyhip_comm_exchange_sizes(dellyhip_ctx* ctx, dellyhip_comm* comm, uint64_t count, uint64_t bytes, int32_t failed, uint64_t* all);
+int dellyhip_comm_exchange_ready(dellyhip_ctx* ctx, dellyhip_comm* comm, int32_t root, int32_t root_failed);
+
+/* gatherv of one opaque payload per rank on the same protocol (size exchange, root readiness, one send / receive group):
+ * the root receives the ranks' payloads back to back in rank order in out[0 .. sum sizes), sizes[r] = bytes of rank r (every
+ * rank gets the sizes).  A root whose out_cap is short makes every rank return DELLYHIP_E_NOMEM before any payload moves.
+ * With a context the pointers are device (or pinned / registered host) memory; on a device-less hostlink plain host memory.
+ * The gather of per-rank classifier results or probe blobs to the rank that merges them. */
+int dellyhip_comm_gather_bytes(dellyhip_ctx* ctx, dellyhip_comm* comm, int32_t root, const void* mine, uint64_t bytes,
+                               void* out, uint64_t out_cap, uint64_t* sizes);
 
 /* Gathers what dellyhip_batch_fetch returns -- result records AND consensus / "REF,ALT" (/ alignment) bytes -- of every
  * rank's batch to `root`: the all-gatherv of SURVEY.md 8e (RCCL has none: one ncclAllGather of the counts, then grouped

@@ -189,3 +189,53 @@ def test_fetch_into_a_pinned_shared_memory_segment(gpu_ctx):
     reader.close()
     rb.free()
     seg.close()
+
+
+def test_a_failed_call_does_not_wedge_the_host_buffer_entry_points(monkeypatch):
+    """the synchronous entry points run through a cached one-slot stream; a collect (or a submit) that fails
+    after work was enqueued used to leave the slot 'submitted' for ever -- every later call on the context failed with
+    'every slot is in flight or held'.  Now the failed batch is dropped and the next call works."""
+    b = synth.make_batch(300, mode="c2", seed=21)
+    ctx = refine.Context()
+    ctx.set_chromosomes(b.chroms)
+    want, wblob = ctx.refine(b)                       # (creates the cached stream of this mode without injection)
+    ctx.close()
+    for var in ("DELLYHIP_TEST_FAIL_COLLECT", "DELLYHIP_TEST_FAIL_SUBMIT"):
+        monkeypatch.setenv(var, "2")
+        ctx = refine.Context()
+        ctx.set_chromosomes(b.chroms)
+        for k in range(2):
+            with pytest.raises(refine.DellyHipError) as e:
+                ctx.refine(b)
+            assert e.value.code == abi.E_NOMEM and "injected" in str(e.value)
+        got, gblob = ctx.refine(b)
+        assert all(np.array_equal(got[f], want[f]) for f in want.dtype.names) and gblob.tobytes() == wblob.tobytes()
+        monkeypatch.delenv(var)
+        ctx.close()
+
+
+def test_a_failed_collect_drops_one_batch_of_a_pipelined_stream(monkeypatch):
+    bs = [synth.make_batch(200, mode="c2", seed=30 + k) for k in range(4)]
+    chroms = bs[0].chroms
+    ctx = refine.Context()
+    wants = []
+    for b in bs:
+        ctx.set_chromosomes(b.chroms)
+        wants.append(ctx.refine(b)[0])
+    monkeypatch.setenv("DELLYHIP_TEST_FAIL_COLLECT", "1")
+    # the batches carry their own chromosomes: one genome for the stream
+    import bench
+    chroms, batches = bench.one_genome(synth, bs)
+    ctx.set_chromosomes(chroms)
+    st = refine.Stream(ctx, depth=3)
+    monkeypatch.delenv("DELLYHIP_TEST_FAIL_COLLECT")
+    st.submit(batches[0], tag=0); st.submit(batches[1], tag=1)
+    with pytest.raises(refine.DellyHipError):
+        st.collect()
+    assert st.pending() == 1                          # batch 0 is gone, batch 1 still in flight
+    st.submit(batches[2], tag=2)
+    for k in (1, 2):
+        res, blob, tag = st.collect()[:3]
+        assert tag == k and np.array_equal(res["ok"], wants[k]["ok"]) and np.array_equal(res["hom_len"], wants[k]["hom_len"])
+    st.close()
+    ctx.close()
