@@ -30,6 +30,7 @@
 #include "lrwfa_kernel.hpp"
 #include "classify_kernel.hpp"
 #include "probes_kernel.hpp"
+#include "edlib_kernel.hpp"
 #include "comm.hpp"
 
 namespace {
@@ -2967,6 +2968,69 @@ int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const c
   if (h[4] > 0) {
     if (!ops || h[4] > ops_cap) return fail(DELLYHIP_E_ARG, "ops buffer too small");
     HIPCHK(hipMemcpy(ops, dops.p, h[4], hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// edlibAlign with everything its result struct holds, any shape the strip machinery takes (edlib_kernel.hpp)
+int dellyhip_edlib_align_full(dellyhip_ctx* c, const char* query, int32_t qn, const char* target, int32_t tn, int32_t k, int32_t mode,
+                              int32_t task, int32_t equalities, int32_t* edit_distance, int32_t* num_locations, int32_t* end_locs,
+                              int32_t* start_locs, int32_t loc_cap, unsigned char* ops, int32_t ops_cap, int32_t* ops_len) {
+  if (!c || !edit_distance || !num_locations || !ops_len || qn < 0 || tn < 0 || (qn && !query) || (tn && !target) || mode < 0 ||
+      mode > 2 || task < 0 || task > 2 || equalities < 0 || equalities > 1 || loc_cap < 0 || (loc_cap && !end_locs) ||
+      (task >= 1 && loc_cap && !start_locs))
+    return fail(DELLYHIP_E_ARG, "bad argument");
+  *ops_len = 0;
+  *num_locations = 0;
+  *edit_distance = -1;
+  if (qn == 0 || tn == 0) {  // edlib.cpp:160-178: one location, no start locations, no alignment (k is not looked at)
+    if (loc_cap < 1) return fail(DELLYHIP_E_ARG, "loc_cap");
+    *edit_distance = (mode == 0) ? std::max(qn, tn) : qn;
+    *num_locations = 1;
+    end_locs[0] = (mode == 0) ? tn - 1 : -1;
+    return 0;
+  }
+  if (tn > dh::LM_RMASK - 1 || qn > dh::LR_NMAX) return fail(DELLYHIP_E_LIMIT, "edlibAlign: target beyond 32766 or query beyond 32000 letters");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  dh::EdFullArgs a{};
+  a.qn = qn; a.tn = tn; a.mode = mode; a.task = task; a.eq = equalities;
+  a.bnd_stride = qn + 128;
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t at = o; o += (bytes + 255) & ~255ull; return at; };
+  take(4ull * (uint64_t)a.bnd_stride * 4);
+  a.off_tmp = take((uint64_t)qn + tn + 64);
+  a.off_lastcol = take(((uint64_t)tn + 2) * 4);
+  a.strip_words = (task == 2) ? dh::lm_dirs_words(tn, qn) : 64;
+  a.off_dirs = take(a.strip_words * 4);
+  const int32_t lcap = (mode == 0) ? 1 : tn + 1;
+  DevBuf<uint8_t> dq, dt, dops, ws;
+  DevBuf<int32_t> dout, dend, dstart;
+  if ((rc = dq.alloc(qn + 16)) || (rc = dt.alloc(tn + 16)) || (rc = dops.alloc((uint64_t)qn + tn + 64)) || (rc = ws.alloc(o)) || (rc = dout.alloc(8)) ||
+      (rc = dend.alloc(lcap)) || (rc = dstart.alloc(lcap)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(dq.p, query, qn, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(dt.p, target, tn, hipMemcpyHostToDevice, c->stream));
+  a.q = dq.p; a.t = dt.p; a.ws = ws.p; a.out = dout.p; a.end_locs = dend.p; a.start_locs = dstart.p; a.loc_cap = lcap;
+  a.ops = dops.p; a.ops_cap = qn + tn + 32;
+  hipLaunchKernelGGL(dh::edlib_full_kernel, dim3(1), dim3(dh::WAVE), 0, c->stream, a);
+  HIPCHK(hipGetLastError());
+  int32_t h[4];
+  HIPCHK(hipMemcpyAsync(h, dout.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (h[3]) return fail(DELLYHIP_E_LIMIT, "edlibAlign: the alignment exceeds the kernel's workspace");
+  if (k >= 0 && h[0] > k) return 0;   // editDistance = -1, no locations, no alignment (src/edlib.h: "-1 if ... larger than k")
+  *edit_distance = h[0];
+  *num_locations = h[1];
+  if (h[1] > loc_cap) return fail(DELLYHIP_E_ARG, "edlibAlign: loc_cap too small (needed count in *num_locations)");
+  if (h[1] > 0) {
+    HIPCHK(hipMemcpy(end_locs, dend.p, (size_t)h[1] * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (task >= 1) HIPCHK(hipMemcpy(start_locs, dstart.p, (size_t)h[1] * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  *ops_len = h[2];
+  if (h[2] > 0) {
+    if (!ops || h[2] > ops_cap) return fail(DELLYHIP_E_ARG, "ops buffer too small");
+    HIPCHK(hipMemcpy(ops, dops.p, h[2], hipMemcpyDeviceToHost));
   }
   return 0;
 }

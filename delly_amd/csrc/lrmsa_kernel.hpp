@@ -106,7 +106,7 @@ constexpr int LM_EQ = 2;    // extended-IUPAC additional equalities
 template <bool DIRS, bool LOC, int EQ>
 __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
                                          int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
-                                         int lane) {
+                                         int lane, int32_t* lastcol = nullptr) {
   constexpr int K = LRK;
   constexpr int POS = 1 << 28;
   const bool hw = (mode & LM_HW) != 0;
@@ -205,6 +205,7 @@ __device__ __noinline__ LmKeys lm_pass_t(const uint8_t* tp, int tstep, int tlen,
         kf = min(kf, ((unsigned)colq[i] << LM_RBITS) | (unsigned)r);
         kl = min(kl, ((unsigned)colq[i] << LM_RBITS) | (unsigned)(LM_RMASK - r));
       }
+      if (lastcol && r >= 0 && r <= tlen) lastcol[r] = colq[i];   // E[r][qlen] of every row (all optimal end locations: edlib_full_kernel)
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -233,11 +234,11 @@ constexpr int LM_EQFAST = 4;
 template <bool DIRS, bool LOC>
 __device__ __forceinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen, const uint8_t* qp, int qstep, int qlen, int q,
                                           int pad, int mode, int r0, const int32_t* bin, int32_t* bout, uint32_t* dirs,
-                                          int lane) {
+                                          int lane, int32_t* lastcol = nullptr) {
   if ((mode & LM_EQ) && (mode & LM_EQFAST))
-    return lm_pass_t<DIRS, LOC, 1>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
-  if (mode & LM_EQ) return lm_pass_t<DIRS, LOC, 2>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
-  return lm_pass_t<DIRS, LOC, 0>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane);
+    return lm_pass_t<DIRS, LOC, 1>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane, lastcol);
+  if (mode & LM_EQ) return lm_pass_t<DIRS, LOC, 2>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane, lastcol);
+  return lm_pass_t<DIRS, LOC, 0>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane, lastcol);
 }
 
 // ---- bit-vector flavour of the last-row pass (Hirschberg halves of edlib's NW PATH, edlib.cpp:1163-1389) -------------
@@ -850,11 +851,12 @@ __device__ __forceinline__ int lm_first_row(int qn) { return ((qn & 63) != 0) ? 
 
 // distance + end location over all target rows (strips); hw: LM_HW or 0 (SHW).  which = 0: first optimal end, 1: last
 __device__ __forceinline__ void lm_locate(const uint8_t* tp, int tstep, int tn, const uint8_t* qp, int qstep, int qn, int mode,
-                                          int32_t* bndA, int32_t* bndB, int lane, int& ed, int& first, int& last) {
+                                          int32_t* bndA, int32_t* bndB, int lane, int& ed, int& first, int& last,
+                                          int32_t* lastcol = nullptr) {
   const int Q = tn / LRS + 1;
   const int r0 = lm_first_row(qn);
   unsigned kf = 0xffffffffu, kl = 0xffffffffu;
-  if ((mode & LM_EQ) && (mode & LM_EQFAST) && tn >= 1 && qn >= 1 && tn <= MYERS_ROWS) {
+  if (!lastcol && (mode & LM_EQ) && (mode & LM_EQFAST) && tn >= 1 && qn >= 1 && tn <= MYERS_ROWS) {
     const bool hw = (mode & LM_HW) != 0;
     LmKeys k;
     if (tn <= WAVE * 32) k = lm_locate_myers<1>(tp, tstep, tn, qp, qstep, qn, hw, r0, lane);
@@ -868,7 +870,7 @@ __device__ __forceinline__ void lm_locate(const uint8_t* tp, int tstep, int tn, 
   for (int q = 0; q < Q; ++q) {
     const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
-    const LmKeys k = lm_pass<false, true>(tp, tstep, tn, qp, qstep, qn, q, 0, mode, r0, bin, bout, nullptr, lane);
+    const LmKeys k = lm_pass<false, true>(tp, tstep, tn, qp, qstep, qn, q, 0, mode, r0, bin, bout, nullptr, lane, lastcol);
     kf = min(kf, k.kf);
     kl = min(kl, k.kl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

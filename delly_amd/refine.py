@@ -35,7 +35,7 @@ EXPORTS = [
     "dellyhip_gather_results", "dellyhip_gather_results_device",
     "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_host_register", "dellyhip_host_unregister", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
     "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_rebase_gathered",
-    "dellyhip_comm_create_hostlink", "dellyhip_comm_info", "dellyhip_comm_exchange_sizes", "dellyhip_comm_exchange_ready", "dellyhip_comm_gather_bytes",
+    "dellyhip_comm_create_hostlink", "dellyhip_comm_info", "dellyhip_comm_exchange_sizes", "dellyhip_comm_exchange_ready", "dellyhip_comm_gather_bytes", "dellyhip_edlib_align_full",
 ]
 
 

@@ -500,6 +500,19 @@ int dellyhip_edlib_align(dellyhip_ctx* ctx, const char* query, int32_t query_len
                          int32_t target_len, int32_t mode, int32_t task, int32_t out[4],
                          unsigned char* ops, int32_t ops_cap, int32_t* ops_len);
 
+/* The whole of EdlibAlignResult (src/edlib.h:160-217) for one edlibAlign(query, target, edlibNewAlignConfig(k, mode, task,
+ * equalities ? the 20 extended-IUPAC pairs of src/assemble.h:425 : NULL, ...)) call: *edit_distance (-1 when k >= 0 and the
+ * distance exceeds k: then no locations and no alignment, src/edlib.h:166), ALL optimal end locations in ascending order
+ * (end_locs[0 .. *num_locations)), the start location of each (task LOC / PATH; start_locs may be NULL for DISTANCE) and
+ * the EDLIB_EDOP_* alignment of the first pair (task PATH), including edlib's Hirschberg regime (src/edlib.cpp:1188-1389).
+ * Shapes: target <= 32766, query <= 32000 letters (DELLYHIP_E_LIMIT beyond).  loc_cap: target_len + 1 always suffices.
+ * This is what include/delly_dropin/edlib.h builds the reference's C API on; any other additionalEqualities set has no
+ * caller in the reference and is rejected there. */
+int dellyhip_edlib_align_full(dellyhip_ctx* ctx, const char* query, int32_t query_len, const char* target, int32_t target_len,
+                              int32_t k, int32_t mode, int32_t task, int32_t equalities, int32_t* edit_distance,
+                              int32_t* num_locations, int32_t* end_locs, int32_t* start_locs, int32_t loc_cap,
+                              unsigned char* ops, int32_t ops_cap, int32_t* ops_len);
+
 /* int lcs(s1, s2)  src/msa.h:10-30 */
 int dellyhip_lcs(dellyhip_ctx* ctx, const char* s1, int32_t m, const char* s2, int32_t n,
                  int32_t* out);

@@ -109,6 +109,27 @@ class Oracle:
             pass
         return o[0], o[1], o[2], o[3], aln[:L].tobytes()
 
+    def edlib_align_full(self, q, t, k=-1, mode=0, task=2, iupac=False):
+        """the reference's edlibAlign with every field of its result (reference only) ->
+        dict(status, ed, ends, starts (None when absent), ops, alphabet)"""
+        q, t = _u8(q), _u8(t)
+        cap = t.size + 2
+        acap = q.size + t.size + 8
+        aln = np.zeros(acap, dtype=np.uint8)
+        ends, starts = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+        out = (C.c_int * 5)()
+        self._f("edlib_align_full")(_p(q), q.size, _p(t), t.size, int(k), int(mode), int(task), int(bool(iupac)), out,
+                                    _p(ends, C.POINTER(C.c_int)), _p(starts, C.POINTER(C.c_int)), cap, _p(aln, C.POINTER(C.c_ubyte)), acap)
+        n = out[2]
+        return dict(status=out[0], ed=out[1], ends=ends[:n].tolist(), starts=(None if (n == 0 or starts[0] == -2) else starts[:n].tolist()),
+                    ops=aln[:out[3]].tobytes(), alphabet=out[4])
+
+    def edlib_cigar(self, ops, fmt):
+        a = _u8(ops)
+        buf = C.create_string_buffer(4 * a.size + 16)
+        n = self._f("edlib_cigar")(_p(a, C.POINTER(C.c_ubyte)), a.size, int(fmt), buf, len(buf))
+        return None if n < 0 else buf.value
+
     def split_align(self, cons, ref):
         """splitAlign + row swap -> (rc, cons_row, ref_row, internals or None)"""
         cons, ref = _u8(cons), _u8(ref)

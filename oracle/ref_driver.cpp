@@ -299,6 +299,38 @@ int dref_edlib_align(const char* q, int qn, const char* t, int tn, int mode, int
   return L;
 }
 
+// edlibAlign with k and every field of EdlibAlignResult (all locations), for the parity tests of dellyhip_edlib_align_full
+// and include/delly_dropin/edlib.h.  out[5] = {status, editDistance, numLocations, alignmentLength, alphabetLength};
+// ends / starts: up to cap entries (starts[0] = -2 when the reference returns no start locations).
+int dref_edlib_align_full(const char* q, int qn, const char* t, int tn, int k, int mode, int task, int iupac, int* out,
+                          int* ends, int* starts, int cap, unsigned char* aln, int acap) {
+  EdlibEqualityPair additionalEqualities[20] = {{'M', 'A'}, {'M', 'C'}, {'R', 'A'}, {'R', 'G'}, {'W', 'A'}, {'W', 'T'}, {'B', 'A'}, {'B', '-'}, {'S', 'C'}, {'S', 'G'}, {'Y', 'C'}, {'Y', 'T'}, {'D', 'C'}, {'D', '-'}, {'K', 'G'}, {'K', 'T'}, {'E', 'G'}, {'E', '-'}, {'F', 'T'}, {'F', '-'}};
+  EdlibAlignResult r = edlibAlign(q, qn, t, tn, edlibNewAlignConfig(k, (EdlibAlignMode)mode, (EdlibAlignTask)task, iupac ? additionalEqualities : NULL, iupac ? 20 : 0));
+  out[0] = r.status;
+  out[1] = r.editDistance;
+  out[2] = r.numLocations;
+  out[3] = r.alignmentLength;
+  out[4] = r.alphabetLength;
+  if (cap > 0) starts[0] = -2;
+  for (int i = 0; i < r.numLocations && i < cap; ++i) {
+    if (r.endLocations) ends[i] = r.endLocations[i];
+    if (r.startLocations) starts[i] = r.startLocations[i];
+  }
+  if (r.alignment && r.alignmentLength <= acap) std::memcpy(aln, r.alignment, (size_t)r.alignmentLength);
+  edlibFreeAlignResult(r);
+  return 0;
+}
+
+// edlibAlignmentToCigar (src/edlib.cpp:294-343): returns the length of the text (copied when it fits), -1 for NULL
+int dref_edlib_cigar(const unsigned char* aln, int n, int fmt, char* out, int cap) {
+  char* c = edlibAlignmentToCigar(aln, n, (EdlibCigarFormat)fmt);
+  if (!c) return -1;
+  const int len = (int)std::strlen(c);
+  if (len < cap) std::memcpy(out, c, (size_t)len + 1);
+  free(c);
+  return len;
+}
+
 // splitAlign(cons, svRefStr, align)  src/split.h:480-538 followed by the row swap of
 // _consRefAlignment (:546-552).  Returns 1/0, rows[0..len) = consensus row, rows[cap..cap+len) = ref row.
 int dref_split_align(const char* cons, int m, const char* ref, int n, char* rows, int cap, int* len) {
