@@ -1865,6 +1865,17 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
   return 0;
 }
 
+#ifdef DH_SPS_DBG
+// profiling builds only (tools/sps_dbg.py): the counters of sparse_needle.hpp, read and cleared
+extern "C" int dellyhip_debug_read(uint64_t* out, int n) {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dh::dh_dbg), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 16; ++i) out[i] = h[i];
+  memset(h, 0, sizeof h);
+  return hipMemcpyToSymbol(HIP_SYMBOL(dh::dh_dbg), h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ---- multi-GPU: cost-balanced sharding + RCCL gather of the results ---------------------------
 struct dellyhip_comm {
   int32_t rank = 0, world = 1;

@@ -67,6 +67,7 @@ struct SparseRes {
   int mmF, mmR;      // mismatch columns on the two traced paths (from the deficits: a path of deficit D with V consensus-only
                      // and H paid reference-only moves crosses (D - 2 V - H) / 2 mismatches)
   unsigned long long t[5];   // DH_LR_TIMING: wall clock after the levels, the first-column tables, the join, refRight, the traces
+  int runF, runR;    // short-read kernel: lane i holds run i of the forward / reverse trace (push order)
 };
 
 // The tables live in the wavefront's workspace, which it re-writes for every junction: table reads bypass the vector L1
@@ -343,12 +344,241 @@ __device__ DH_SP_FN void sp_level_block2(const uint8_t* consF, const uint8_t* re
 // written over level d - 2 in place -- diagonal q reads entries q and q + 1 of that row, chunks go in ascending order and
 // every chunk reads before it writes, so nothing is overwritten early.  The rows must be zero when d0 == 0 (done here);
 // index = diagonal + SP_LB + 1.
+#ifdef DH_SPS_DBG
+__device__ unsigned long long dh_dbg[16];   // profiling builds: [0] level calls, [1] levels, [2] ticks in the diagonal loop, [3] ticks in the level tail, [4] ticks in the
+                                            // block epilogue (store wait), [5] extension calls, [6] ticks in extensions, [7] ticks zeroing the tile
+#define DH_DBG_ADD(i, v) do { if (lane == 0) atomicAdd(&dh_dbg[i], (unsigned long long)(v)); } while (0)
+#define DH_DBG_T() wall_clock64()
+#else
+#define DH_DBG_ADD(i, v) do { } while (0)
+#define DH_DBG_T() 0ull
+#endif
+constexpr int SPS_OFF = 20;   // index of diagonal 0 in a byte row of the short-read tile (dword aligned; entry -1 is padding)
+
+// ---- the level loop of the short-read kernel, second formulation (round 4) ------------------------------------------------
+// Round 3's loop (sps_level_block_v1 below) gave every lane ONE diagonal per step and spent ~110 wave instructions per 64
+// table entries, two thirds of them control flow, byte-wide LDS traffic and waits: the loop was issue-bound at four
+// wavefronts per SIMD (profiles/r04: 450 instructions per 128 diagonals x 2 matrices, 2.4 cycles each).  Here a lane owns FOUR
+// consecutive diagonals: the three tile rows it needs arrive as four dword reads per matrix (levels d - 1 and d - 2 at the
+// lane's diagonals, and the same rows shifted by one diagonal -- unaligned dword reads -- for the two neighbour moves), the
+// level that leaves the tile goes to the workspace as one coalesced dword store, the new entries are written as one dword.
+// The candidate, the first eight-letter compare and the clamp to the diagonal's last row are straight-line code per entry;
+// the body is instantiated for the diagonal ranges that need the first-column rule (NEG: k < 0) or the window's right edge
+// (EDGE: n - k < m, or diagonals beyond the table) so that the interior pays for neither.  Diagonals whose first compare
+// matched all eight letters -- the few an alignment follows -- are finished afterwards with the whole wavefront comparing
+// 512 letters at once (one LDS round trip instead of one per eight letters).
+// Same recurrence, same table contents as v1 (bit-compared through every sparse parity test; -DDH_SPS_LEVEL_V1 keeps v1).
+// LDS reads that are not naturally aligned are served lane by lane on gfx950 (tools/lds_rate.hip, profiles/r04/lds_rate.txt:
+// an unaligned ds_read_b64 occupies the LDS pipeline for 29 - 37 cycles, an unaligned ds_read_b32 for 64, their aligned forms
+// for 2.5 / 1.6) -- round 3's level loop spent its time there, not in the instruction stream.  Eight letters from any byte
+// address are therefore composed from three ALIGNED dwords with two v_alignbyte_b32.
+typedef const __attribute__((address_space(3))) uint32_t* sp_lds_u32p;
+__device__ __forceinline__ uint64_t sp_lds8a(const uint8_t* p) {
+  const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);      // (LDS addresses are 32 bits wide)
+  sp_lds_u32p q = (sp_lds_u32p)(uintptr_t)(a & ~3u);
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, a & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, a & 3u);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// four entries of one matrix: diagonals qb .. qb + 3.  e1 / e2: levels d - 1 / d - 2 at those diagonals, e1l: level d - 1 one
+// diagonal to the left, e2r: level d - 2 one diagonal to the right (bytes, row + 1, 0 = none).  seed1 = 1 at level 0.
+// Returns the four new entries; maxB = running maximum of (row + 1); pend gets bit (pbit + i) for an entry that wants more.
+template <bool NEG, bool EDGE>
+__device__ __forceinline__ uint32_t sps_entries4(const uint8_t* cons, const uint8_t* ref, uint32_t e1, uint32_t e1l, uint32_t e2, uint32_t e2r,
+                                                 int qb, int m, int n, int dhalf, int seed1, int ND, int& maxB, uint32_t& pend, int pbit) {
+  // pass 1: the four candidates, then all eight letter loads in flight together; pass 2: the compares
+  int Bv[4], r0v[4], rmaxv[4];
+  uint64_t zv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = qb + i, k = q - m;
+    const int E1 = (int)((e1 >> (8 * i)) & 255u), E1L = (int)((e1l >> (8 * i)) & 255u);
+    const int E2 = (int)((e2 >> (8 * i)) & 255u), E2R = (int)((e2r >> (8 * i)) & 255u);
+    int rmax = m;
+    int B = E1;                                                     // level d - 1 reaches at least as far
+    if (EDGE) {
+      const int nk = n - k;
+      rmax = min(m, nk);
+      if ((unsigned)(E1L - 1) <= (unsigned)nk) B = max(B, E1L);     // reference-only move from diagonal k - 1 (its column + 1 <= n)
+    } else {
+      B = max(B, E1L);
+    }
+    B = max(B, E2 ? min(E2 + 1, rmax + 1) : 0);                     // mismatch on this diagonal, clamped to its last row
+    B = max(B, ((unsigned)(E2R - 1) < (unsigned)m) ? E2R + 1 : 0);  // consensus-only move from diagonal k + 1 (rows 0 .. m - 1)
+    if (NEG) {
+      const int kk = -k;
+      if ((unsigned)(kk - 1) < (unsigned)dhalf) B = max(B, kk + 1); // first column: D[r][0] = 2 r  (k < 0 and 2 |k| <= d)
+      B = max(B, (k >= 0) ? seed1 : 0);
+    } else {
+      B = max(B, seed1);                                            // level 0: row 0 of every diagonal k >= 0
+    }
+    Bv[i] = B;
+    rmaxv[i] = rmax;
+    r0v[i] = max(B - 1, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = qb + i - m;
+    zv[i] = sp_lds8a(cons + r0v[i]) ^ sp_lds8a(ref + (NEG ? max(r0v[i] + k, 0) : r0v[i] + k));
+  }
+  uint32_t outw = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = qb + i;
+    const int adv = zv[i] ? (int)(__builtin_ctzll(zv[i]) >> 3) : 8;
+    int NB = Bv[i] ? min(r0v[i] + adv, rmaxv[i]) + 1 : 0;
+    bool more = (Bv[i] != 0) && (adv >= 8) && (rmaxv[i] - r0v[i] > 8);
+    if (EDGE) {
+      NB = (q < ND) ? NB : 0;
+      more = more && (q < ND);
+    }
+    outw |= (uint32_t)NB << (8 * i);
+    maxB = max(maxB, NB);
+    pend |= (more ? 1u : 0u) << (pbit + i);
+  }
+  return outw;
+}
+
+// finishes the entries flagged in `pend` (bit i: forward entry i of the lane, bit 4 + i: reverse entry i): for each the whole
+// wavefront compares 512 letters from the row the first compare stopped at.  cur rows already hold the provisional entries.
+__device__ __forceinline__ void sps_extend_pending(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR,
+                                                   uint8_t* curF, uint8_t* curR, int q0, int m, int n, uint32_t pend, int& maxB_F,
+                                                   int& maxB_R, int lane) {
+  unsigned long long lanes = __ballot(pend != 0u);
+  while (lanes) {
+    const int src = __builtin_ctzll(lanes);
+    lanes &= lanes - 1;
+    uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)pend, src);
+    while (bits) {
+      const int e = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const bool rev = e >= 4;
+      const int q = q0 + 4 * src + (e & 3), k = q - m;
+      const uint8_t* cons = rev ? consR : consF;
+      const uint8_t* ref = rev ? refR : refF;
+      uint8_t* cur = rev ? curR : curF;
+      const int end = min(m, n - k);
+      int r = (int)cur[q] - 1;                          // (uniform address: the provisional entry, row of the first mismatch - none yet)
+      for (;;) {
+        const int rr = r + 8 * lane;
+        uint64_t z = 0;
+        if (rr < end) z = sp_lds8a(cons + rr) ^ sp_lds8a(ref + rr + k);
+        const unsigned long long stop = __ballot(rr >= end || z != 0ull);
+        if (stop == 0ull) { r += 8 * WAVE; continue; }  // (512 matches and still inside: consensus rows <= 254 never get here)
+        const int jl = __builtin_ctzll(stop);
+        const int rj = r + 8 * jl;
+        const uint32_t zlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(z & 0xffffffffull), jl);
+        const uint32_t zhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(z >> 32), jl);
+        const uint64_t zz = ((uint64_t)zhi << 32) | zlo;
+        r = (rj >= end) ? end : min(rj + (zz ? (int)(__builtin_ctzll(zz) >> 3) : 8), end);
+        break;
+      }
+      if (lane == 0) cur[q] = (uint8_t)(r + 1);
+      if (rev) maxB_R = max(maxB_R, r + 1); else maxB_F = max(maxB_F, r + 1);
+    }
+  }
+}
+
+template <bool NEG, bool EDGE, bool L0>
+__device__ __forceinline__ void sps_level_step(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m, int n,
+                                               int d, int q0, int ND, uint8_t* curF, uint8_t* curR, const uint8_t* p1F, const uint8_t* p1R,
+                                               uint8_t* gF, uint8_t* gR, int& maxB_F, int& maxB_R, int lane) {
+  const int qb = q0 + 4 * lane;
+  uint32_t e1F = 0, e1lF = 0, e2F = 0, e2rF = 0, e1R = 0, e1lR = 0, e2R = 0, e2rR = 0;
+  if (!L0) {
+    // aligned dwords only: the rows shifted by one diagonal are composed from the neighbouring dword (v_alignbyte_b32)
+    const uint32_t* a1F = reinterpret_cast<const uint32_t*>(p1F + qb);
+    const uint32_t* a2F = reinterpret_cast<const uint32_t*>(curF + qb);
+    const uint32_t* a1R = reinterpret_cast<const uint32_t*>(p1R + qb);
+    const uint32_t* a2R = reinterpret_cast<const uint32_t*>(curR + qb);
+    e1F = a1F[0]; e1lF = __builtin_amdgcn_alignbyte(e1F, a1F[-1], 3u); e2F = a2F[0]; e2rF = __builtin_amdgcn_alignbyte(a2F[1], e2F, 1u);
+    e1R = a1R[0]; e1lR = __builtin_amdgcn_alignbyte(e1R, a1R[-1], 3u); e2R = a2R[0]; e2rR = __builtin_amdgcn_alignbyte(a2R[1], e2R, 1u);
+    if (d >= 2 && qb < ND) {   // level d - 2 leaves the tile now (level d is written over it): to the workspace as bytes
+      *reinterpret_cast<uint32_t*>(gF + qb) = e2F;
+      *reinterpret_cast<uint32_t*>(gR + qb) = e2R;
+    }
+  }
+  uint32_t pend = 0;
+  const int seed1 = L0 ? 1 : 0, dhalf = d >> 1;
+  const uint32_t oF = sps_entries4<NEG, EDGE>(consF, refF, e1F, e1lF, e2F, e2rF, qb, m, n, dhalf, seed1, ND, maxB_F, pend, 0);
+  __builtin_amdgcn_sched_barrier(0);   // (the two matrices one after the other: eight 64-bit letter words in flight, not sixteen -- no spills at 128 registers)
+  const uint32_t oR = sps_entries4<NEG, EDGE>(consR, refR, e1R, e1lR, e2R, e2rR, qb, m, n, dhalf, seed1, ND, maxB_R, pend, 4);
+  if (qb < ND) {
+    *reinterpret_cast<uint32_t*>(curF + qb) = oF;
+    *reinterpret_cast<uint32_t*>(curR + qb) = oR;
+  }
+  if (__ballot(pend != 0u)) {
+    const unsigned long long te = DH_DBG_T();
+    sps_extend_pending(consF, refF, consR, refR, curF, curR, q0, m, n, pend, maxB_F, maxB_R, lane);
+    DH_DBG_ADD(5, 1);
+    DH_DBG_ADD(6, DH_DBG_T() - te);
+  }
+}
+
 template <typename TILE>
 __device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
+                                         int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
+                                         int16_t* reachR, int lane) {
+  static_assert(TILE::narrow, "byte rows");
+  static_assert(sizeof(T.row[0][0]) % 4 == 0 && SPS_OFF % 4 == 0, "dword access to the tile rows");
+  const int ND = n + m + 1;
+  const unsigned long long tz0 = DH_DBG_T();
+  if (d0 == 0) {
+    uint32_t* z = reinterpret_cast<uint32_t*>(&T.row[0][0][0]);
+    for (int i = lane; i < (int)(sizeof(T.row) / 4); i += WAVE) z[i] = 0u;
+  }
+  __syncthreads();
+  DH_DBG_ADD(0, 1);
+  DH_DBG_ADD(7, DH_DBG_T() - tz0);
+  for (int d = d0; d <= d1; ++d) {
+    const unsigned long long tl0 = DH_DBG_T();
+    uint8_t* curF = T.row[0][d & 1] + SPS_OFF;
+    uint8_t* curR = T.row[1][d & 1] + SPS_OFF;
+    const uint8_t* p1F = T.row[0][(d + 1) & 1] + SPS_OFF;
+    const uint8_t* p1R = T.row[1][(d + 1) & 1] + SPS_OFF;
+    uint8_t* gF = reinterpret_cast<uint8_t*>(FRf) + (size_t)max(d - 2, 0) * ndp;
+    uint8_t* gR = reinterpret_cast<uint8_t*>(FRr) + (size_t)max(d - 2, 0) * ndp;
+    int maxB_F = 0, maxB_R = 0;
+    for (int q0 = 0; q0 < ND; q0 += 4 * WAVE) {
+      const bool neg = q0 < m;                          // some diagonal of the step lies below the main one
+      const bool edge = q0 + 4 * WAVE - 1 > n;          // some diagonal has fewer than m rows inside the window, or lies beyond the table
+      if (d == 0) {
+        if (neg || edge) sps_level_step<true, true, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+        else sps_level_step<false, false, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+      } else if (neg || edge) {
+        sps_level_step<true, true, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+      } else {
+        sps_level_step<false, false, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+      }
+    }
+    const unsigned long long tl1 = DH_DBG_T();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      maxB_F = max(maxB_F, __shfl_xor(maxB_F, o));
+      maxB_R = max(maxB_R, __shfl_xor(maxB_R, o));
+    }
+    if (lane == 0) {
+      reachF[d] = (int16_t)(maxB_F <= 0 ? SP_NEG : maxB_F - 1);
+      reachR[d] = (int16_t)(maxB_R <= 0 ? SP_NEG : maxB_R - 1);
+    }
+    __syncthreads();
+    DH_DBG_ADD(1, 1);
+    DH_DBG_ADD(2, tl1 - tl0);
+    DH_DBG_ADD(3, DH_DBG_T() - tl1);
+  }
+  const unsigned long long tw0 = DH_DBG_T();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  DH_DBG_ADD(4, DH_DBG_T() - tw0);
+}
+
+template <typename TILE>
+__device__ DH_SP_FN void sps_level_block_v1(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m,
                                              int n, int d0, int d1, int16_t* FRf, int16_t* FRr, int ndp, TILE& T, int16_t* reachF,
                                              int16_t* reachR, int lane) {
   static_assert(TILE::narrow, "byte rows");
-  constexpr int OFF = SP_LB + 1;
+  constexpr int OFF = SPS_OFF;
   const int ND = n + m + 1;
   if (d0 == 0) {
     uint32_t* z = reinterpret_cast<uint32_t*>(&T.row[0][0][0]);
@@ -574,7 +804,7 @@ __device__ DH_SP_FN int sp_deep_list(const FRV& FR, int m, int n, int S, int rlo
   return (cnt <= cap) ? cnt : -1;
 }
 
-// sp_deep_list on the byte row of level S the short-read tile still holds (row + 1, 0 = none; lv = row + SP_LB + 1)
+// sp_deep_list on the byte row of level S the short-read tile still holds (row + 1, 0 = none; lv = row + SPS_OFF)
 template <bool WAIT = true>
 __device__ __forceinline__ int sps_deep_list(const uint8_t* lv, int ND, int rlo, int32_t* list, int cap, int lane) {
   int cnt = 0;
@@ -680,9 +910,11 @@ __device__ DH_SP_FN void sp_first_columns_both(const FRV& FRf, const FRV& FRr, i
 
 // traceback from (r, c) with deficit D: the reference's rule (vertical, then horizontal, then diagonal; src/needle.h:154-192)
 // decided on the tables; runs in push order.  Returns the number of runs or -1 on overflow.  Wave-uniform.
-template <typename FRV>
+// REGRUNS: the runs stay in a register -- lane i holds run i (at most WAVE runs; more: overflow) -- instead of going through
+// the wavefront's HBM workspace (the short-read kernel: nothing of a junction resolved at <= 1 level touches the workspace)
+template <typename FRV, bool REGRUNS = false>
 __device__ DH_SP_FN int sp_trace(const FRV& FR, int m, int n, int r, int c, int D, int32_t* runs, int cap, int lane,
-                                     int* mismatches = nullptr) {
+                                     int* mismatches = nullptr, int* runreg = nullptr) {
   const int ND = n + m + 1;
   const int D0 = rfl(D);
   int nv = 0, nh = 0;
@@ -692,7 +924,8 @@ __device__ DH_SP_FN int sp_trace(const FRV& FR, int m, int n, int r, int c, int 
     if (len <= 0) return;
     if (op == last_op) { last_len += len; return; }
     if (last_op >= 0) {
-      if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
+      if (REGRUNS) { if (lane == nruns) *runreg = (last_op << 24) | last_len; }
+      else if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
       ++nruns;
     }
     last_op = op;
@@ -723,13 +956,137 @@ __device__ DH_SP_FN int sp_trace(const FRV& FR, int m, int n, int r, int c, int 
     }
   }
   if (last_op >= 0) {
-    if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
+    if (REGRUNS) { if (lane == nruns) *runreg = (last_op << 24) | last_len; }
+    else if (nruns < cap && lane == 0) runs[nruns] = (last_op << 24) | last_len;
     ++nruns;
   }
   if (mismatches) *mismatches = (D0 - 2 * nv - nh) / 2;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  return (nruns <= cap) ? nruns : -1;
+  if (!REGRUNS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  return (nruns <= (REGRUNS ? WAVE : cap)) ? nruns : -1;
+}
+
+// ---- evaluation of the short-read kernel without the workspace (round 4) ---------------------------------------------------
+// Round 3 built the deep lists, the first-column tables and the run lists in the wavefront's HBM workspace: ~30 dependent
+// global loads / atomics per junction, each a round trip of 1 - 2 us under load, which is what the phases after the level
+// loop were made of (profiles/r04).  When both deep lists fit one lane each (<= 64 diagonals, the usual case: 1 - 20) and the
+// levels in question are <= 8, nothing needs memory: lane t keeps its diagonal and that diagonal's furthest rows at levels
+// 0 .. SE as packed bytes; the first column of row r at level d,
+//     cF[d][r] = r + min { k_t : FR[d][k_t] >= r, r >= -k_t },
+// is a loop over the listed diagonals with v_readlane (rows live one per lane), and the join proceeds as before.
+// State left for refRight: the reverse list (qR, packed rows) stays in registers.
+struct SpsSmall {
+  int qF, qR, nF, nR;         // lane t: its listed diagonal index (q = k + m), -1 beyond the list; list lengths
+  uint32_t pF[3], pR[3];      // rows + 1 of that diagonal at levels 0 .. 8, one byte each (0 = none)
+};
+
+template <typename FRV>
+__device__ __forceinline__ bool sps_lists_small(const FRV& frF, const FRV& frR, const uint8_t* lvF, const uint8_t* lvR, int ND, int m, int SE,
+                                                int rlo, int rloR, SpsSmall& Q, int lane) {
+  Q.qF = Q.qR = -1;
+  int nF = 0, nR = 0;
+  for (int q0 = 0; q0 < ND; q0 += WAVE) {
+    const int q = q0 + lane;
+    const bool hf = (q < ND) && ((int)lvF[min(q, ND - 1)] - 1 >= rlo);
+    const bool hr = (q < ND) && ((int)lvR[min(q, ND - 1)] - 1 >= rloR);
+    unsigned long long bf = __ballot(hf), br = __ballot(hr);
+    if (nF + __popcll(bf) > WAVE || nR + __popcll(br) > WAVE) return false;
+    while (bf) {
+      const int b = __builtin_ctzll(bf);
+      bf &= bf - 1;
+      Q.qF = (lane == nF) ? q0 + b : Q.qF;
+      ++nF;
+    }
+    while (br) {
+      const int b = __builtin_ctzll(br);
+      br &= br - 1;
+      Q.qR = (lane == nR) ? q0 + b : Q.qR;
+      ++nR;
+    }
+  }
+  Q.nF = nF;
+  Q.nR = nR;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) { Q.pF[w] = 0u; Q.pR[w] = 0u; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {
+    if (d <= SE) {
+      const int vf = (Q.qF >= 0) ? frF.get(d, Q.qF) + 1 : 0;
+      const int vr = (Q.qR >= 0) ? frR.get(d, Q.qR) + 1 : 0;
+      Q.pF[d >> 2] |= (uint32_t)(vf & 255) << (8 * (d & 3));
+      Q.pR[d >> 2] |= (uint32_t)(vr & 255) << (8 * (d & 3));
+    }
+  }
+  return true;
+}
+
+// join over the rows rlo .. rhi (needle.h:96-115) from the registers of sps_lists_small: key = (total deficit << 40) | (row << 20)
+// | column of the winner (0x7fff... : none), dsel = its forward deficit.  Same arithmetic as the table version below.
+__device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, int SE, int rlo, int rhi, long long& key, int& dsel, int lane) {
+  key = 0x7fffffffffffffffll;
+  int dbest = 0;
+  for (int r0 = rlo; r0 <= rhi; r0 += WAVE) {
+    const int r = r0 + lane, rr = m - r;       // forward row, reverse row
+    int lo_[9], c2_[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { lo_[d] = SP_INF; c2_[d] = SP_INF; }
+    for (int t = 0; t < Q.nF; ++t) {
+      const int k = __builtin_amdgcn_readlane(Q.qF, t) - m;
+      const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pF[0], t), p1 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pF[1], t),
+                     p2 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pF[2], t);
+      const bool on = r + k >= 0;              // the row exists on this diagonal (k < 0: rows >= -k)
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        if (d <= SE) {
+          const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
+          lo_[d] = (on && v >= r) ? min(lo_[d], r + k) : lo_[d];
+        }
+      }
+    }
+    for (int t = 0; t < Q.nR; ++t) {
+      const int k = __builtin_amdgcn_readlane(Q.qR, t) - m;
+      const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pR[0], t), p1 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pR[1], t),
+                     p2 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pR[2], t);
+      const bool on = rr + k >= 0;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        if (d <= SE) {
+          const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
+          c2_[d] = (on && v >= rr) ? min(c2_[d], rr + k) : c2_[d];
+        }
+      }
+    }
+    if (r <= rhi) {
+      long long kb = 0x7fffffffffffffffll;
+      int db = 0;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) {
+        const int lo = lo_[d];
+        if (d <= SE && lo <= n) {
+          int e = 0;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) e += (q <= SE && (c2_[q] > n || lo > n - c2_[q])) ? 1 : 0;
+          if (e <= SE && d + e <= SE) {
+            const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
+            if (kk <= kb) { kb = kk; db = d; }
+          }
+        }
+      }
+      if (kb < key) { key = kb; dbest = db; }
+    }
+  }
+  long long kmin = key;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int lo = __shfl_xor((int)(kmin & 0xffffffffll), o), hi = __shfl_xor((int)(kmin >> 32), o);
+    const long long w = ((long long)hi << 32) | (unsigned int)lo;
+    kmin = w < kmin ? w : kmin;
+  }
+  const unsigned long long who = __ballot(key == kmin && key != 0x7fffffffffffffffll);
+  dsel = who ? __shfl(dbest, __builtin_ctzll(who)) : 0;
+  key = kmin;
 }
 
 // The whole procedure for one junction (one wavefront).  cons / ref: clean letters; rcons / rref: their reverse
@@ -746,7 +1103,11 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
   int S = min(W.smax, s_first);
   for (;;) {
     if constexpr (LDSSTR && TILE::narrow) {        // short-read kernel: one tile, kept between the rounds
+#ifdef DH_SPS_LEVEL_V1
+      sps_level_block_v1(cons, ref, rcons, rref, m, n, done + 1, S, W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
+#else
       sps_level_block(cons, ref, rcons, rref, m, n, done + 1, S, W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
+#endif
     } else {
       for (int d = done + 1; d <= S; d += SP_LB)
         sp_level_block2<TILE>(cons, ref, rcons, rref, m, n, d, min(d + SP_LB - 1, S), W.frF, W.frR, W.ndp, T, reachF, reachR, lane);
@@ -761,8 +1122,8 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
     typedef typename std::conditional<TILED8, FrTile8, FrGlobal16>::type FRV;
     FRV frF, frR;
     if constexpr (TILED8) {
-      frF = FrTile8{reinterpret_cast<const uint8_t*>(W.frF), W.ndp, &T.row[0][0][0] + SP_LB + 1, &T.row[0][1][0] + SP_LB + 1, S};
-      frR = FrTile8{reinterpret_cast<const uint8_t*>(W.frR), W.ndp, &T.row[1][0][0] + SP_LB + 1, &T.row[1][1][0] + SP_LB + 1, S};
+      frF = FrTile8{reinterpret_cast<const uint8_t*>(W.frF), W.ndp, &T.row[0][0][0] + SPS_OFF, &T.row[0][1][0] + SPS_OFF, S};
+      frR = FrTile8{reinterpret_cast<const uint8_t*>(W.frR), W.ndp, &T.row[1][0][0] + SPS_OFF, &T.row[1][1][0] + SPS_OFF, S};
     } else {
       frF = FrGlobal16{W.frF, W.ndp};
       frR = FrGlobal16{W.frR, W.ndp};
@@ -790,13 +1151,26 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
       const int d = d0 + lane;
       feasible = __ballot(d <= SE && reachF[min(d, SE)] >= 0 && (int)reachR[SE - min(d, SE)] >= m - (int)reachF[min(d, SE)]) != 0ull;
     }
-    if (rlo <= rhi && feasible) {
+    bool small = false;
+    SpsSmall Q;
+    if constexpr (LDSSTR && TILE::narrow) {
+      if (rlo <= rhi && feasible && SE >= S - 1 && SE <= 8) {   // (the tile holds levels S and S - 1; nine packed levels per diagonal)
+        small = sps_lists_small(frF, frR, T.row[0][SE & 1] + SPS_OFF, T.row[1][SE & 1] + SPS_OFF, ND, m, SE, rlo, m - rhi, Q, lane);
+        if (small) {
+#ifdef DH_LR_TIMING
+          O.t[1] = wall_clock64();
+#endif
+          sps_join_small(Q, m, n, SE, rlo, rhi, key, dsel, lane);
+        }
+      }
+    }
+    if (rlo <= rhi && feasible && !small) {
       int nlistF;
       bool tables_done = false;
       if constexpr (LDSSTR && TILE::narrow) {
         if (SE >= S - 1) {   // (the tile holds levels S and S - 1)
-          nlistF = sps_deep_list<false>(T.row[0][SE & 1] + SP_LB + 1, ND, rlo, W.listF, W.runs_cap, lane);
-          nlistR = sps_deep_list<false>(T.row[1][SE & 1] + SP_LB + 1, ND, m - rhi, W.listR, W.runs_cap, lane);
+          nlistF = sps_deep_list<false>(T.row[0][SE & 1] + SPS_OFF, ND, rlo, W.listF, W.runs_cap, lane);
+          nlistR = sps_deep_list<false>(T.row[1][SE & 1] + SPS_OFF, ND, m - rhi, W.listR, W.runs_cap, lane);
         } else {
           nlistF = sp_deep_list(frF, m, n, SE, rlo, W.listF, W.runs_cap, lane);
           nlistR = sp_deep_list(frR, m, n, SE, m - rhi, W.listR, W.runs_cap, lane);
@@ -906,7 +1280,13 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
       const int eR = bestD - dsel;
       // refRight: last t <= n - refLeft with rev[consRight][t] at deficit eR (needle.h:119-123)
       int rright = 0;
-      if (nlistR >= 0) {   // (row consRight >= m - rhi: every diagonal that reaches it is listed)
+      if (small) {         // (the reverse list and its rows at every level are still in registers)
+        const int w = eR >> 2, sh = 8 * (eR & 3);
+        const uint32_t pw = (w == 0) ? Q.pR[0] : (w == 1) ? Q.pR[1] : Q.pR[2];
+        const int v = (int)((pw >> sh) & 255u) - 1;
+        const int t = cr_ + Q.qR - m;
+        if (Q.qR >= 0 && t >= 0 && t <= n - O.refLeft && v >= cr_) rright = t;
+      } else if (nlistR >= 0) {   // (row consRight >= m - rhi: every diagonal that reaches it is listed)
         for (int i0 = 0; i0 < nlistR; i0 += WAVE) {
           const int i = i0 + lane;
           if (i < nlistR) {
@@ -929,8 +1309,14 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
 #ifdef DH_LR_TIMING
       O.t[3] = wall_clock64();
 #endif
-      O.nrunsF = sp_trace(frF, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF);
-      O.nrunsR = sp_trace(frR, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR);
+      if constexpr (LDSSTR && TILE::narrow) {
+        O.runF = O.runR = 0;
+        O.nrunsF = sp_trace<FRV, true>(frF, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF, &O.runF);
+        O.nrunsR = sp_trace<FRV, true>(frR, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR, &O.runR);
+      } else {
+        O.nrunsF = sp_trace(frF, m, n, O.consLeft, O.refLeft, dsel, W.runsF, W.runs_cap, lane, &O.mmF);
+        O.nrunsR = sp_trace(frR, m, n, cr_, O.refRight, eR, W.runsR, W.runs_cap, lane, &O.mmR);
+      }
 #ifdef DH_LR_TIMING
       O.t[4] = wall_clock64();
 #endif
@@ -954,9 +1340,21 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
 
 // column masks of the glued alignment (needle.h:196-219) from the two run lists: forward trace reversed, the reference
 // gap, the reverse trace in push order.  PL / append as needle_masks (split_main.hpp).  Returns the number of columns.
-template <typename PL, typename APPEND>
-__device__ __forceinline__ int sparse_masks(PL& L, const int32_t* runsF, int nF, const int32_t* runsR, int nR, int gapref, int maskw,
-                                            int lane, int& posC, APPEND append) {
+// run i of a list: from the wavefront's workspace, or from the register of sp_trace<.., true> (lane i holds run i)
+struct RunsMem {
+  const int32_t* p;
+  __device__ __forceinline__ int at(int i) const { return rfl(sp_ld32(p + i)); }
+  __device__ __forceinline__ int mine(int i, int n) const { return (i >= 0 && i < n) ? sp_ld32(p + i) : 0; }   // lane-wise, i per lane
+};
+struct RunsReg {
+  int r;
+  __device__ __forceinline__ int at(int i) const { return __builtin_amdgcn_readlane(r, i); }
+  __device__ __forceinline__ int mine(int i, int n) const { const int v = __shfl(r, max(min(i, WAVE - 1), 0)); return (i >= 0 && i < n) ? v : 0; }
+};
+
+template <typename PL, typename APPEND, typename RUNS = RunsMem>
+__device__ __forceinline__ int sparse_masks_t(PL& L, RUNS runsF, int nF, RUNS runsR, int nR, int gapref, int maskw,
+                                              int lane, int& posC, APPEND append) {
   for (int w = lane; w < maskw; w += WAVE) {
     L.mV[w] = 0;
     L.mR[w] = 0;
@@ -972,24 +1370,40 @@ __device__ __forceinline__ int sparse_masks(PL& L, const int32_t* runsF, int nF,
     }
   };
   for (int i = nF - 1; i >= 0; --i) {
-    const int x = rfl(sp_ld32(runsF + i));
+    const int x = runsF.at(i);
     put(x >> 24, x & 0xffffff);
   }
   put(2, gapref);
   posC = pos;
   for (int i = 0; i < nR; ++i) {
-    const int x = rfl(sp_ld32(runsR + i));
+    const int x = runsR.at(i);
     put(x >> 24, x & 0xffffff);
   }
   return pos;
 }
 
+template <typename PL, typename APPEND>
+__device__ __forceinline__ int sparse_masks(PL& L, const int32_t* runsF, int nF, const int32_t* runsR, int nR, int gapref, int maskw,
+                                            int lane, int& posC, APPEND append) {
+  return sparse_masks_t(L, RunsMem{runsF}, nF, RunsMem{runsR}, nR, gapref, maskw, lane, posC, append);
+}
+
 // sparse_masks with every run written by the whole wavefront (one word per lane), the cumulative counts by a prefix sum
 // over the lanes, and no letter pass: returns the number of columns, both = columns with a letter in both rows.
 // (The equality mask mE is NOT produced: the caller has the match / mismatch counts from the traces.)
+template <typename PL, typename RUNS>
+__device__ __forceinline__ int sparse_masks_counts_t(PL& L, RUNS runsF, int nF, RUNS runsR, int nR, int gapref, int maskw,
+                                                     int lane, int& posC, int& both);
+
 template <typename PL>
 __device__ __forceinline__ int sparse_masks_counts(PL& L, const int32_t* runsF, int nF, const int32_t* runsR, int nR, int gapref, int maskw,
                                                    int lane, int& posC, int& both) {
+  return sparse_masks_counts_t(L, RunsMem{runsF}, nF, RunsMem{runsR}, nR, gapref, maskw, lane, posC, both);
+}
+
+template <typename PL, typename RUNS>
+__device__ __forceinline__ int sparse_masks_counts_t(PL& L, RUNS runsF, int nF, RUNS runsR, int nR, int gapref, int maskw,
+                                                     int lane, int& posC, int& both) {
   for (int w = lane; w < maskw; w += WAVE) {
     L.mV[w] = 0;
     L.mR[w] = 0;
@@ -1008,16 +1422,16 @@ __device__ __forceinline__ int sparse_masks_counts(PL& L, const int32_t* runsF, 
     pos += len;
   };
   // (run words are independent loads: fetch up to 64 of each list at once)
-  const int xF = (lane < nF) ? sp_ld32(runsF + (nF - 1 - lane)) : 0;
-  const int xR = (lane < nR) ? sp_ld32(runsR + lane) : 0;
+  const int xF = runsF.mine(nF - 1 - lane, nF);
+  const int xR = runsR.mine(lane, nR);
   for (int i = 0; i < nF; ++i) {
-    const int x = (i < WAVE) ? __shfl(xF, i) : rfl(sp_ld32(runsF + (nF - 1 - i)));
+    const int x = (i < WAVE) ? __shfl(xF, i) : runsF.at(nF - 1 - i);
     put(x >> 24, x & 0xffffff);
   }
   put(2, gapref);
   posC = pos;
   for (int i = 0; i < nR; ++i) {
-    const int x = (i < WAVE) ? __shfl(xR, i) : rfl(sp_ld32(runsR + i));
+    const int x = (i < WAVE) ? __shfl(xR, i) : runsR.at(i);
     put(x >> 24, x & 0xffffff);
   }
   __syncthreads();

@@ -111,12 +111,12 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
   if (sr.found) {
     const int gapref = (n - sr.refRight) - sr.refLeft;
     if (A.want_alignment) {   // the alignment rows need every column's letters
-      Ltot = sparse_masks(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC,
-                          [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+      Ltot = sparse_masks_t(L.u.p, RunsReg{sr.runF}, sr.nrunsF, RunsReg{sr.runR}, sr.nrunsR, gapref, MASKW, lane, posC,
+                            [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
       masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
     } else {
       int both = 0;
-      Ltot = sparse_masks_counts(L.u.p, W.runsF, sr.nrunsF, W.runsR, sr.nrunsR, gapref, MASKW, lane, posC, both);
+      Ltot = sparse_masks_counts_t(L.u.p, RunsReg{sr.runF}, sr.nrunsF, RunsReg{sr.runR}, sr.nrunsR, gapref, MASKW, lane, posC, both);
       pre_mm = rfl(sr.mmF + sr.mmR);
       pre_ma = rfl(both) - pre_mm;
     }
@@ -167,7 +167,11 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
     w = rfl(w);
     if (w >= A.n_work) break;
     const int j = A.work_list[w];
-    if (j >= 0 && !process_sparse(A, j, L, scratch, lane) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
+    // (the lane index is laundered once per junction: address arithmetic on it is then recomputed per junction instead of being
+    //  hoisted out of this loop and kept -- or spilled to scratch memory -- for the whole kernel)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    if (j >= 0 && !process_sparse(A, j, L, scratch, ln) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
     __syncthreads();
   }
 }
