@@ -168,7 +168,7 @@ __device__ __forceinline__ void sp_tile_levels(const uint8_t* aF, const uint8_t*
   constexpr int OFF = SP_LB + 1;
   const int ND = n + m + 1;
   const int base = tlo - OFF;
-  auto ld8 = [&](const uint8_t* p) -> uint64_t { return STAGED ? sp_lds8u(p) : sp_load8(p); };
+  auto ld8 = [&](const uint8_t* p) -> uint64_t { return STAGED ? sp_lds8a(p) : sp_load8(p); };   // (LDS: aligned dwords only, see sp_lds8a)
   for (int j = 0; j < nl; ++j) {
     const int d = d0 + j;
     const int halo = nl - 1 - j;
@@ -368,19 +368,6 @@ constexpr int SPS_OFF = 20;   // index of diagonal 0 in a byte row of the short-
 // matched all eight letters -- the few an alignment follows -- are finished afterwards with the whole wavefront comparing
 // 512 letters at once (one LDS round trip instead of one per eight letters).
 // Same recurrence, same table contents as v1 (bit-compared through every sparse parity test; -DDH_SPS_LEVEL_V1 keeps v1).
-// LDS reads that are not naturally aligned are served lane by lane on gfx950 (tools/lds_rate.hip, profiles/r04/lds_rate.txt:
-// an unaligned ds_read_b64 occupies the LDS pipeline for 29 - 37 cycles, an unaligned ds_read_b32 for 64, their aligned forms
-// for 2.5 / 1.6) -- round 3's level loop spent its time there, not in the instruction stream.  Eight letters from any byte
-// address are therefore composed from three ALIGNED dwords with two v_alignbyte_b32.
-typedef const __attribute__((address_space(3))) uint32_t* sp_lds_u32p;
-__device__ __forceinline__ uint64_t sp_lds8a(const uint8_t* p) {
-  const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);      // (LDS addresses are 32 bits wide)
-  sp_lds_u32p q = (sp_lds_u32p)(uintptr_t)(a & ~3u);
-  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-  const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, a & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, a & 3u);
-  return ((uint64_t)hi << 32) | lo;
-}
-
 // four entries of one matrix: diagonals qb .. qb + 3.  e1 / e2: levels d - 1 / d - 2 at those diagonals, e1l: level d - 1 one
 // diagonal to the left, e2r: level d - 2 one diagonal to the right (bytes, row + 1, 0 = none).  seed1 = 1 at level 0.
 // Returns the four new entries; maxB = running maximum of (row + 1); pend gets bit (pbit + i) for an entry that wants more.

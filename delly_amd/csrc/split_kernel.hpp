@@ -34,6 +34,21 @@
 
 namespace dh {
 
+// LDS reads that are not naturally aligned are served lane by lane on gfx950 (tools/lds_rate.hip, profiles/r04/lds_rate.txt:
+// an unaligned ds_read_b64 occupies the LDS pipeline for 29 - 37 cycles, an unaligned ds_read_b32 for 64, their aligned forms
+// for 2.5 / 1.6) -- round 3's level loop spent its time there, not in the instruction stream.  Eight letters from any byte
+// address are therefore composed from three ALIGNED dwords with two v_alignbyte_b32.
+typedef const __attribute__((address_space(3))) uint32_t* sp_lds_u32p;
+__device__ __forceinline__ uint64_t sp_lds8a(const uint8_t* p) {
+  const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);      // (LDS addresses are 32 bits wide)
+  sp_lds_u32p q = (sp_lds_u32p)(uintptr_t)(a & ~3u);
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+  const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, a & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, a & 3u);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+
+
 constexpr int WAVE = 64;
 constexpr int NMAX = 2048;            // max |svRefStr| of the short-read kernel
 constexpr int KMAX = 5;               // rows per lane: |consensus| <= 64*KMAX-1

@@ -77,7 +77,7 @@ __device__ __forceinline__ int copy_letters8(uint8_t* dst, const uint8_t* src, i
 // dst = reverse complement of src[0 .. len) (letters in A, C, G, T, N), LDS to LDS
 __device__ __forceinline__ void revcomp8(uint8_t* dst, const uint8_t* src, int len, int lane) {
   const int full = len & ~7;
-  for (int i = lane * 8; i < full; i += WAVE * 8) st8u(dst + i, comp8(__builtin_bswap64(ld8u(src + len - 8 - i))));
+  for (int i = lane * 8; i < full; i += WAVE * 8) st8u(dst + i, comp8(__builtin_bswap64(sp_lds8a(src + len - 8 - i))));   // (LDS: aligned dwords only, see sp_lds8a)
   if (lane < len - full) dst[full + lane] = comp_acgtn(src[len - 1 - full - lane]);
 }
 
@@ -649,9 +649,9 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           if (nr + na + 1 <= A.out_allele_cap && clean_letters) {
             // REF = S.ref[rA .. rB), ALT = S.cons[vA .. vB)
             const int fr = nr & ~7, fa = na & ~7;
-            for (int i = lane * 8; i < fr; i += WAVE * 8) st8u(al + i, ld8u(S.ref + rA + i));
+            for (int i = lane * 8; i < fr; i += WAVE * 8) st8u(al + i, sp_lds8a(S.ref + rA + i));
             if (lane < nr - fr) al[fr + lane] = S.ref[rA + fr + lane];
-            for (int i = lane * 8; i < fa; i += WAVE * 8) st8u(al + nr + 1 + i, ld8u(S.cons + vA + i));
+            for (int i = lane * 8; i < fa; i += WAVE * 8) st8u(al + nr + 1 + i, sp_lds8a(S.cons + vA + i));
             if (lane < na - fa) al[nr + 1 + fa + lane] = S.cons[vA + fa + lane];
             if (lane == 0) al[nr] = ',';
             allele_len = nr + na + 1;
