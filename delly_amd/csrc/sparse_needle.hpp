@@ -432,6 +432,38 @@ __device__ __forceinline__ uint32_t sps_entries4(const uint8_t* cons, const uint
 __device__ __forceinline__ void sps_extend_pending(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR,
                                                    uint8_t* curF, uint8_t* curR, int q0, int m, int n, uint32_t pend, int& maxB_F,
                                                    int& maxB_R, int lane) {
+  // Many flagged entries (low-complexity sequence: repeats match eight letters on many diagonals at once): every lane
+  // walks its own entries, eight letters per step, all lanes side by side -- the wavefront-wide compare below handles ONE
+  // entry per LDS round trip and is the faster way only for the handful an alignment follows.
+  int total = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) total += __popcll(__ballot((pend >> e) & 1u));
+  if (total > 6) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool mine = (pend >> e) & 1u;
+      if (__ballot(mine) == 0ull) continue;
+      if (mine) {
+        const bool rev = e >= 4;
+        const int q = q0 + 4 * lane + (e & 3), k = q - m;
+        const uint8_t* cons = rev ? consR : consF;
+        const uint8_t* ref = rev ? refR : refF;
+        uint8_t* cur = rev ? curR : curF;
+        const int end = min(m, n - k);
+        int r = (int)cur[q] - 1;
+        for (;;) {
+          const uint64_t z = sp_lds8a(cons + r) ^ sp_lds8a(ref + r + k);
+          if (z) { r += (int)(__builtin_ctzll(z) >> 3); break; }
+          r += 8;
+          if (r >= end) break;
+        }
+        r = min(r, end);
+        cur[q] = (uint8_t)(r + 1);
+        if (rev) maxB_R = max(maxB_R, r + 1); else maxB_F = max(maxB_F, r + 1);
+      }
+    }
+    return;
+  }
   unsigned long long lanes = __ballot(pend != 0u);
   while (lanes) {
     const int src = __builtin_ctzll(lanes);
@@ -468,7 +500,7 @@ __device__ __forceinline__ void sps_extend_pending(const uint8_t* consF, const u
 }
 
 template <bool NEG, bool EDGE, bool L0>
-__device__ __forceinline__ void sps_level_step(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m, int n,
+__device__ __forceinline__ uint32_t sps_level_step(const uint8_t* consF, const uint8_t* refF, const uint8_t* consR, const uint8_t* refR, int m, int n,
                                                int d, int q0, int ND, uint8_t* curF, uint8_t* curR, const uint8_t* p1F, const uint8_t* p1R,
                                                uint8_t* gF, uint8_t* gR, int& maxB_F, int& maxB_R, int lane) {
   const int qb = q0 + 4 * lane;
@@ -495,12 +527,7 @@ __device__ __forceinline__ void sps_level_step(const uint8_t* consF, const uint8
     *reinterpret_cast<uint32_t*>(curF + qb) = oF;
     *reinterpret_cast<uint32_t*>(curR + qb) = oR;
   }
-  if (__ballot(pend != 0u)) {
-    const unsigned long long te = DH_DBG_T();
-    sps_extend_pending(consF, refF, consR, refR, curF, curR, q0, m, n, pend, maxB_F, maxB_R, lane);
-    DH_DBG_ADD(5, 1);
-    DH_DBG_ADD(6, DH_DBG_T() - te);
-  }
+  return pend;   // entries whose first compare matched all eight letters: finished by the caller (ONE copy of that code)
 }
 
 template <typename TILE>
@@ -530,13 +557,20 @@ __device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* re
     for (int q0 = 0; q0 < ND; q0 += 4 * WAVE) {
       const bool neg = q0 < m;                          // some diagonal of the step lies below the main one
       const bool edge = q0 + 4 * WAVE - 1 > n;          // some diagonal has fewer than m rows inside the window, or lies beyond the table
+      uint32_t pend;
       if (d == 0) {
-        if (neg || edge) sps_level_step<true, true, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
-        else sps_level_step<false, false, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+        if (neg || edge) pend = sps_level_step<true, true, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+        else pend = sps_level_step<false, false, true>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
       } else if (neg || edge) {
-        sps_level_step<true, true, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+        pend = sps_level_step<true, true, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
       } else {
-        sps_level_step<false, false, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+        pend = sps_level_step<false, false, false>(consF, refF, consR, refR, m, n, d, q0, ND, curF, curR, p1F, p1R, gF, gR, maxB_F, maxB_R, lane);
+      }
+      if (__ballot(pend != 0u)) {
+        const unsigned long long te = DH_DBG_T();
+        sps_extend_pending(consF, refF, consR, refR, curF, curR, q0, m, n, pend, maxB_F, maxB_R, lane);
+        DH_DBG_ADD(5, 1);
+        DH_DBG_ADD(6, DH_DBG_T() - te);
       }
     }
     const unsigned long long tl1 = DH_DBG_T();
