@@ -270,6 +270,7 @@ struct dellyhip_ctx {
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
   int msa_only = 0;          // env DELLYHIP_MSA_ONLY=1 (profiling builds): msa() batches stop after the MSA kernels
   int msa_waves = 16;        // resident wavefronts of msa_kernel per CU (env DELLYHIP_MSA_WAVES; 128 VGPRs and 9.7 KB of LDS allow 16)
+  int msa_team = 0;          // wavefronts per junction of the MSA kernel: 0 = by batch size (env DELLYHIP_MSA_TEAM = 1 | 2 | 4 forces it)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
@@ -352,6 +353,8 @@ struct dellyhip_batch {
   DevBuf<uint8_t> msa_ws;
   DevBuf<uint8_t> msa_big_ws;        // msa_big instance: junctions beyond the standard instance's shapes
   dh::MsaPlan msa_plan;
+  int msa_team = 1, msa_grid = 1;     // wavefronts per junction of the score-table MSA kernel, its blocks
+  uint64_t msa_stride = 0;            // workspace bytes per block
   int msa_big_grid = 0;
   // timing
   std::vector<hipEvent_t> ev;        // 4 events per launch since the last kernel_ms()
@@ -1194,6 +1197,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_ONLY")) c->msa_only = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_WAVES")) c->msa_waves = std::max(1, std::min(16, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_MSA_TEAM")) c->msa_team = atoi(t);
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   if (borrowed) {
     c->stream = borrowed;
@@ -1540,7 +1544,10 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       }
     } else {
       const dh::MsaPlan& mp = b->msa_plan;
-      if ((rc = b->msa_ws.reserve(std::max<uint64_t>(1, mp.ws_stride * (uint64_t)std::min(n, c->n_cu * c->msa_waves))))) return bail(rc);
+      b->msa_team = dh::msa_team_waves(n, c->n_cu * c->msa_waves, c->msa_team);
+      b->msa_grid = dh::msa_team_grid(n, c->n_cu * c->msa_waves, b->msa_team);
+      b->msa_stride = dh::msa_team_stride(mp.nmax, b->msa_team);
+      if ((rc = b->msa_ws.reserve(std::max<uint64_t>(1, b->msa_stride * (uint64_t)b->msa_grid)))) return bail(rc);
       // msa_big: as many resident wavefronts as junctions are expected there; a few stand by for the unpredictable
       // case (a node of the standard instance growing beyond its 512 columns)
       b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
@@ -1679,16 +1686,15 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.out_stride = b->out_stride;
     ma.cons_len = b->cons_len.p;
     ma.ws = b->msa_ws.p;
-    ma.ws_stride = b->msa_plan.ws_stride;
+    ma.ws_stride = b->msa_stride;
     ma.out_cons_cap = b->out_cons_cap;
     ma.big_counter = c->counters.p + 9;
     ma.n_work = b->n;
     ma.work_counter = c->counters.p;
     ma.defer_counter = c->counters.p + 8;
     ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
-    int grid = std::min(b->n, c->n_cu * c->msa_waves);
-    if ((rc = dh::msa_launch(ma, grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
-                             b->msa_plan.big_nmax)))
+    if ((rc = dh::msa_launch(ma, b->msa_grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
+                             b->msa_plan.big_nmax, b->msa_team)))
       return fail(rc, "msa_launch");
     HIPCHK(hipGetLastError());
     if (c->msa_only) {   // profiling: the records keep what the MSA kernels wrote (tools/msa_phases.py)
@@ -2489,7 +2495,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
     S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
     S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
-    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only;
+    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team;
   }
   *out = st.release();
   return 0;

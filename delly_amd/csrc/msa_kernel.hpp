@@ -27,6 +27,14 @@
 #include "split_kernel.hpp"
 
 
+// MSA_SYNC(): the hand-over between the lanes of ONE wavefront (LDS / workspace written by some lanes, read by others).  The
+// kernels of this file run one wavefront per workgroup, where __syncthreads() is exactly this fence (the compiler drops the
+// s_barrier of a single-wave workgroup); the team kernel runs several wavefronts of a workgroup through DIFFERENT merges at
+// the same time, where a real barrier inside a merge would deadlock.
+#ifndef MSA_SYNC
+#define MSA_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#endif
+
 namespace dh {
 
 // shared by both instances of the MSA code (msa_body.inc)
@@ -104,7 +112,7 @@ __device__ __forceinline__ int consensus_node(const Node& a, const dellyhip_para
       L.last[i] = last;
     }
   }
-  __syncthreads();
+  MSA_SYNC();
   const int thr = max(2, min(P.min_clique_size, a.rows));
   int outn = 0;
   for (int base = 0; base < a.len; base += WAVE) {
@@ -255,9 +263,23 @@ inline int msa_tmax(const dellyhip_params& P, int wanted) {
 
 // a.work_counter, a.defer_counter and a.big_counter must be zeroed on the stream before the call.  big_ws: workspace of
 // msa_big (big_grid blocks of big_stride bytes); junctions the standard instance flags with DELLYHIP_E_LIMIT are re-done there.
+// Wavefronts per junction of the score-table kernel (msa_team_kernel): one while a launch has enough junctions for every
+// resident slot, two or four when it does not (DELLYHIP_MSA_TEAM overrides; `delly sr` hands over 10^3 .. 10^4 per chromosome)
+inline int msa_team_waves(int n_junctions, int slots, int forced) {
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  if ((long long)n_junctions * 4 <= slots) return 4;
+  if ((long long)n_junctions * 2 <= slots + slots / 16) return 2;
+  return 1;
+}
+inline uint64_t msa_team_stride(int nmax, int team) { return team <= 1 ? ((MsaWs::bytes(nmax) + 255) & ~255ull) : ((MsaTeamWs::bytes(nmax, team) + 255) & ~255ull); }
+// blocks of `team` wavefronts that keep `slots` wavefront slots busy
+inline int msa_team_grid(int n_junctions, int slots, int team) { return std::max(1, std::min(n_junctions, slots / std::max(team, 1))); }
+
 inline int msa_launch(const MsaArgs& a, int grid, int nmax, hipStream_t s, uint8_t* big_ws = nullptr, uint64_t big_stride = 0,
-                      int big_grid = 0, int big_nmax = 0) {
-  hipLaunchKernelGGL(msa_kernel, dim3(grid), dim3(WAVE), 0, s, a, nmax);
+                      int big_grid = 0, int big_nmax = 0, int team = 1) {
+  if (team == 4) hipLaunchKernelGGL(msa_team_kernel<4>, dim3(grid), dim3(WAVE * 4), 0, s, a, nmax);
+  else if (team == 2) hipLaunchKernelGGL(msa_team_kernel<2>, dim3(grid), dim3(WAVE * 2), 0, s, a, nmax);
+  else hipLaunchKernelGGL(msa_kernel, dim3(grid), dim3(WAVE), 0, s, a, nmax);
   hipLaunchKernelGGL(msa_slow_kernel, dim3(grid), dim3(WAVE), 0, s, a, nmax);
   if (big_ws && big_grid > 0) {
     MsaArgs b = a;
