@@ -832,12 +832,16 @@ __device__ void process_junction(const SplitArgs& A, int j, WaveLds& L, uint32_t
 }
 
 template <int K>
-__global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A) {
+__global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A0) {
   __shared__ WaveLds L;
   const int lane = threadIdx.x;
+  if (A0.pair_mode && *A0.work_counter == 0) return;  // nothing was deferred by the packed kernel
+  if (A0.sps_left && *A0.sps_left == 0) return;
+  // (junction_post is a called function and takes the arguments by reference: the copy it reads lives in scratch memory, 208
+  //  bytes per lane.  Made HERE, behind the early exits: as the kernel parameter itself it was written at kernel entry -- 13 KB
+  //  of HBM writes per wavefront, 78 MB per step, by kernels that return at once because the sparse kernel left nothing)
+  const SplitArgs A = A0;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
-  if (A.pair_mode && *A.work_counter == 0) return;  // nothing was deferred by the packed kernel
-  if (A.sps_left && *A.sps_left == 0) return;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;
@@ -854,11 +858,12 @@ __global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A) {
 
 // post-processing kernel: one junction per wavefront, junctions the DP kernel marked JS_FOUND
 template <int K>
-__global__ __launch_bounds__(WAVE) void split_post_kernel(SplitArgs A) {
+__global__ __launch_bounds__(WAVE) void split_post_kernel(SplitArgs A0) {
   __shared__ WaveLds L;
   const int lane = threadIdx.x;
+  if (A0.sps_left && *A0.sps_left == 0) return;
+  const SplitArgs A = A0;   // (the copy junction_post reads: made behind the early exit, see split_align_kernel)
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
-  if (A.sps_left && *A.sps_left == 0) return;
   for (int w = blockIdx.x; w < A.n_work; w += gridDim.x) {
     const int j = A.work_list[w];
     if (j < 0) continue;

@@ -353,11 +353,12 @@ __device__ __forceinline__ void process_pair(const SplitArgs& A, int jA, int jB,
 #define DH_PAIR_WAVES 5
 #endif
 template <int K>
-__global__ __launch_bounds__(WAVE, DH_PAIR_WAVES) void split_pair_kernel(SplitArgs A) {
+__global__ __launch_bounds__(WAVE, DH_PAIR_WAVES) void split_pair_kernel(SplitArgs A0) {
   __shared__ PairLds L;
   const int lane = threadIdx.x;
+  if (A0.sps_left && *A0.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
+  const SplitArgs A = A0;   // (the copy the called helpers read: made behind the early exit, see split_align_kernel)
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
-  if (A.sps_left && *A.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
   for (;;) {
     int w = 0;
     if (lane == 0) w = atomicAdd(A.work_counter, 1);

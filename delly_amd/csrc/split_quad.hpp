@@ -345,14 +345,15 @@ __device__ __forceinline__ void process_quad(const SplitArgs& A, const int (&jq)
 // round runs the chip partly empty, so the host tops a whole number of quad rounds up with pair items
 // (cheaper wavefronts) instead of a thin extra quad round.  -1 = empty seat.
 template <int KQ, int KP>
-__global__ __launch_bounds__(WAVE, DH_QUAD_WAVES) void split_quad_kernel(SplitArgs A, int n_quads) {
+__global__ __launch_bounds__(WAVE, DH_QUAD_WAVES) void split_quad_kernel(SplitArgs A0, int n_quads) {
   __shared__ union {
     QuadLds q;
     PairLds p;
   } L;
   const int lane = threadIdx.x;
+  if (A0.sps_left && *A0.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
+  const SplitArgs A = A0;   // (the copy the called helpers read: made behind the early exit, see split_align_kernel)
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
-  if (A.sps_left && *A.sps_left == 0) return;   // the sparse kernel finished every junction of the batch
   for (;;) {
     int w = 0;
     if (lane == 0) w = atomicAdd(A.work_counter, 1);

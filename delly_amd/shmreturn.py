@@ -49,6 +49,13 @@ class Segment:
             struct.pack_into("<Q", self.shm.buf, 24, self.record_bytes)
         else:
             self.shm = shared_memory.SharedMemory(name=_name(tag, rank))
+            # (before Python 3.13 every attach registers the segment with this process's resource_tracker, which unlinks it when
+            #  the READER exits -- under the owner's feet; only the owner may unlink)
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:   # noqa: BLE001
+                pass
             if self.shm.size < size:
                 raise ValueError("segment of rank %d is smaller than agreed (%d < %d)" % (rank, self.shm.size, size))
         self.bytes = np.frombuffer(self.shm.buf, dtype=np.uint8)
@@ -78,8 +85,10 @@ class Segment:
         struct.pack_into("<Q", self.shm.buf, 0, (seq | 1) + 1)    # even: complete
 
     # ---- reader side -----------------------------------------------------------------------------------------------
-    def read(self, dtype):
-        """-> (sequence number, records as `dtype` view, blob view) of the last committed batch, or None while the owner writes"""
+    def read(self, dtype, copy=False):
+        """-> (sequence number, records as `dtype` view, blob view) of the last committed batch, or None while the owner writes.
+        The views are zero-copy and only validated at the moment of the read: the owner's next begin() overwrites them, so a
+        reader that consumes them later passes copy=True (or the owner waits for the reader before it calls begin())."""
         seq0, n, nb, rb = struct.unpack_from("<QQQQ", self.shm.buf, 0)
         if seq0 & 1:
             return None
@@ -87,6 +96,8 @@ class Segment:
             raise ValueError("record layout mismatch: %d bytes in the segment, %d expected" % (rb, np.dtype(dtype).itemsize))
         rec = self.bytes[HEADER:HEADER + n * rb].view(dtype)
         blob = self.bytes[self.blob_at:self.blob_at + nb]
+        if copy:
+            rec, blob = np.array(rec), np.array(blob)
         if struct.unpack_from("<Q", self.shm.buf, 0)[0] != seq0:
             return None
         return seq0 // 2, rec, blob
@@ -101,7 +112,10 @@ class Segment:
         self.bytes = None
         try:
             self.shm.close()
-            if self.owner:
-                self.shm.unlink()
-        except (BufferError, FileNotFoundError):
+        except BufferError:      # a view handed out by read() / records_view() is still referenced: the mapping stays, the NAME must still go
             pass
+        if self.owner:
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass

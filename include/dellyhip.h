@@ -266,9 +266,11 @@ int dellyhip_batch_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_sp
  * junctions per wavefront; split_pair_kernel<K> for consensus sequences of 160 .. 319 bp). */
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms_dp);
 
-/* Junctions of the batch's LAST run that split_sparse_kernel did not finish -- shapes beyond its tile, letters outside
- * A, C, G, T, N, deficits beyond its 32 levels -- and handed to the dense kernels (0 when the sparse kernel is off or the
- * batch has no short-read junctions).  The sparse kernel's cost grows with a junction's deficit, the dense kernels' does
+/* Junctions that split_sparse_kernel did not finish -- shapes beyond its tile, letters outside A, C, G, T, N, deficits
+ * beyond its 32 levels -- and handed to the dense kernels, in the LAST RUN ON THIS CONTEXT (the counter belongs to the
+ * context, not to the batch: with several resident batches per context call this after the run of `b` and before the next
+ * dellyhip_batch_run on the context; the pipelined path reports the number per batch with its results).  0 when the sparse
+ * kernel is off or the run had no short-read junctions.  The sparse kernel's cost grows with a junction's deficit, the dense kernels' does
  * not (like the reference, src/needle.h:64-115): this is the number that says which regime a batch ran in. */
 int dellyhip_batch_sparse_left(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t* left);
 
