@@ -79,3 +79,24 @@ def test_single_item_wrappers_on_real_reads(reference, gpu_ctx):
         s = lr.seqs_of(k)
         assert gpu_ctx.msa_edlib(s) == reference.msa_edlib(s)
         assert gpu_ctx.msa_wfa(s) == reference.msa_wfa(s)
+
+
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_real_split_reads_as_dup_inv_bnd_on_rearranged_real_sequence(reference, sparse, monkeypatch):
+    """The example data only carries a deletion: the other six SV types get the SAME real split reads on chromosomes made of
+    rearranged real chr18 sequence (tests/golden/make_example_reads.py, `svx`): DUP, INV 3to3 / 5to5, BND 3to5 / 5to3 / 3to3 /
+    5to5 -- the reference refines every one to the base -- plus reads of the wrong strand and ordinary reads as candidates of
+    every type.  msa() + alignConsensus(), sparse kernel on and off, against oracle/_ref."""
+    z = np.load(os.path.join(HERE, "golden", "example_reads.npz"))
+    chroms = [z["svx_chr%d" % i] for i in range(int(z["svx_nchr"]))]
+    b = synth.Batch(chroms, z["svx_junc"], z["svx_blob"], z["svx_off"], 1, None)
+    monkeypatch.setenv("DELLYHIP_SR_SPARSE", sparse)
+    ctx = refine.Context()
+    ctx.set_chromosomes(b.chroms)
+    gr, gb = ctx.refine(b, want_alignment=True)
+    ctx.close()
+    rr, rb = reference.refine_batch(b, want_alignment=True)
+    compare(gr, gb, rr, rb, fields=CORE, label="rearranged example reads")
+    svt = b.junctions["svt"][:7].tolist()
+    assert svt == [3, 0, 1, 7, 8, 5, 6] and gr["ok"][:7].tolist() == [1] * 7 and int(gr["ok"][7:].sum()) == 0
+    assert (gr["sr_align_quality"][:7] == 1.0).all() and (gr["sr_support"][:7] == 10).all()

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from delly_amd import synth
+from delly_amd import refine, synth
 from util import CORE, INTERNAL, compare
 
 pytestmark = pytest.mark.gpu
@@ -137,3 +137,20 @@ def test_msa_long_nodes_take_the_direct_kernel(gpu_ctx, port):
             assert "-4" in str(e)
             continue
         assert got == port.msa(reads), it
+
+
+@pytest.mark.parametrize("team", [2, 4])
+def test_msa_team_of_wavefronts_gives_the_same_consensus(reference, team, monkeypatch):
+    """msa_team_kernel<W>: W wavefronts per junction (LCS pairs across the team, merges claimed as their children finish) --
+    the schedule must not show in the result: whole refine batches vs the reference itself, team size forced"""
+    monkeypatch.setenv("DELLYHIP_MSA_TEAM", str(team))
+    ctx = refine.Context()
+    try:
+        for n_reads, seed in ((20, 5), (7, 6), (2, 7), (3, 8)):
+            b = synth.make_batch(96, mode="c2", n_reads=n_reads, seed=seed)
+            ctx.set_chromosomes(b.chroms)
+            gr, gb = ctx.refine(b, want_alignment=False)
+            rr, rb = reference.refine_batch(b, want_alignment=False, n_threads=os.cpu_count() or 1)
+            compare(gr, gb, rr, rb, fields=CORE, blobs=("cons", "allele"), label="team %d, %d reads" % (team, n_reads))
+    finally:
+        ctx.close()
