@@ -161,10 +161,16 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
   __shared__ SpsLds L;
   const int lane = threadIdx.x;
   uint32_t* scratch = A.scratch + (size_t)blockIdx.x * A.scratch_words;
+  // the first item of every wavefront is its block index -- 4 096 wavefronts asking ONE counter for their first item at launch
+  // queue up behind each other for tens of microseconds -- the following ones come from the counter (offset by the grid size)
+  bool first = true;
   for (;;) {
-    int w = 0;
-    if (lane == 0) w = atomicAdd(A.work_counter, 1);
-    w = rfl(w);
+    int w = (int)blockIdx.x;
+    if (!first) {
+      if (lane == 0) w = atomicAdd(A.work_counter, 1) + (int)gridDim.x;
+      w = rfl(w);
+    }
+    first = false;
     if (w >= A.n_work) break;
     const int j = A.work_list[w];
     // (the lane index is laundered once per junction: address arithmetic on it is then recomputed per junction instead of being
