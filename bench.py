@@ -122,7 +122,7 @@ def cpu_baseline(batch, budget_s=12.0):
 
 def _profile_file(name):
     """newest committed copy of a profile artefact (profiles/rNN/<name>)"""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             return path
@@ -551,9 +551,11 @@ def main():
     # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
     # streams the library verified to run side by side, so the tail of one step's launch runs under the head of the next
     # (one 10 000-junction launch alone: 2.4 wavefronts per resident slot, a 50 us ramp and a 180 us tail of 0.40 ms).
-    # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: one context, the return of step k - 1's
-    # results overlaps the kernels of step k.
-    ctxs = [ctx] if multi else [ctx, refine.Context(device=local, share_with=ctx)]
+    # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: the return of step k - 1's results overlaps
+    # the kernels of step k.
+    # (N > 1 too: the two resident batches live in two contexts, so the return of step k - 1's results -- compaction kernels
+    #  and downloads on that batch's own stream -- is not queued behind the kernels of step k)
+    ctxs = [ctx, refine.Context(device=local, share_with=ctx)]
     streams = list(ctx.compute_streams())[:len(ctxs)]
     rbs = [ctxs[k % len(ctxs)].upload(b) for k, b in enumerate(batches)]
 
@@ -889,6 +891,8 @@ def main():
         dist.barrier()       # (readers unmap before the owners unlink)
     if seg is not None:
         seg.close()
+    for cx in ctxs[1:]:
+        cx.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
