@@ -59,9 +59,21 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 struct DevPool {
   // dirty: handed back without a synchronisation -- work enqueued by the previous owner may still touch it (hipFree used
   // to wait implicitly).  The first reuse of a dirty block waits for the device once and clears the flag on every block.
-  struct Block { void* p; size_t bytes; int device; bool dirty; };
+  struct Block { void* p; size_t bytes; int device; bool dirty; uint64_t seq; };
   std::mutex mu;
   std::vector<Block> free_list;
+  uint64_t seq = 0;   // blocks handed back so far (a device synchronisation cleans every block handed back before it started)
+  // the device a block lives on: asked of the runtime, not assumed to be the calling thread's current device (a destructor
+  // may run under another current device in a process that drives several GPUs)
+  static int device_of(const void* p, bool host) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess) return a.device;
+    (void)hipGetLastError();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)host;
+    return dev;
+  }
   static DevPool& get() { static DevPool* P = new DevPool(); return *P; }   // (never destroyed: the runtime may be gone at exit)
   static size_t round_up(size_t b) { return b <= (1u << 20) ? ((b + 255) & ~(size_t)255) : ((b + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1)); }
   void* take(size_t want, size_t* got, hipError_t* err) {
@@ -69,7 +81,7 @@ struct DevPool {
     (void)hipGetDevice(&dev);
     want = round_up(std::max<size_t>(want, 1));
     {
-      std::lock_guard<std::mutex> g(mu);
+      std::unique_lock<std::mutex> g(mu);
       size_t best = free_list.size();
       for (size_t i = 0; i < free_list.size(); ++i)
         if (free_list[i].device == dev && free_list[i].bytes >= want && free_list[i].bytes <= 2 * want + (1u << 16) &&
@@ -78,11 +90,16 @@ struct DevPool {
       if (best != free_list.size()) {
         Block b = free_list[best];
         free_list.erase(free_list.begin() + (long)best);
-        if (b.dirty) {
-          (void)hipDeviceSynchronize();
-          for (auto& f : free_list)
-            if (f.device == dev) f.dirty = false;
+        if (!b.dirty) {
+          *got = b.bytes;
+          return b.p;
         }
+        const uint64_t upto = seq;
+        g.unlock();                            // (the wait for the device happens outside the lock: other threads go on allocating)
+        (void)hipDeviceSynchronize();
+        g.lock();
+        for (auto& f : free_list)
+          if (f.device == dev && f.seq <= upto) f.dirty = false;
         *got = b.bytes;
         return b.p;
       }
@@ -111,12 +128,11 @@ struct DevPool {
     return v;
   }
   void give(void* p, size_t bytes) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    const int dev = device_of(p, false);
     std::vector<Block> victims;
     {
       std::lock_guard<std::mutex> g(mu);
-      free_list.push_back(Block{p, bytes, dev, true});
+      free_list.push_back(Block{p, bytes, dev, true, ++seq});
       size_t parked = 0;
       for (auto& f : free_list)
         if (f.device == dev) parked += f.bytes;
@@ -1014,8 +1030,7 @@ struct PinPool {
     return p;
   }
   void give(void* p, size_t bytes) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    const int dev = DevPool::device_of(p, true);   // (the device the block was pinned for, whatever the current one is)
     std::lock_guard<std::mutex> g(mu);
     free_list.push_back(Block{p, bytes, dev});
   }
