@@ -18,6 +18,8 @@
 #include <vector>
 
 #include "../../include/dellyhip.h"
+#include <thread>
+#include <chrono>
 #include "msa_kernel.hpp"
 #include "split_main.hpp"
 #include "split_pk.hpp"
@@ -32,6 +34,8 @@
 #include "probes_kernel.hpp"
 #include "edlib_kernel.hpp"
 #include "comm.hpp"
+
+static bool streams_run_concurrently(hipStream_t a, hipStream_t b, int* scratch2);   // (defined with the pipelined path)
 
 namespace {
 
@@ -279,6 +283,10 @@ struct dellyhip_ctx {
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
   int lr_waves = 8;          // resident wavefronts of the strip kernel per CU when the sparse passes are on (env DELLYHIP_LR_WAVES)
+  int lr_team_serial = 0;    // env DELLYHIP_LR_TEAMS_SERIAL (A/B)
+  int lr_teams = 64;         // teams of lr_dense_team_kernel at most (env DELLYHIP_LR_TEAMS; 0: the dense strips stay on lr_kernel's wavefronts)
+  hipStream_t lr_aux = nullptr;            // the teams' stream (beside the stream of the batch); lr_aux_all: every candidate created for it
+  std::vector<hipStream_t> lr_aux_all;
   int sps_waves = 16;        // wavefronts of split_sparse_kernel per CU (env DELLYHIP_SPS_WAVES; 16 = what LDS and registers allow)
   int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
   int sparse_cost = 160;     // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
@@ -333,6 +341,9 @@ struct dellyhip_batch {
   int lr_first = 0, lr_count = 0, lr_blocks = 0;
   dh::LrArgs lr{};
   DevBuf<uint8_t> lr_ws;
+  int lr_teams = 0;                  // teams of lr_dense_team_kernel for this batch (0: none)
+  DevBuf<int32_t> lr_team_state;     // dh::LRT_* counters + the list of junctions handed to the teams
+  hipEvent_t lr_fork = nullptr, lr_join = nullptr;
   // long-read insertions (svt 4 beyond the short-read shapes)
   int lri_first = 0, lri_count = 0, lri_blocks = 0;
   dh::LrInsArgs lri{};
@@ -503,6 +514,29 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   return run_split_dense(c, b, s, direct, a, mid_done);
 }
 
+// the stream lr_dense_team_kernel runs on, beside the stream of the batch; the fork / join events of the batch.  HIP streams
+// share a few hardware queues and two streams on one queue run in order (the teams would start when lr_kernel ends: correct,
+// but nothing gained), so candidates are probed against the context's own stream as dellyhip_compute_streams probes its pair.
+int ensure_lr_aux(dellyhip_ctx* c, dellyhip_batch* b) {
+  if (!b->lr_fork) HIPCHK(hipEventCreateWithFlags(&b->lr_fork, hipEventDisableTiming));
+  if (!b->lr_join) HIPCHK(hipEventCreateWithFlags(&b->lr_join, hipEventDisableTiming));
+  if (c->lr_aux) return 0;
+  int* probe = nullptr;
+  const bool can_probe = !getenv("DELLYHIP_STREAM_NO_PROBE") && dh::dev_alloc((void**)&probe, 2 * sizeof(int)) == hipSuccess;
+  hipStream_t pick = nullptr;
+  for (int t = 0; t < 4 && !pick; ++t) {
+    hipStream_t cand = nullptr;
+    if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+    c->lr_aux_all.push_back(cand);
+    if (!can_probe || streams_run_concurrently(c->stream, cand, probe)) pick = cand;
+  }
+  if (probe) dh::dev_free(probe);
+  if (!pick && !c->lr_aux_all.empty()) pick = c->lr_aux_all[0];
+  if (!pick) return fail(DELLYHIP_E_RUNTIME, "no stream for the long-read teams");
+  c->lr_aux = pick;
+  return 0;
+}
+
 dh::SplitArgs make_split_args(dellyhip_ctx* c, dellyhip_batch* b, bool direct) {
   dh::SplitArgs a{};
   a.junc = b->junc.p;
@@ -578,8 +612,32 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
     const int grid = std::min(b->lr_count, b->lr_blocks);
     dh::LrArgs lr = b->lr;
     lr.realign = (c->params.reserved & 1) ? 1 : 0;
+    lr.lr_grid = grid;
+    hipStream_t aux = nullptr;
+    if (b->lr_teams > 0 && lr.team_state && ensure_lr_aux(c, b) == 0) aux = (s == c->lr_aux) ? c->stream : c->lr_aux;
+    const bool serial = aux && c->lr_team_serial;   // (A/B: the teams after lr_kernel on the batch's own stream)
+    if (aux) {
+      HIPCHK(hipMemsetAsync(lr.team_state, 0, dh::LRT_LIST * sizeof(int32_t), s));
+      HIPCHK(hipMemsetAsync(lr.team_state + dh::LRT_LIST, 0xff, (size_t)lr.team_cap * sizeof(int32_t), s));
+#ifdef DH_LR_TEAM_DEBUG
+      HIPCHK(hipMemsetAsync(lr.team_state + dh::LRT_LIST + lr.team_cap, 0, (8 * 4096 + 8) * sizeof(int32_t), s));
+#endif
+      HIPCHK(hipEventRecord(b->lr_fork, s));
+    } else {
+      lr.team_state = nullptr;
+    }
     hipLaunchKernelGGL(dh::lr_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, lr);
     HIPCHK(hipGetLastError());
+    if (serial) {
+      hipLaunchKernelGGL(dh::lr_dense_team_kernel, dim3(b->lr_teams), dim3(dh::WAVE * dh::LR_TEAM_W), 0, s, a, lr);
+      HIPCHK(hipGetLastError());
+    } else if (aux) {   // the teams run beside lr_kernel; the batch's stream goes on when both are through
+      HIPCHK(hipStreamWaitEvent(aux, b->lr_fork, 0));
+      hipLaunchKernelGGL(dh::lr_dense_team_kernel, dim3(b->lr_teams), dim3(dh::WAVE * dh::LR_TEAM_W), 0, aux, a, lr);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(b->lr_join, aux));
+      HIPCHK(hipStreamWaitEvent(s, b->lr_join, 0));
+    }
   }
   if (b->lri_count > 0 && !direct) {
     a.work_list = b->work.p + b->lri_first;
@@ -661,6 +719,7 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   R.off_trR = take((uint64_t)R.mcap + R.ncap + 64);
   R.off_stack = take((uint64_t)Q * R.strip_words * 4);
   R.off_masks = take(dh::lr_masks_bytes());
+  R.off_bndx = take((uint64_t)(dh::LR_TEAM_W - 1) * ((uint64_t)R.ncap + 128) * 4);
   // sparse longNeedle (sparse_needle.hpp): furthest-reaching tables for up to 256 deficit levels of this batch's
   // longest shapes (2 int16 per diagonal + 2 int32 per consensus row and level, both matrices) + the run lists
   R.sparse_bytes = 0;
@@ -677,7 +736,24 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
   // registers allow (156 VGPRs: 3 per SIMD) -- LDS permitting -- and the workspace budget holds
   b->lr_blocks = std::max(1, std::min(lr_cnt, c->n_cu * (c->use_sparse ? c->lr_waves : 4)));
   b->lr_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lr_blocks, ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1)));
-  int rc = b->lr_ws.reserve((size_t)R.ws_stride * b->lr_blocks);
+  // teams for the dense strips (lr_dense_team_kernel): their workspaces follow lr_kernel's; the list takes two junctions per team,
+  // what lr_kernel finds beyond that it sweeps itself (a batch of unalignable junctions has more wavefronts than teams)
+  b->lr_teams = 0;
+  R.team_state = nullptr;
+  R.team_first_ws = b->lr_blocks;
+  R.team_cap = 0;
+  if (c->use_sparse && c->lr_teams > 0) {
+    const uint64_t room = ws_budget_bytes() / std::max<uint64_t>(R.ws_stride, 1);
+    const int teams = (int)std::min<uint64_t>((uint64_t)std::min(lr_cnt, c->lr_teams), room > (uint64_t)b->lr_blocks ? room - b->lr_blocks : 0);
+    if (teams > 0) {
+      R.team_cap = 2 * teams;
+      int rc = b->lr_team_state.reserve((size_t)dh::LRT_LIST + R.team_cap + 8 * 4096 + 8);   // (+ the marks of debug builds)
+      if (rc) return rc;
+      b->lr_teams = teams;
+      R.team_state = b->lr_team_state.p;
+    }
+  }
+  int rc = b->lr_ws.reserve((size_t)R.ws_stride * (b->lr_blocks + b->lr_teams));
   if (rc) return rc;
   R.ws = b->lr_ws.p;
   return 0;
@@ -1207,6 +1283,8 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LR_WAVES")) c->lr_waves = std::max(1, std::min(8, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_LR_TEAMS")) c->lr_teams = std::max(0, std::min(256, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_LR_TEAMS_SERIAL")) c->lr_team_serial = atoi(t) ? 1 : 0;
   if (const char* t = getenv("DELLYHIP_SPS_WAVES")) c->sps_waves = std::max(1, std::min(20, atoi(t)));
   if (const char* t = getenv("DELLYHIP_SPARSE_COST")) c->sparse_cost = std::max(1, atoi(t));
   if (const char* t = getenv("DELLYHIP_QUAD_MIX")) c->quad_mix = atoi(t) != 0;
@@ -1278,6 +1356,7 @@ void dellyhip_destroy(dellyhip_ctx* c) {
   c->scratch.release();
   c->counters.release();
   if (c->serial_ev) (void)hipEventDestroy(c->serial_ev);
+  for (auto q : c->lr_aux_all) (void)hipStreamDestroy(q);
   if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1317,7 +1396,9 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
+  if (b->lr_fork) (void)hipEventDestroy(b->lr_fork);
+  if (b->lr_join) (void)hipEventDestroy(b->lr_join);
   for (auto e : b->ev) (void)hipEventDestroy(e);
   for (auto e : b->ev_free) (void)hipEventDestroy(e);
   if (b->len_ev) (void)hipEventDestroy(b->len_ev);
@@ -1767,6 +1848,14 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
 int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
   if (!b->pending) return 0;
+  if (getenv("DELLYHIP_TRACE_SYNC")) {   // (debugging aid: a batch that does not finish says how far its stream got)
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipEventQuery(b->last) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    if (hipEventQuery(b->last) == hipErrorNotReady)
+      fprintf(stderr, "dellyhip_batch_sync: not finished after 5 s; long-read fork event (after the team state memsets, before lr_kernel): %s\n",
+              !b->lr_fork ? "none" : hipEventQuery(b->lr_fork) == hipSuccess ? "reached" : "NOT reached");
+    (void)hipGetLastError();
+  }
   HIPCHK(hipEventSynchronize(b->last));
   for (size_t q = 0; q + 3 < b->ev.size(); q += 4) {
     float a = 0, d = 0, e = 0;
@@ -1799,6 +1888,35 @@ int dellyhip_batch_sparse_left(dellyhip_ctx* c, dellyhip_batch* b, int32_t* left
   if (rc || !c->counters.p || !b->ever_run) return rc;
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpy(left, c->counters.p + 31, sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int dellyhip_batch_lr_team_stats(dellyhip_ctx* c, dellyhip_batch* b, int32_t out[4]) {
+  if (!c || !b || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc || !b->ever_run || b->lr_teams <= 0 || !b->lr_team_state.p) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  int32_t v[4];
+  HIPCHK(hipMemcpy(v, b->lr_team_state.p, sizeof(v), hipMemcpyDeviceToHost));
+#ifdef DH_LR_TEAM_DEBUG
+  {
+    std::vector<int32_t> all((size_t)dh::LRT_LIST + b->lr.team_cap + 8 * (size_t)b->lr_teams);
+    HIPCHK(hipMemcpy(all.data(), b->lr_team_state.p, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    fprintf(stderr, "lr teams: count %d taken %d done %d error %d | list", all[0], all[1], all[2], all[3]);
+    for (int i = 0; i < std::min(b->lr.team_cap, 12); ++i) fprintf(stderr, " %d", all[dh::LRT_LIST + i]);
+    fprintf(stderr, "\n");
+    for (int t = 0; t < b->lr_teams; ++t) {
+      const int32_t* d = all.data() + dh::LRT_LIST + b->lr.team_cap + 8 * t;
+      static int base = 0; if (t == 0) { int32_t v = 0; (void)hipMemcpy(&v, b->lr_team_state.p + dh::LRT_LIST + b->lr.team_cap + 8 * 4096, 4, hipMemcpyDeviceToHost); base = v; }
+      if (d[0]) fprintf(stderr, "  team %d: junction %d | x10us after lr_kernel's block 0 started: entry %d, got it %d, set up +%d, R strips +%d, M strips +%d, winner +%d, end +%d = %d\n", t, d[1], d[2] - base, d[3] - base, d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[0] - d[7], d[0] - base);
+    }
+  }
+#endif
+  out[0] = b->lr_teams;
+  out[1] = std::min(v[dh::LRT_COUNT], b->lr.team_cap);   // junctions the teams took (the list's capacity bounds it)
+  out[2] = v[dh::LRT_TAKEN];
+  out[3] = v[dh::LRT_ERROR];
   return 0;
 }
 
@@ -1879,7 +1997,9 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < b->n; ++i) {
       rebase_offsets(results[i], off[i]);
+#ifndef DH_LR_TIMING   // (the timing build of tools/ hands its phase times out in this field)
       results[i].reserved = 0;   // (transient kernel state -- SPS_DONE and the like -- does not cross the ABI)
+#endif
     }
   }
   if (out_blob_len) *out_blob_len = used;
@@ -2509,7 +2629,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // stream), the compaction kernels and the memsets find room at once instead of in the kernel's tail -- 32.4 against
     // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
     S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
-    S.ctx->lr_waves = c->lr_waves; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
+    S.ctx->lr_waves = c->lr_waves; S.ctx->lr_teams = c->lr_teams; S.ctx->lr_team_serial = c->lr_team_serial; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
     S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team;
   }
   *out = st.release();

@@ -47,7 +47,18 @@ struct LrArgs {
   uint64_t off_sparse;    // furthest-reaching tables of the sparse longNeedle (sparse_needle.hpp)
   uint64_t sparse_bytes;  // 0: dense strip passes only
   int32_t sparse_cost;    // predicted deficit beyond which the dense strips are taken (SparseWs::pred_cap)
+  // dense strips on a TEAM of wavefronts (lr_dense_team_kernel, running beside lr_kernel on a second stream): lr_kernel hands the
+  // junctions its sparse passes give up on to the list in team_state instead of sweeping the strips on its one wavefront
+  int32_t* team_state;    // nullptr: no team kernel.  [LRT_COUNT] junctions listed, [LRT_TAKEN] claimed by teams, [LRT_IN]
+                          // (unused), [LRT_ERROR]; the list (junction indices, -1 = not yet written) from [LRT_LIST]
+  uint64_t off_bndx;      // LR_TEAM_W - 1 more boundary rows behind bnd0 / bnd1 (a team keeps LR_TEAM_W + 1 strips' rows alive)
+  int32_t team_first_ws;  // workspace index of team 0 (the teams' workspaces follow lr_kernel's)
+  int32_t team_cap;       // entries of the list; a junction that finds it full stays on lr_kernel's wavefront
+  int32_t lr_grid;        // wavefronts of lr_kernel: every one of them ends with ONE fetch beyond the work list, so the work counter
+                          // reads n_work + lr_grid exactly when lr_kernel is through with every junction
 };
+constexpr int LR_TEAM_W = 4;   // wavefronts of a team
+enum { LRT_COUNT = 0, LRT_TAKEN = 1, LRT_IN = 2, LRT_ERROR = 3, LRT_LIST = 4 };
 
 struct StrPtr {           // the four strings of a junction (workspace)
   uint8_t* cons;
@@ -119,12 +130,46 @@ __device__ __forceinline__ int writelane16(int sval, int lane_idx, int old) {  /
 
 // ---- strip passes ------------------------------------------------------------------------
 
+// Strips of one matrix on DIFFERENT wavefronts of a team: strip q + 1 needs the last row of strip q, column by column, so it
+// can run a few blocks of 16 columns behind it.  Each strip counts its finished blocks in LDS; the boundary rows go through
+// the workspace as before (same CU, same L1: the counter is a workgroup-scope release / acquire).  A block of the producer
+// ends 62 columns behind the consumer's first lane, so the values of block b are there once the producer has finished b + 5.
+struct LrPipe {
+  int* prev = nullptr;      // finished blocks of the strip whose last row is read (nullptr: none, or the strips run one after the other)
+  int* mine = nullptr;      // this strip's counter (nullptr: nobody reads its last row)
+  int prev_nblk = 0;        // blocks the producer runs in total
+  int* bail = nullptr;      // set when a wait ran out of patience: a team member is gone, everybody stops waiting
+};
+#ifndef DH_LR_TEAM_PATIENCE
+#define DH_LR_TEAM_PATIENCE 400000000ull   // 4 s of the 100 MHz wall clock
+#endif
+constexpr unsigned long long LR_TEAM_PATIENCE = DH_LR_TEAM_PATIENCE;
+__device__ __forceinline__ void lr_pipe_wait(const LrPipe& P, int blk) {   // before the boundary values of block `blk` are loaded
+  if (!P.prev) return;
+  const int need = min(P.prev_nblk, blk + 5);
+  volatile int* pv = P.prev;
+  if (*pv < need) {
+    const unsigned long long t0 = wall_clock64();
+    while (*pv < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (*(volatile int*)P.bail) break;
+      if (wall_clock64() - t0 > LR_TEAM_PATIENCE) { *(volatile int*)P.bail = 1; break; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lr_pipe_post(const LrPipe& P, int blocks_done) {
+  if (!P.mine) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the boundary stores of the block first)
+  *(volatile int*)P.mine = blocks_done;
+}
+
 // R pass of strip q (rev rows rho = q*320 + ls - pad).  bin/bout: boundary rows (V' of the row
 // above the strip / of the strip's last row), index = column.  Pushes the running-max codes of
 // pass_R (split_kernel.hpp) to `stack`, the final running maxima to brout[q*320 + ls].
 // Returns the final V' of the strip's last slot (lane 63).
 __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref, int m, int n, int q, int pad,
-                                      const int32_t* bin, int32_t* bout, uint32_t* stack, int32_t* brout, int lane) {
+                                      const int32_t* bin, int32_t* bout, uint32_t* stack, int32_t* brout, int lane, LrPipe P = LrPipe{}) {
   constexpr int K = LRK;
   int a[K], hg[K], h[K], br[K];
   uint32_t acc[K];
@@ -147,8 +192,10 @@ __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref,
   // (one wavefront per SIMD cannot hide a dependent HBM/L2 load per 16 steps)
   auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < n) ? (int)rref[ci] : NOMATCH; };
   auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= n) ? bin[ci + 1] : NEGBIG; };
+  lr_pipe_wait(P, 0);
   int chunk = ld_chunk(0), bchunk = ld_bnd(0);   // column of lane 0 at step 16*blk+f is 16*blk+f+1
   for (int blk = 0; blk < nblk; ++blk) {
+    lr_pipe_wait(P, blk + 1);
     const int chunk_n = ld_chunk(blk + 1), bchunk_n = ld_bnd(blk + 1);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
@@ -185,6 +232,7 @@ __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref,
       const int col = blk * 16 + lane - 62;
       if (lane < 16 && col >= 0 && col <= n) bout[col] = outv;
     }
+    lr_pipe_post(P, blk + 1);
     chunk = chunk_n;
     bchunk = bchunk_n;
   }
@@ -198,7 +246,7 @@ __device__ __noinline__ int lr_pass_R(const uint8_t* rcons, const uint8_t* rref,
 // hpad = final V' (scaled) of local slot `pad_ls` (M row m lives there in strip 0).
 __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* ref, int m, int n, int q, int pad,
                                             const int32_t* bin, int32_t* bout, const uint32_t* stack,
-                                            const int32_t* brin, int pad_ls, int lane, int& hpad) {
+                                            const int32_t* brin, int pad_ls, int lane, int& hpad, LrPipe P = LrPipe{}) {
   constexpr int K = LRK;
   int a[K], hg[K], h[K], bm[K], g[K], bestkey[K];
   uint32_t dw[K];
@@ -229,6 +277,7 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
   uint32_t wn[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) wn[i] = ld_scratch(&stack[((size_t)(nblk - 1) * K + i) * WAVE + lane]);
+  lr_pipe_wait(P, 0);   // (the blocks run from nblk - 1 down: block blk is number nblk - 1 - blk of this pass)
   int chunk = ld_chunk(nblk - 1), bchunk = ld_bnd(nblk - 1);
   for (int blk = nblk - 1; blk >= 0; --blk) {
 #pragma unroll
@@ -242,6 +291,7 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
 #pragma unroll
       for (int i = 0; i < K; ++i) wn[i] = ld_scratch(&stack[((size_t)(blk - 1) * K + i) * WAVE + lane]);
     }
+    lr_pipe_wait(P, nblk - blk);
     const int chunk_n = ld_chunk(blk - 1), bchunk_n = ld_bnd(blk - 1);
 #pragma unroll
     for (int f = 15; f >= 0; --f) {
@@ -274,6 +324,7 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
       const int col = T - 63 - 16 * blk - 15 + lane;
       if (lane < 16 && col >= 0 && col <= n) bout[col] = outv;
     }
+    lr_pipe_post(P, nblk - blk);
     chunk = chunk_n;
     bchunk = bchunk_n;
   }
@@ -297,7 +348,7 @@ __device__ __noinline__ long long lr_pass_M(const uint8_t* cons, const uint8_t* 
 
 // direction pass of strip q (natural slots: row = q*320 + ls), rows <= rmax, columns 1..ncols
 __device__ __noinline__ void lr_pass_dir(const uint8_t* rowstr, const uint8_t* colstr, int m, int q, int rmax, int ncols,
-                                         const int32_t* bin, int32_t* bout, uint32_t* dirs, int lane) {
+                                         const int32_t* bin, int32_t* bout, uint32_t* dirs, int lane, LrPipe P = LrPipe{}) {
   constexpr int K = LRK;
   int a[K], hg[K], h[K];
   uint32_t acc[K];
@@ -318,8 +369,10 @@ __device__ __noinline__ void lr_pass_dir(const uint8_t* rowstr, const uint8_t* c
   int outv = 0;
   auto ld_chunk = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (ci < ncols) ? (int)colstr[ci] : NOMATCH; };
   auto ld_bnd = [&](int blk) { const int ci = blk * 16 + (lane & 15); return (bin && ci + 1 <= ncols) ? bin[ci + 1] : NEGBIG; };
+  lr_pipe_wait(P, 0);
   int chunk = ld_chunk(0), bchunk = ld_bnd(0);
   for (int blk = 0; blk < nblk; ++blk) {
+    lr_pipe_wait(P, blk + 1);
     const int chunk_n = ld_chunk(blk + 1), bchunk_n = ld_bnd(blk + 1);
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
@@ -354,6 +407,7 @@ __device__ __noinline__ void lr_pass_dir(const uint8_t* rowstr, const uint8_t* c
       const int col = blk * 16 + lane - 62;
       if (lane < 16 && col >= 0 && col <= ncols) bout[col] = outv;
     }
+    lr_pipe_post(P, blk + 1);
     chunk = chunk_n;
     bchunk = bchunk_n;
   }
@@ -432,7 +486,7 @@ __device__ __forceinline__ int lr_nw_distance(const uint8_t* target, int tn, con
     int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bnd1 : bnd0) : nullptr;
     d = lr_pass_ed(target, tn, query, qn, q, bin, bout, tn - q * LRS, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    DH_SYNC();
   }
   return rfl(d);
 }
@@ -459,26 +513,141 @@ __device__ __noinline__ int lr_traceback(const uint32_t* dirs, uint64_t strip_wo
   return tl;
 }
 
+// -DDH_LR_TEAM_DEBUG (tools/lr_team_check.py): the time line of every team behind the list, 8 ints per team, in units of 10 us of the
+// 100 MHz wall clock: [0] end, [1] junction, [2] the workgroup started, [3] junction obtained, [4] set-up done, [5] R strips, [6] M strips,
+// [7] winner; lr_kernel's block 0 leaves its own start behind the marks.  dellyhip_batch_lr_team_stats prints them.
+#ifdef DH_LR_TEAM_DEBUG
+#define LRT_MARK(code, val) do { if (lane == 0) { int32_t* dbg_ = R.team_state + LRT_LIST + R.team_cap + 8 * (int)blockIdx.x; const int now_ = (int)((wall_clock64() / 1000ull) & 0x7fffffffull); if ((code) == 1) dbg_[1] = (val); if ((code) >= 1 && (code) <= 5) dbg_[2 + (code)] = now_; if ((code) == 9) dbg_[0] = now_; if ((code) == 0) dbg_[2] = now_; } } while (0)
+#else
+#define LRT_MARK(code, val) do { } while (0)
+#endif
+// ---- a team of wavefronts for the dense strips -------------------------------------------------------------------------
+// lr_dense_team_kernel: LR_TEAM_W wavefronts per workgroup.  Wavefront 0 ("main") runs the junction as lr_kernel would; the
+// others only run strips: main writes a command (which matrix, its strings and buffers) into LDS, every wavefront w takes the
+// strips w, w + W, ... of it, and consecutive strips run pipelined (LrPipe) instead of one after the other.  A team keeps
+// W + 1 boundary rows: strip q writes row q % (W + 1), which strip q + W + 1 -- the same wavefront as its reader q + 1,
+// later -- overwrites.
+enum { LRC_EXIT = 0, LRC_R = 1, LRC_M = 2, LRC_DIR = 3 };
+struct LrTeamCtl {
+  int seq, cmd, done, bail;
+  int prog[LR_QMAX + 2];             // finished blocks per strip of the running command
+  const uint8_t* rowstr;
+  const uint8_t* colstr;
+  int m, n, Q, pad, rmax, pad_ls;    // (n = columns of the command)
+  uint32_t* codes;                   // R / M: running-max codes, DIR: direction codes; strip q at q * strip_words
+  uint64_t strip_words;
+  int32_t* br;
+  int32_t* bnd[LR_TEAM_W + 1];
+  long long key[LR_TEAM_W];          // M: best join key of a wavefront's strips
+  int hl, hpad;                      // R: final V' of the last strip; M: final V' of M row m
+};
+
+__device__ __forceinline__ void lr_team_strips(LrTeamCtl& C, int wv, int lane) {
+  constexpr int W = LR_TEAM_W;
+  const int cmd = rfl(C.cmd), Q = rfl(C.Q), m = rfl(C.m), n = rfl(C.n), pad = rfl(C.pad);
+  const uint8_t* rowstr = C.rowstr;
+  const uint8_t* colstr = C.colstr;
+  uint32_t* codes = C.codes;
+  const uint64_t strip_words = C.strip_words;
+  long long key = (long long)0x8000000000000000ll;
+  for (int p = wv; p < Q; p += W) {
+    const int32_t* bin = (p > 0) ? C.bnd[(p - 1) % (W + 1)] : nullptr;
+    int32_t* bout = (p + 1 < Q) ? C.bnd[p % (W + 1)] : nullptr;
+    LrPipe P;
+    P.prev = (p > 0) ? &C.prog[p - 1] : nullptr;
+    P.mine = (p + 1 < Q) ? &C.prog[p] : nullptr;
+    P.prev_nblk = (n + 63 + 15) >> 4;
+    P.bail = &C.bail;
+    if (cmd == LRC_R) {
+      const int hl = lr_pass_R(rowstr, colstr, m, n, p, pad, bin, bout, codes + (size_t)p * strip_words, C.br, lane, P);
+      if (p == Q - 1 && lane == 0) C.hl = hl;
+    } else if (cmd == LRC_M) {
+      const int q = Q - 1 - p;
+      int hpad = 0;
+      const long long k = lr_pass_M(rowstr, colstr, m, n, q, pad, bin, bout, codes + (size_t)q * strip_words, C.br, rfl(C.pad_ls), lane, hpad, P);
+      key = k > key ? k : key;
+      if (q == 0 && lane == 0) C.hpad = hpad;
+    } else {
+      lr_pass_dir(rowstr, colstr, m, p, rfl(C.rmax), n, bin, bout, codes + (size_t)p * strip_words, lane, P);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DH_SYNC();
+  }
+  if (cmd == LRC_M && lane == 0) C.key[wv] = key;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  DH_SYNC();
+}
+
+// main wavefront: hand the command in C to the helpers, run the own share of its strips, wait for theirs
+__device__ __forceinline__ void lr_team_run(LrTeamCtl& C, int cmd, int lane) {
+  if (lane < LR_QMAX + 2) C.prog[lane] = 0;
+  if (lane < LR_TEAM_W) C.key[lane] = (long long)0x8000000000000000ll;
+  if (lane == 0) { C.cmd = cmd; C.done = 0; }
+  DH_SYNC();
+  if (lane == 0) *(volatile int*)&C.seq = C.seq + 1;
+  lr_team_strips(C, 0, lane);
+  volatile int* dn = &C.done;
+  if (*dn < LR_TEAM_W - 1) {
+    const unsigned long long t0 = wall_clock64();
+    while (*dn < LR_TEAM_W - 1) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > LR_TEAM_PATIENCE) { *(volatile int*)&C.bail = 1; break; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// the other wavefronts of a team: strips on command until main says LRC_EXIT
+__device__ __forceinline__ void lr_team_helper(LrTeamCtl& C, int wv, int lane) {
+  int seen = 0;
+  for (;;) {
+    volatile int* sq = &C.seq;
+    {   // (main always ends with LRC_EXIT; it waits for lr_kernel, which does not wait for anybody -- the limit is for a dead main only)
+      const unsigned long long t0 = wall_clock64();
+      while (*sq == seen) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200ull * LR_TEAM_PATIENCE) return;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    seen = rfl(*sq);
+    if (rfl(C.cmd) == LRC_EXIT) return;
+    lr_team_strips(C, wv, lane);
+    if (lane == 0) __hip_atomic_fetch_add(&C.done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
 // direction codes of rows 0..rmax x columns 1..ncols (all strips), then the traceback
 __device__ __forceinline__ int lr_dir_and_trace(const uint8_t* rowstr, const uint8_t* colstr, int m, int rmax, int ncols,
                                                 uint32_t* dirs, uint64_t strip_words, int32_t* bnd0, int32_t* bnd1,
-                                                uint8_t* tr, int lane, int& tailV, int& tailH) {
+                                                uint8_t* tr, int lane, int& tailV, int& tailH, LrTeamCtl* C = nullptr) {
   const int Q = rmax / LRS + 1;
-  for (int q = 0; q < Q; ++q) {
-    const int32_t* bin = (q > 0) ? ((q & 1) ? bnd0 : bnd1) : nullptr;
-    int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bnd1 : bnd0) : nullptr;
-    lr_pass_dir(rowstr, colstr, m, q, rmax, ncols, bin, bout, dirs + (size_t)q * strip_words, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  if (C && Q > 1) {   // the strips on the team
+    if (lane == 0) {
+      C->rowstr = rowstr; C->colstr = colstr; C->m = m; C->n = ncols; C->Q = Q; C->pad = 0; C->rmax = rmax; C->pad_ls = 0;
+      C->codes = dirs; C->strip_words = strip_words;
+    }
+    lr_team_run(*C, LRC_DIR, lane);
+  } else {
+    for (int q = 0; q < Q; ++q) {
+      const int32_t* bin = (q > 0) ? ((q & 1) ? bnd0 : bnd1) : nullptr;
+      int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bnd1 : bnd0) : nullptr;
+      lr_pass_dir(rowstr, colstr, m, q, rmax, ncols, bin, bout, dirs + (size_t)q * strip_words, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DH_SYNC();
+    }
   }
   const int nops = lr_traceback(dirs, strip_words, rmax, ncols, tr, lane, tailV, tailH);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  DH_SYNC();
   return nops;
 }
 
 // ---- one long-read junction per wavefront ------------------------------------------------
-__device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane) {
+// TEAM false: lr_kernel (one wavefront; with R.team_state set, a junction the sparse passes give up on goes to the teams' list);
+// TEAM true: the main wavefront of a team of lr_dense_team_kernel (no sparse attempt, the strips through C)
+template <bool TEAM = false>
+__device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, int j, LrLds& LL, uint8_t* ws, int lane, LrTeamCtl* C = nullptr) {
   PostRef L{LL.u.post.mV, LL.u.post.mR, LL.u.post.mE, LL.u.post.cumV, LL.u.post.cumR};
   int maskw = LR_MASKW_LDS;
   auto pick_masks = [&](int m_, int n_) {   // (call once m and n are known, before the masks are built)
@@ -567,7 +736,7 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     *X.out = Rr;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  DH_SYNC();
   go = rfl((int)go) != 0;
 #ifdef DH_LR_TIMING
   const unsigned long long tq0 = wall_clock64();
@@ -575,11 +744,11 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
   int err_est = -1;   // consensus errors estimated from the orientation test (unknown without it)
   if (go && R.realign && m > 0 && n > 0) {
     myers_lut_init(ML.lut, lane);   // (the LDS is shared with the later phases of the previous junction)
-    __syncthreads();
+    DH_SYNC();
     // split.h:564-572: keep the orientation with the smaller NW edit distance to the window
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    DH_SYNC();
     // (bit-vector distance, myers_kernel.hpp; the plain strip recurrence lr_nw_distance gives the same numbers)
     // (bit-vector distance, myers_kernel.hpp; pattern = the shorter string, the distance is symmetric; beyond the rows
     //  of one pass the pattern is cut into strips whose boundary deltas park in the boundary-row arrays)
@@ -621,14 +790,14 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
         if (own_cons) X.ob[i] = ch;   // (a trimmed small-inversion consensus is restored by the caller: assemble.h:850-853)
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      DH_SYNC();
     }
   }
   if (go) {
     for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
     for (int i = lane; i < n; i += WAVE) S.rref[i] = rc_at(S.ref, n, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    DH_SYNC();
   }
   X.go = go;
   X.uniformize();
@@ -641,7 +810,7 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
   // ---- longNeedle without the dense matrices (sparse_needle.hpp) when the letters are clean and the deficit budget suffices
   bool sparse_done = false;
   int spLtot = 0, spPosC = 0;
-  if (X.go && R.sparse_bytes > 0 && m >= 1 && n >= 1) {
+  if (!TEAM && X.go && R.sparse_bytes > 0 && m >= 1 && n >= 1) {
     int dirty = 0;
     for (int i = lane; i < m; i += WAVE) dirty |= comp_acgtn(S.cons[i]) ? 0 : 1;   // (case matters: the forward pass compares raw bytes)
     for (int i = lane; i < n; i += WAVE) dirty |= comp_acgtn(S.ref[i]) ? 0 : 1;
@@ -668,9 +837,9 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
       W.frR = W.frF + levels * W.ndp;
       W.cF = reinterpret_cast<int32_t*>(W.frR + levels * W.ndp);
       W.cR = W.cF + levels * (m + 1);
-      __syncthreads();
+      DH_SYNC();
       const SparseRes sr = sparse_long_needle<SpTile, false>(S.cons, S.rcons, S.ref, S.rref, m, n, W, LL.u.tile, LL.reachF, LL.reachR, 8, lane);
-      __syncthreads();
+      DH_SYNC();
 #ifdef DH_LR_TIMING
       tq2 = wall_clock64();
       if (sr.resolved && sr.found) {   // sparse phases, units of 50 us: levels | tables | join + refRight | traces
@@ -735,20 +904,60 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     return;
   }
 
+  // The dense strips of this junction on a team (lr_dense_team_kernel)?  The junction then runs through the rest of this function
+  // with go = false -- a record that says "not refined", as for any junction without a window -- and its index is put on the
+  // teams' list at the very end: whatever this wavefront writes is written before the team starts and is written again there.
+  int defer_slot = -1;
+  if (!TEAM && R.team_state != nullptr && X.go) {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&R.team_state[LRT_COUNT], 1);
+    slot = rfl(slot);
+    if (slot < R.team_cap) {   // (a full list: this wavefront sweeps the strips itself, as without teams)
+      defer_slot = slot;
+      X.go = false;
+      X.uniformize();
+    }
+  }
   // ---- longNeedle: R strips, then M strips in reverse order
   const int Q = (m + 1 + LRS - 1) / LRS;
   const int pad = Q * LRS - (m + 1);
   int unsplit = 0, revmn = 0;
   long long key = (long long)0x8000000000000000ll;
-  if (X.go) {
+#ifdef DH_LR_TIMING
+  const unsigned long long td0 = wall_clock64();
+  unsigned long long td1 = td0, td2 = td0, td3 = td0;
+#endif
+  if (TEAM) LRT_MARK(2, X.go);
+  if (TEAM && X.go) {
+    if (lane == 0) {
+      C->rowstr = S.rcons; C->colstr = S.rref; C->m = m; C->n = n; C->Q = Q; C->pad = pad; C->rmax = 0; C->pad_ls = pad;
+      C->codes = stack; C->strip_words = R.strip_words; C->br = brbuf;
+    }
+    lr_team_run(*C, LRC_R, lane);
+    if (TEAM) LRT_MARK(3, Q);
+    revmn = rfl(C->hl) - m;
+    DH_SYNC();
+    if (lane == 0) { C->rowstr = S.cons; C->colstr = S.ref; }
+    lr_team_run(*C, LRC_M, lane);
+    for (int w = 0; w < LR_TEAM_W; ++w) {
+      const long long k = C->key[w];
+      key = k > key ? k : key;
+    }
+    unsplit = (rfl(C->hpad) >> LR_CSHIFT) - m;
+    DH_SYNC();
+    if (TEAM) LRT_MARK(4, unsplit);
+  } else if (X.go) {
     for (int q = 0; q < Q; ++q) {
       const int32_t* bin = (q > 0) ? ((q & 1) ? bnd0 : bnd1) : nullptr;
       int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bnd1 : bnd0) : nullptr;
       const int hl = lr_pass_R(S.rcons, S.rref, m, n, q, pad, bin, bout, stack + (size_t)q * R.strip_words, brbuf, lane);
       if (q == Q - 1) revmn = hl - m;   // rev row m is the last slot of the last strip
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      DH_SYNC();
     }
+#ifdef DH_LR_TIMING
+    td1 = wall_clock64();
+#endif
     for (int p = 0; p < Q; ++p) {
       const int q = Q - 1 - p;
       const int32_t* bin = (p > 0) ? ((p & 1) ? bnd0 : bnd1) : nullptr;
@@ -759,9 +968,12 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
       key = k > key ? k : key;
       if (q == 0) unsplit = (hpad >> LR_CSHIFT) - m;   // M row m = rev row 0 = local slot pad of strip 0
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      DH_SYNC();
     }
   }
+#ifdef DH_LR_TIMING
+  td2 = wall_clock64();
+#endif
   // ---- winner, refRight (needle.h:83-123,152)
   if (X.go) {
     const int khi = rfl((int)(key >> 32)), klo = rfl((int)(key & 0xffffffffll));
@@ -827,6 +1039,7 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     X.go = found;
     X.uniformize();
   }
+  if (TEAM) LRT_MARK(5, X.go);
   // ---- tracebacks on recomputed direction codes, column masks, split detection
   go = X.go;
   int Ltot = 0, posC = 0;
@@ -834,10 +1047,10 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     const int consLeft = X.consLeft, refLeft = X.refLeft, consRight = X.consRight, refRight = X.refRight;
     int nF = 0, tvF = 0, thF = 0, nR = 0, tvR = 0, thR = 0;
     if (consLeft > 0 && refLeft > 0)
-      nF = lr_dir_and_trace(S.cons, S.ref, m, consLeft, refLeft, stack, R.strip_words, bnd0, bnd1, trF, lane, tvF, thF);
+      nF = lr_dir_and_trace(S.cons, S.ref, m, consLeft, refLeft, stack, R.strip_words, bnd0, bnd1, trF, lane, tvF, thF, TEAM ? C : nullptr);
     else { tvF = consLeft; thF = (consLeft > 0) ? 0 : refLeft; }
     if (consRight > 0 && refRight > 0)
-      nR = lr_dir_and_trace(S.rcons, S.rref, m, consRight, refRight, stack, R.strip_words, bnd0, bnd1, trR, lane, tvR, thR);
+      nR = lr_dir_and_trace(S.rcons, S.rref, m, consRight, refRight, stack, R.strip_words, bnd0, bnd1, trR, lane, tvR, thR, TEAM ? C : nullptr);
     else { tvR = consRight; thR = (consRight > 0) ? 0 : refRight; }
     const int gapref = (n - refRight) - refLeft;
     const long long total = (long long)thF + tvF + nF + gapref + nR + tvR + thR;
@@ -850,12 +1063,29 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
       masks_finish(A, X, S, L, Ltot, posC, lane);
     }
   }
+#ifdef DH_LR_TIMING
+  td3 = wall_clock64();
+#endif
   split_detect(A, X, S, L, go, Ltot, posC, lane);
+  if (!TEAM && defer_slot >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __threadfence();
+    if (lane == 0) atomicExch(&R.team_state[LRT_LIST + defer_slot], j);
+  }
+#ifdef DH_LR_TIMING
+  if (lane == 0) {   // dense path, units of 200 us: set-up + sparse attempt | R strips | M strips | winner + direction passes + traces + masks
+    auto u8 = [](unsigned long long a, unsigned long long b) { return (int)min(255ull, (b - a) / 20000ull); };
+    X.out->reserved = u8(tq0, td0) | (u8(td0, td1) << 8) | (u8(td1, td2) << 16) | (u8(td2, td3) << 24);
+  }
+#endif
 }
 
 __global__ __launch_bounds__(WAVE) void lr_kernel(SplitArgs A, LrArgs R) {
   __shared__ LrLds L;
   const int lane = threadIdx.x;
+#ifdef DH_LR_TEAM_DEBUG
+  if (R.team_state && blockIdx.x == 0 && lane == 0) R.team_state[LRT_LIST + R.team_cap + 8 * 4096] = (int)((wall_clock64() / 1000ull) & 0x7fffffffull);
+#endif
   uint8_t* ws = R.ws + (size_t)blockIdx.x * R.ws_stride;
   // junction latencies differ by an order of magnitude (levels of the sparse passes, dense fallback): the wavefronts
   // pull from the host-sorted list (largest consensus x window first) instead of striding over it
@@ -865,9 +1095,91 @@ __global__ __launch_bounds__(WAVE) void lr_kernel(SplitArgs A, LrArgs R) {
     w = rfl(w);
     if (w >= A.n_work) break;
     const int j = A.work_list[w];
+#if defined(DH_LR_TIMING) && DH_LR_TIMING == 2   // when a junction starts and ends, units of 50 us of the 100 MHz wall clock (low 16 bits each)
+    const unsigned long long tj0 = wall_clock64();
+#endif
     if (j >= 0) process_lr(A, R, j, L, ws, lane);
-    __syncthreads();
+#if defined(DH_LR_TIMING) && DH_LR_TIMING == 2
+    if (j >= 0 && lane == 0) A.res[j].reserved = (int)((((tj0 / 5000ull) & 0xffffull) << 16) | ((wall_clock64() / 5000ull) & 0xffffull));
+#endif
+    DH_SYNC();
   }
+}
+
+// The dense strips of the junctions lr_kernel listed, one junction per team of LR_TEAM_W wavefronts.  Launched on a second
+// stream right after lr_kernel so that the teams work while lr_kernel is still busy with the sparse passes of the other
+// junctions; a team that finds the list empty waits until lr_kernel has been through every junction (its work counter says so).
+// If the two streams happen to run one after the other the teams simply find the complete list.
+__global__ __launch_bounds__(WAVE * LR_TEAM_W) void lr_dense_team_kernel(SplitArgs A, LrArgs R) {
+  __shared__ LrLds L;
+  __shared__ LrTeamCtl C;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = rfl((int)(threadIdx.x / WAVE));
+  if (threadIdx.x == 0) { C.seq = 0; C.cmd = LRC_EXIT; C.done = 0; C.bail = 0; }
+  __syncthreads();   // (the only real barrier of this kernel)
+  // the teams are the critical path of a batch (a few junctions, ~6 M instructions each) and share their SIMDs with lr_kernel's
+  // wavefronts: they issue first
+  __builtin_amdgcn_s_setprio(3);
+  LRT_MARK(0, 0);
+  if (wv != 0) {
+    lr_team_helper(C, wv, lane);
+    return;
+  }
+  uint8_t* ws = R.ws + (size_t)(R.team_first_ws + (int)blockIdx.x) * R.ws_stride;
+  if (lane == 0) {
+    const uint64_t row = ((uint64_t)R.ncap + 128) * 4;
+    C.bnd[0] = reinterpret_cast<int32_t*>(ws + R.off_bnd0);
+    C.bnd[1] = reinterpret_cast<int32_t*>(ws + R.off_bnd1);
+    for (int k = 2; k <= LR_TEAM_W; ++k) C.bnd[k] = reinterpret_cast<int32_t*>(ws + R.off_bndx + (uint64_t)(k - 2) * row);
+  }
+  DH_SYNC();
+  int32_t* ts = R.team_state;
+  const int n_work = A.n_work;
+  for (;;) {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(&ts[LRT_TAKEN], 1);
+    k = rfl(k);
+    bool have = false;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+      if (k >= R.team_cap) break;   // (beyond the list: lr_kernel keeps those junctions)
+      if (__hip_atomic_load(&ts[LRT_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) { have = true; break; }
+      const int dn = __hip_atomic_load(A.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      if (dn >= n_work + R.lr_grid) {   // every wavefront of lr_kernel has made its last fetch: the count is final
+        have = __hip_atomic_load(&ts[LRT_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+      if (wall_clock64() - t0 > 150ull * LR_TEAM_PATIENCE) {   // (ten minutes: lr_kernel is gone)
+        if (lane == 0) atomicExch(&ts[LRT_ERROR], 1);
+        break;
+      }
+    }
+    if (!have) break;
+    int j = -1;
+    while ((j = __hip_atomic_load(&ts[LRT_LIST + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {   // (written right after the count)
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 160ull * LR_TEAM_PATIENCE) break;
+    }
+    __threadfence();
+    j = rfl(j);
+    if (j < 0) {
+      if (lane == 0) atomicExch(&ts[LRT_ERROR], 1);
+      break;
+    }
+    LRT_MARK(1, j);
+    process_lr<true>(A, R, j, L, ws, lane, &C);
+    DH_SYNC();
+    LRT_MARK(9, j);
+    if (rfl(*(volatile int*)&C.bail) && lane == 0) {   // a wait inside the team ran out: the junction's record is not to be trusted
+      A.res[j].status = DELLYHIP_E_RUNTIME;
+      atomicExch(&ts[LRT_ERROR], 1);
+    }
+  }
+  if (lane == 0) { C.cmd = LRC_EXIT; }
+  DH_SYNC();
+  if (lane == 0) *(volatile int*)&C.seq = C.seq + 1;
 }
 
 }  // namespace dh

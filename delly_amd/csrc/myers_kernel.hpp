@@ -244,7 +244,7 @@ __device__ __forceinline__ int myers_nw_big(const uint8_t* pattern, int pn, cons
     int8_t* hout = (q + 1 < S) ? ((q & 1) ? hb1 : hb0) : nullptr;
     d = myers_nw_distance<MYERS_NW>(pattern + base, min(MYERS_ROWS, pn - base), text, tn, lane, base, hin, hout);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    DH_SYNC();
   }
   return d;
 }
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
   __shared__ MyersLds<MYERS_NW> L;
   const int lane = threadIdx.x;
   myers_lut_init(L.lut, lane);
-  __syncthreads();
+  DH_SYNC();
   struct Item { int j, a, bb, la, lb; uint64_t oa, ob; };
   auto describe = [&](int item) -> Item {
     // junction of this item: binary search in pair_first
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(WAVE) void nw_jobs_kernel(NwArgs A) {
   __shared__ MyersLds<MYERS_NW> L;   // (the one- and two-word variants use a prefix of it)
   const int lane = threadIdx.x;
   myers_lut_init(L.lut, lane);
-  __syncthreads();
+  DH_SYNC();
   // (the loop condition must be a scalar compare: hipcc's exec-mask structurisation of a `break` it cannot prove
   //  uniform produced a non-terminating loop here, see split_main.hpp JCtx)
   const int n_items = __builtin_amdgcn_readfirstlane((int)(uint32_t)A.n_jobs);

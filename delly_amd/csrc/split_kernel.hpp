@@ -32,6 +32,13 @@
 
 #include "../../include/dellyhip.h"
 
+// DH_SYNC(): the hand-over between the lanes of ONE wavefront (LDS / workspace written by some lanes, read by others).  The
+// kernels built from these headers run one wavefront per workgroup, where __syncthreads() is exactly this pair of fences (the
+// compiler drops the s_barrier of a single-wave workgroup).  Code that can also run inside a TEAM of wavefronts per workgroup
+// (lr_dense_team_kernel: the main wavefront runs the junction, the others only the strips it hands them) must not contain a real
+// barrier, so it says DH_SYNC() and the team meets through LDS flags.
+#define DH_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
 namespace dh {
 
 // LDS reads that are not naturally aligned are served lane by lane on gfx950 (tools/lds_rate.hip, profiles/r04/lds_rate.txt:

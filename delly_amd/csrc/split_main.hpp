@@ -293,7 +293,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
           else {
             fill_segment(S.ref + o, sg, lane);
             if (FAST) {    // (a reverse-complemented piece keeps letters outside A, C, G, T, N: check what was written)
-              __syncthreads();
+              DH_SYNC();
               for (int i = lane; i < sg.len; i += WAVE) dirty |= comp_acgtn(S.ref[o + i]) ? 0 : 1;
             }
           }
@@ -327,7 +327,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     v = (lane == at(offsetof(dellyhip_result, ref_len))) ? n : v;
     if (lane < (int)(sizeof(dellyhip_result) / 4)) reinterpret_cast<int*>(X.out)[lane] = v;
   }
-  __syncthreads();
+  DH_SYNC();
   if constexpr (STR::has_rc) {
     if (go && FAST) {
       if (!X.dirty) {
@@ -339,7 +339,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
       for (int i = lane; i < m; i += WAVE) S.rcons[i] = rc_at(S.cons, m, i);
       for (int i = lane; i < n; i += WAVE) S.rref[i] = rc_at(S.ref, n, i);
     }
-    __syncthreads();
+    DH_SYNC();
   }
   X.uniformize();
 }
@@ -448,7 +448,7 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
                                              int lane) {
   const int m = X.m, n = X.n;
   uint8_t* ob = X.ob;
-  __syncthreads();
+  DH_SYNC();
   if (lane == 0) {
     int cv = 0, cr = 0;
     int nw = (Ltot + 63) >> 6;
@@ -461,7 +461,7 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
     L.cumV[nw] = cv;
     L.cumR[nw] = cr;
   }
-  __syncthreads();
+  DH_SYNC();
   // characters of every column -> equality mask (+ optional alignment output)
   uint8_t* aln = ob + A.out_cons_cap + A.out_allele_cap;
   for (int base = 0; base < Ltot; base += 64) {
@@ -489,7 +489,7 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
       aln[Ltot + jcol] = c1;
     }
   }
-  __syncthreads();
+  DH_SYNC();
   if (A.want_alignment && lane == 0) {
     X.out->aln_off = X.ob_off + A.out_cons_cap + A.out_allele_cap;
     X.out->aln_len = Ltot;
@@ -707,7 +707,7 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
       }
     }
   }
-  __syncthreads();
+  DH_SYNC();
 }
 
 // longNeedle's glued alignment (needle.h:196-219) as column masks; column order:
@@ -722,7 +722,7 @@ __device__ __forceinline__ int needle_masks(PL& L, const uint8_t* trF, int nF, i
     L.mR[w] = 0;
     L.mE[w] = 0;
   }
-  __syncthreads();
+  DH_SYNC();
   int pos = 0;
   for (int k = 0; k < thF; k += 64) { mask_append(L, pos, min(64, thF - k), 0ull, ~0ull, lane); pos += min(64, thF - k); }
   for (int k = 0; k < tvF; k += 64) { mask_append(L, pos, min(64, tvF - k), ~0ull, 0ull, lane); pos += min(64, tvF - k); }
@@ -774,7 +774,7 @@ __device__ __noinline__ void junction_post(const SplitArgs& A, JCtx& X, StrLds& 
       thR = (consRight > 0) ? 0 : refRight;
     }
   }
-  __syncthreads();
+  DH_SYNC();
 
   // alignment as column masks
   int Ltot = 0, posC = 0;
@@ -847,9 +847,9 @@ __global__ __launch_bounds__(WAVE) void split_align_kernel(SplitArgs A0) {
     if (j < 0) continue;
     if (A.pair_mode) {  // launched behind the packed kernel: only junctions it deferred
       if (A.res[j].status != DH_DEFERRED) continue;
-      __syncthreads();
+      DH_SYNC();
       if (lane == 0) A.res[j].status = 0;
-      __syncthreads();
+      DH_SYNC();
     }
     process_junction<K>(A, j, L, scratch, lane);
     if (A.pair_mode && lane == 0) A.res[j].reserved = 1;  // post-processing already done

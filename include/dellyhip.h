@@ -273,6 +273,11 @@ int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms
  * kernel is off or the run had no short-read junctions.  The sparse kernel's cost grows with a junction's deficit, the dense kernels' does
  * not (like the reference, src/needle.h:64-115): this is the number that says which regime a batch ran in. */
 int dellyhip_batch_sparse_left(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t* left);
+/* Long-read batches: the dense strip fallback of the strip kernel runs on teams of wavefronts beside it.
+ * out[0] = teams launched for this batch (0: none -- DELLYHIP_LR_TEAMS=0, or no long-read junction), out[1] = junctions of
+ * the last run the teams swept, out[2] = claims the teams made on the list (>= out[0]: every team ends with one that finds nothing), out[3] = 1 if a team gave up waiting
+ * (those junctions carry status DELLYHIP_E_RUNTIME).  Synchronises the batch. */
+int dellyhip_batch_lr_team_stats(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t out[4]);
 
 /* ---- multi-GPU: junction sharding + gather of the results to one rank ------------------------ */
 

@@ -102,3 +102,60 @@ def test_lr_insertions_vs_reference(lr_ctx, reference):
     gr, gb = lr_ctx.refine(b, want_alignment=True)
     rr, rb = reference.refine_batch(b, params=abi.params_lr(realign=True))
     compare(gr, gb, rr, rb, label="hip-vs-reference LR INS")
+
+
+def _unalignable(b, every=1, seed=5):
+    """the batch with the consensus of every `every`-th junction replaced by random letters of the same length: the sparse
+    longNeedle gives up on those after its first rounds and the dense strips run"""
+    rng = np.random.default_rng(seed)
+    blob = b.seq_blob.copy()
+    for k in range(0, b.n, every):
+        o = int(b.junctions["seq_first"][k])
+        lo, hi = int(b.seq_off[o]), int(b.seq_off[o + 1])
+        blob[lo:hi] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, hi - lo)]
+    return synth.Batch(b.chroms, b.junctions, blob, b.seq_off, b.with_msa, b.truth)
+
+
+def _refine_with_teams(b, teams, monkeypatch, serial=False):
+    monkeypatch.setenv("DELLYHIP_LR_TEAMS", str(teams))
+    if serial:
+        monkeypatch.setenv("DELLYHIP_LR_TEAMS_SERIAL", "1")
+    else:
+        monkeypatch.delenv("DELLYHIP_LR_TEAMS_SERIAL", raising=False)
+    ctx = refine.Context(params=abi.params_lr(realign=True))
+    ctx.set_chromosomes(b.chroms)
+    rb = ctx.upload(b)
+    rb.run(); rb.sync()
+    rb.run(); rb.sync()          # (the second run finds the counters and the list of the first)
+    stats = rb.lr_team_stats()
+    res0, blob0 = rb.fetch()
+    rb.free()
+    res, blob = ctx.refine(b, want_alignment=True)   # (the one-shot entry point: with the alignment rows)
+    compare(res0, blob0, res, blob, fields=[f for f in CORE + INTERNAL + INTERNAL_FOUND if f != "aln_len"], blobs=("cons", "allele"), label="resident vs one-shot")
+    ctx.close()
+    return res, blob, stats
+
+
+def test_dense_strips_on_teams_vs_reference(monkeypatch, reference):
+    """lr_dense_team_kernel: junctions whose consensus does not align go to teams of four wavefronts that sweep
+    the strips of the dense longNeedle pipelined.  Same records as the reference, and the teams really took them."""
+    b = _unalignable(synth.make_batch(12, mode="lr", sub_rate=0.01, first=300), every=2)
+    gr, gb, stats = _refine_with_teams(b, 64, monkeypatch)
+    assert stats[0] == 12 and stats[1] >= 6 and stats[3] == 0, stats
+    rr, rb = reference.refine_batch(b, params=abi.params_lr(realign=True))
+    compare(gr, gb, rr, rb, label="teams-vs-reference")
+    assert int(gr["ok"].sum()) <= 6
+
+
+def test_teams_equal_single_wavefront_strips(monkeypatch):
+    """the same batch with the teams beside lr_kernel, after it on one stream, with fewer teams than dense junctions (the list
+    is taken in turns; beyond two junctions per team lr_kernel sweeps the strips itself) and without teams: bit-identical"""
+    b = _unalignable(synth.make_batch(96, mode="lr", sub_rate=0.01, first=700), every=3)
+    base, base_blob, s0 = _refine_with_teams(b, 0, monkeypatch)
+    assert s0 == (0, 0, 0, 0)
+    for teams, serial in ((64, False), (64, True), (3, False), (1, False)):
+        res, blob, stats = _refine_with_teams(b, teams, monkeypatch, serial=serial)
+        label = "teams %d serial %s" % (teams, serial)
+        assert stats[0] == min(teams, b.n) and stats[3] == 0, (label, stats)
+        assert stats[1] == min(2 * stats[0], stats[1]) and stats[1] >= min(2 * teams, 30), (label, stats)
+        compare(res, blob, base, base_blob, fields=CORE + INTERNAL + INTERNAL_FOUND, label=label)
