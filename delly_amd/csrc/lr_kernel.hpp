@@ -1145,12 +1145,14 @@ __global__ __launch_bounds__(WAVE * LR_TEAM_W) void lr_dense_team_kernel(SplitAr
       if (k >= R.team_cap) break;   // (beyond the list: lr_kernel keeps those junctions)
       if (__hip_atomic_load(&ts[LRT_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) { have = true; break; }
       const int dn = __hip_atomic_load(A.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
       if (dn >= n_work + R.lr_grid) {   // every wavefront of lr_kernel has made its last fetch: the count is final
+        __threadfence();
         have = __hip_atomic_load(&ts[LRT_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k;
         break;
       }
-      __builtin_amdgcn_s_sleep(32);
+      // (no fence while polling: a device-scope fence writes the L2 back and invalidates it, and 64 idle teams doing that every
+      //  microsecond cost lr_kernel's table loads a third of their speed)
+      __builtin_amdgcn_s_sleep(127);
       if (wall_clock64() - t0 > 150ull * LR_TEAM_PATIENCE) {   // (ten minutes: lr_kernel is gone)
         if (lane == 0) atomicExch(&ts[LRT_ERROR], 1);
         break;
