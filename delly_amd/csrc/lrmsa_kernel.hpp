@@ -787,8 +787,10 @@ inline uint64_t lm_dirs_words(int tcap, int qcap) {
 __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int mode, int32_t* bnd,
                                           int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
                                           uint8_t* ops, int ops_cap, int lane) {
-  // explicit stack of rectangles (t0, tlen, q0, qlen), processed left to right
-  int st[LM_STACK][4];
+  // explicit stack of rectangles (t0, tlen, q0, qlen), processed left to right.  In LDS: indexed by the stack pointer, a local
+  // array would live in scratch memory (384 B per lane in every kernel that aligns long strings; one wavefront per workgroup
+  // in all of them, and one path at a time)
+  __shared__ int st[LM_STACK][4];
   int sp = 0;
   st[sp][0] = 0; st[sp][1] = tn; st[sp][2] = 0; st[sp][3] = qn;
   ++sp;
