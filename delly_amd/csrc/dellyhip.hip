@@ -620,7 +620,7 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
       HIPCHK(hipMemsetAsync(lr.team_state, 0, dh::LRT_LIST * sizeof(int32_t), s));
       HIPCHK(hipMemsetAsync(lr.team_state + dh::LRT_LIST, 0xff, (size_t)lr.team_cap * sizeof(int32_t), s));
 #ifdef DH_LR_TEAM_DEBUG
-      HIPCHK(hipMemsetAsync(lr.team_state + dh::LRT_LIST + lr.team_cap, 0, (8 * 4096 + 8) * sizeof(int32_t), s));
+      HIPCHK(hipMemsetAsync(lr.team_state + dh::LRT_LIST + lr.team_cap, 0, (size_t)dh::LRT_DBG_INTS * sizeof(int32_t), s));
 #endif
       HIPCHK(hipEventRecord(b->lr_fork, s));
     } else {
@@ -747,7 +747,7 @@ int setup_lr_workspace(dellyhip_ctx* c, dellyhip_batch* b, int lr_m, int lr_n, i
     const int teams = (int)std::min<uint64_t>((uint64_t)std::min(lr_cnt, c->lr_teams), room > (uint64_t)b->lr_blocks ? room - b->lr_blocks : 0);
     if (teams > 0) {
       R.team_cap = 2 * teams;
-      int rc = b->lr_team_state.reserve((size_t)dh::LRT_LIST + R.team_cap + 8 * 4096 + 8);   // (+ the marks of debug builds)
+      int rc = b->lr_team_state.reserve((size_t)dh::LRT_LIST + R.team_cap + dh::LRT_DBG_INTS);   // (+ the marks of debug builds)
       if (rc) return rc;
       b->lr_teams = teams;
       R.team_state = b->lr_team_state.p;

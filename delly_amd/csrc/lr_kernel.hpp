@@ -49,8 +49,8 @@ struct LrArgs {
   int32_t sparse_cost;    // predicted deficit beyond which the dense strips are taken (SparseWs::pred_cap)
   // dense strips on a TEAM of wavefronts (lr_dense_team_kernel, running beside lr_kernel on a second stream): lr_kernel hands the
   // junctions its sparse passes give up on to the list in team_state instead of sweeping the strips on its one wavefront
-  int32_t* team_state;    // nullptr: no team kernel.  [LRT_COUNT] junctions listed, [LRT_TAKEN] claimed by teams, [LRT_IN]
-                          // (unused), [LRT_ERROR]; the list (junction indices, -1 = not yet written) from [LRT_LIST]
+  int32_t* team_state;    // nullptr: no team kernel.  [LRT_COUNT] junctions listed, [LRT_TAKEN] claimed by teams,
+                          // [LRT_ERROR]; the list (junction indices, -1 = not yet written) from [LRT_LIST]
   uint64_t off_bndx;      // LR_TEAM_W - 1 more boundary rows behind bnd0 / bnd1 (a team keeps LR_TEAM_W + 1 strips' rows alive)
   int32_t team_first_ws;  // workspace index of team 0 (the teams' workspaces follow lr_kernel's)
   int32_t team_cap;       // entries of the list; a junction that finds it full stays on lr_kernel's wavefront
@@ -58,7 +58,12 @@ struct LrArgs {
                           // reads n_work + lr_grid exactly when lr_kernel is through with every junction
 };
 constexpr int LR_TEAM_W = 4;   // wavefronts of a team
-enum { LRT_COUNT = 0, LRT_TAKEN = 1, LRT_IN = 2, LRT_ERROR = 3, LRT_LIST = 4 };
+enum { LRT_COUNT = 0, LRT_TAKEN = 1, LRT_SPARE = 2, LRT_ERROR = 3, LRT_LIST = 4 };
+#ifdef DH_LR_TEAM_DEBUG
+constexpr int LRT_DBG_INTS = 8 * 4096 + 8;   // time-line marks behind the list (8 ints per team) + lr_kernel's start
+#else
+constexpr int LRT_DBG_INTS = 0;
+#endif
 
 struct StrPtr {           // the four strings of a junction (workspace)
   uint8_t* cons;
