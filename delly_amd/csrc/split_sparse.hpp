@@ -75,7 +75,11 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
   SparseWs W;
   W.ndp = (n + m + 2 + 63) & ~63;
   W.smax = SPS_SMAX;
+#ifdef SPS_PRED_CAP
+  W.pred_cap = SPS_PRED_CAP;   // (tuning builds: give up when the deficit predicted after a round exceeds this)
+#else
   W.pred_cap = 1 << 20;     // (never give up early: an unresolved junction costs a whole dense wavefront of ~1 ms)
+#endif
   W.runs_cap = SPS_LIST;
   uint8_t* sp = reinterpret_cast<uint8_t*>(scratch);
   W.runsF = reinterpret_cast<int32_t*>(sp);
