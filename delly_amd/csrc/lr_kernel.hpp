@@ -57,7 +57,10 @@ struct LrArgs {
   int32_t lr_grid;        // wavefronts of lr_kernel: every one of them ends with ONE fetch beyond the work list, so the work counter
                           // reads n_work + lr_grid exactly when lr_kernel is through with every junction
 };
-constexpr int LR_TEAM_W = 4;   // wavefronts of a team
+#ifndef DH_LR_TEAM_W
+#define DH_LR_TEAM_W 4
+#endif
+constexpr int LR_TEAM_W = DH_LR_TEAM_W;   // wavefronts of a team (2 / 6 / 8 measured: DESIGN.md 3.7)
 enum { LRT_COUNT = 0, LRT_TAKEN = 1, LRT_SPARE = 2, LRT_ERROR = 3, LRT_LIST = 4 };
 #ifdef DH_LR_TEAM_DEBUG
 constexpr int LRT_DBG_INTS = 8 * 4096 + 8;   // time-line marks behind the list (8 ints per team) + lr_kernel's start
