@@ -318,6 +318,12 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         res, _ = rb.fetch()
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
                      "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
+        if lr:   # the dense strips of junctions the sparse passes give up on run on teams of wavefronts
+            try:
+                ts = rb.lr_team_stats()
+                out[name]["lr_teams"], out[name]["lr_team_junctions"] = ts[0], ts[1]
+            except Exception:
+                pass
         rb.free()
         try:   # the same batch from host buffers through the pipelined path
             hi = host_inclusive_rate(ctx, [b], b.with_msa, seconds=0.5 if dt < 0.05 else 3 * dt, depth=5 if dt < 0.02 else 3)
