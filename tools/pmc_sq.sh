@@ -13,7 +13,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k, d in acc.items():
-    if not any(x in k for x in ("split_sparse", "split_quad", "split_post", "classify_kernel<1>", "nw_jobs", "msa_kernel", "lrmsa", "lr_kernel", "ins_kernel", "myers_pairs", "lrwfa", "wfa_pairs", "blob_")):
+    if not any(x in k for x in ("split_sparse", "split_quad", "split_post", "classify_kernel<1>", "nw_jobs", "msa_kernel", "lrmsa", "lr_kernel", "ins_kernel", "myers_pairs", "lrwfa", "wfa_pairs", "blob_", "lr_dense_team")):
         continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
     ns = sum(dur[k]) / len(dur[k])
