@@ -169,13 +169,17 @@ struct RcclLink final : Link {
 struct HostLink final : Link {
   static constexpr uint64_t MAGIC = 0x64656c6c79686c31ull;   // "dellyhl1"
   static constexpr int MAX_PARTS = 8;
+  static constexpr int MAX_RANKS = 64;
+  // The message sequence is per (sender, destination): a receiver compares msg_to[its rank] with what IT has consumed.  (One
+  // counter per sender -- round 4 -- broke as soon as two collectives had different roots: the second root found the
+  // sender's counter ahead of its own count and took the message meant for the first root for its own.)
   struct Slot {
     std::atomic<uint64_t> attached;      // 1 once the rank has mapped the segment
     std::atomic<uint64_t> round;         // all-gather rounds this rank has published
     uint64_t words[2][2];                // [parity][word]
-    std::atomic<uint64_t> msg;           // messages this rank has published in its outbox
-    std::atomic<uint64_t> ack;           // ... and how many of them the receiver has consumed
-    uint64_t gen, n_parts, dst, part[MAX_PARTS];
+    std::atomic<uint64_t> msg_to[MAX_RANKS];     // messages this rank has published for each destination
+    std::atomic<uint64_t> ack_from[MAX_RANKS];   // ... and how many of them that destination has consumed
+    uint64_t gen, n_parts, part[MAX_PARTS];      // the message in the outbox (one at a time: rewritten only after its acknowledgement)
     char pad_[64];
   };
   struct Ctl {
@@ -203,6 +207,7 @@ struct HostLink final : Link {
   uint64_t box_gen = 0;
   std::vector<Map> peer_box;     // mapped outboxes of the peers
   std::vector<uint64_t> peer_gen, seen_msg;
+  int last_dst = -1;             // destination of the message that occupies my outbox
   bool use_device = true;
   double timeout_s = 120.0;
   struct Part { void* dev; uint64_t bytes; int peer; bool is_send; };
@@ -232,29 +237,42 @@ struct HostLink final : Link {
     name = name_ ? name_ : "";
     use_device = device;
     if (name.empty() || name.size() > 96 || name.find('/') != std::string::npos) return fail(-2, "bad segment name");
+    if (world < 1 || world > MAX_RANKS || rank < 0 || rank >= world) return fail(-2, "hostlink: 1 .. 64 ranks");
     if (const char* t = getenv("DELLYHIP_LINK_TIMEOUT_S")) timeout_s = std::max(0.05, atof(t));
     ctl_bytes = sizeof(Ctl) + (size_t)(world - 1) * sizeof(Slot);
     const std::string cn = seg("ctl");
-    int fd = -1;
     if (rank == 0) {
       shm_unlink(cn.c_str());   // (a stale segment of a crashed run)
-      fd = shm_open(cn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+      const int fd = shm_open(cn.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, (off_t)ctl_bytes) != 0) { if (fd >= 0) close(fd); return fail(-3, "cannot create " + cn); }
-    } else {
-      if (!wait_for([&] { fd = shm_open(cn.c_str(), O_RDWR, 0600); if (fd < 0) return false;
-                           struct stat st; if (fstat(fd, &st) == 0 && (size_t)st.st_size >= ctl_bytes) return true;
-                           close(fd); fd = -1; return false; }))
-        return fail(-3, "rank 0 never created " + cn);
-    }
-    void* p = mmap(nullptr, ctl_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return fail(-3, "mmap of " + cn);
-    ctl = static_cast<Ctl*>(p);
-    if (rank == 0) {
+      void* p = mmap(nullptr, ctl_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) return fail(-3, "mmap of " + cn);
+      ctl = static_cast<Ctl*>(p);
       ctl->world = (uint64_t)world;
       ctl->magic.store(MAGIC, std::memory_order_release);
-    } else if (!wait_for([&] { return ctl->magic.load(std::memory_order_acquire) == MAGIC; })) {
-      return fail(-3, "control segment never initialised");
+    } else {
+      // A segment of this name may be the leftover of a crashed run that rank 0 has not replaced yet: a fresh one has this
+      // rank's slot untouched (ftruncate zero-fills), a leftover in which this rank took part has not.  Anything else is
+      // dropped and looked up again until the deadline.
+      const bool ok = wait_for([&] {
+        const int fd = shm_open(cn.c_str(), O_RDWR, 0600);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || (size_t)st.st_size < ctl_bytes) { close(fd); return false; }
+        void* p = mmap(nullptr, ctl_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return false;
+        Ctl* c = static_cast<Ctl*>(p);
+        if (c->magic.load(std::memory_order_acquire) == MAGIC && c->slot[rank].attached.load(std::memory_order_acquire) == 0 &&
+            c->slot[rank].round.load(std::memory_order_relaxed) == 0 && c->slot[0].attached.load(std::memory_order_acquire) != 2) {
+          ctl = c;
+          return true;
+        }
+        munmap(p, ctl_bytes);
+        return false;
+      });
+      if (!ok) return fail(-3, "rank 0 never created (a fresh) " + cn);
     }
     if (ctl->world != (uint64_t)world) return fail(-2, "ranks disagree about the world size");
     ctl->slot[rank].attached.store(1, std::memory_order_release);
@@ -263,9 +281,14 @@ struct HostLink final : Link {
     seen_msg.assign(world, 0);
     return 0;
   }
+  bool outbox_free() const {   // the message in my outbox (if any) has been consumed by its destination
+    if (last_dst < 0) return true;
+    const Slot& me = ctl->slot[rank];
+    return me.ack_from[last_dst].load(std::memory_order_acquire) >= me.msg_to[last_dst].load(std::memory_order_relaxed);
+  }
   ~HostLink() override {
     if (ctl && box.p)   // a receiver may still be reading the last message
-      (void)wait_for([&] { return ctl->slot[rank].ack.load(std::memory_order_acquire) >= ctl->slot[rank].msg.load(std::memory_order_relaxed); });
+      (void)wait_for([&] { return outbox_free(); });
     if (box.p) { box.drop(); shm_unlink(seg("box", rank, box_gen).c_str()); }
     for (Map& m : peer_box) m.drop();
     if (ctl) {
@@ -347,7 +370,8 @@ struct HostLink final : Link {
     if (n_send > MAX_PARTS) return fail(-2, "too many parts in one send group");
     if (n_send) {
       Slot& me = ctl->slot[rank];
-      if (!wait_for([&] { return me.ack.load(std::memory_order_acquire) >= me.msg.load(std::memory_order_relaxed); }))
+      if (dst < 0 || dst >= world) return fail(-2, "send to a rank outside the communicator");
+      if (!wait_for([&] { return outbox_free(); }))
         return fail(-3, "timed out waiting for the previous message to be consumed");
       if (int rc = ensure_box(total)) return rc;
       uint64_t at = 0, k = 0;
@@ -363,19 +387,19 @@ struct HostLink final : Link {
       }
       me.gen = box_gen;
       me.n_parts = n_send;
-      me.dst = (uint64_t)dst;
-      me.msg.store(me.msg.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+      last_dst = dst;
+      me.msg_to[dst].store(me.msg_to[dst].load(std::memory_order_relaxed) + 1, std::memory_order_release);
     }
     for (size_t i = 0; i < parts.size();) {
       if (parts[i].is_send) { ++i; continue; }
       const int q = parts[i].peer;
       Slot& sq = ctl->slot[q];
-      if (!wait_for([&] { return sq.msg.load(std::memory_order_acquire) > seen_msg[q]; })) {
+      if (q < 0 || q >= world) return fail(-2, "receive from a rank outside the communicator");
+      if (!wait_for([&] { return sq.msg_to[rank].load(std::memory_order_acquire) > seen_msg[q]; })) {
         char b[96];
         snprintf(b, sizeof b, "timed out waiting for the payload of rank %d", q);
         return fail(-3, b);
       }
-      if (sq.dst != (uint64_t)rank) return fail(-3, "a peer's message is addressed to another rank");
       if (peer_gen[q] != sq.gen || !peer_box[q].p) {
         peer_box[q].drop();
         const std::string bn = seg("box", q, sq.gen);
@@ -402,8 +426,8 @@ struct HostLink final : Link {
         const hipError_t e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(-3, std::string("HIP: ") + hipGetErrorString(e));
       }
-      seen_msg[q] = sq.msg.load(std::memory_order_relaxed);
-      sq.ack.store(seen_msg[q], std::memory_order_release);
+      seen_msg[q] = sq.msg_to[rank].load(std::memory_order_relaxed);
+      sq.ack_from[rank].store(seen_msg[q], std::memory_order_release);
     }
     parts.clear();
     return 0;

@@ -25,6 +25,7 @@
 
 #include "../../include/dellyhip.h"
 #include "split_kernel.hpp"
+#include "split_pk.hpp"   // pk, pk_add / pk_sub / pk_max: the packed Gotoh pass of msa_body.inc
 
 
 // MSA_SYNC(): the hand-over between the lanes of ONE wavefront (LDS / workspace written by some lanes, read by others).  The

@@ -33,6 +33,9 @@ def _worker(name, rank, world, script, q):
                     out.append(("ok", comm.gather_bytes(payload, root=step[2], cap=step[3])))
                 elif kind == "info":
                     out.append(("ok", comm.info()))
+                elif kind == "sleep":
+                    time.sleep(step[1].get(rank, 0.0))
+                    out.append(("ok", None))
             except refine.DellyHipError as e:
                 out.append(("err", e.code, str(e)))
         comm.close()
@@ -106,6 +109,30 @@ def test_payload_group_gatherv_of_ragged_sizes_growing_outbox():
     from delly_amd import abi
     for r in range(3):   # the root's buffer is too small: everybody learns it before any payload moves
         assert got[r][3][0] == "err" and got[r][3][1] == abi.E_NOMEM
+
+
+def test_alternating_roots_with_a_slow_sender():
+    # the message sequence must be per (sender, destination).  Root 0 twice (rank 1 and 2 each publish two
+    # messages for rank 0), then root 2 while rank 1 is slow: rank 2 reaches its receive for rank 1 long before rank 1
+    # publishes, and must not mistake rank 1's earlier messages (for rank 0) for its own.  Then root 1, then root 0 again.
+    sizes = [[7, 300, 5000], [1 << 20, 9, 2], [11, 70000, 13], [5, 6, 7], [100, 200, 300]]
+    roots = [0, 0, 2, 1, 0]
+    script = []
+    for k, (sz, root) in enumerate(zip(sizes, roots)):
+        if k == 2:
+            script.append(("sleep", {0: 0.3, 1: 1.5}))
+        if k == 3:
+            script.append(("sleep", {2: 1.0}))
+        script.append(("gather", sz, root, 1 << 24))
+    got = _run(3, script)
+    for r in range(3):
+        outs = [o for o in got[r] if not (o[0] == "ok" and o[1] is None)]
+        assert len(outs) == len(sizes), got[r]
+        for k, (sz, root) in enumerate(zip(sizes, roots)):
+            want = b"".join(bytes([65 + q]) * sz[q] for q in range(3))
+            tag, (data, got_sz) = outs[k]
+            assert tag == "ok" and got_sz == sz
+            assert data == (want if r == root else None)
 
 
 def test_a_missing_peer_is_an_error_not_a_hang():
