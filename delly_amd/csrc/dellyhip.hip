@@ -295,6 +295,7 @@ struct dellyhip_ctx {
   int msa_only = 0;          // env DELLYHIP_MSA_ONLY=1 (profiling builds): msa() batches stop after the MSA kernels
   int msa_waves = 16;        // resident wavefronts of msa_kernel per CU (env DELLYHIP_MSA_WAVES; 128 VGPRs and 9.7 KB of LDS allow 16)
   int msa_team = 0;          // wavefronts per junction of the MSA kernel: 0 = by batch size (env DELLYHIP_MSA_TEAM = 1 | 2 | 4 forces it)
+  int msa_pair = 1;          // two merges of a junction per Gotoh pass where they fit (env DELLYHIP_MSA_PAIR=0: one merge per pass, A/B)
   int quad_mix = 0;          // env DELLYHIP_QUAD_MIX=1: top whole quad rounds up with pair items
 };
 
@@ -1291,6 +1292,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_MSA_ONLY")) c->msa_only = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_WAVES")) c->msa_waves = std::max(1, std::min(16, atoi(t)));
   if (const char* t = getenv("DELLYHIP_MSA_TEAM")) c->msa_team = atoi(t);
+  if (const char* t = getenv("DELLYHIP_MSA_PAIR")) c->msa_pair = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   if (borrowed) {
     c->stream = borrowed;
@@ -1789,6 +1791,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.work_counter = c->counters.p;
     ma.defer_counter = c->counters.p + 8;
     ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
+    ma.pair = c->msa_pair;
     if ((rc = dh::msa_launch(ma, b->msa_grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
                              b->msa_plan.big_nmax, b->msa_team)))
       return fail(rc, "msa_launch");
@@ -2630,7 +2633,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
     S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
     S.ctx->lr_waves = c->lr_waves; S.ctx->lr_teams = c->lr_teams; S.ctx->lr_team_serial = c->lr_team_serial; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
-    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team;
+    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team; S.ctx->msa_pair = c->msa_pair;
   }
   *out = st.release();
   return 0;

@@ -65,6 +65,7 @@ struct MsaArgs {
   int32_t* defer_counter; // junctions handed to the direct-float kernel
   int32_t* big_counter;   // junctions beyond the limits of the standard instance (-> msa_big kernel); may be null
   int32_t out_cons_cap;   // bytes of the consensus slot at out_blob + j*out_stride
+  int32_t pair;           // 1: two merges of a junction share a Gotoh pass where they fit (gotoh_pass_pair); 0: one merge per pass
   // single-item gotoh mode (dellyhip_gotoh): two given alignments
   const uint8_t* g_a1;
   const uint8_t* g_a2;
@@ -268,8 +269,10 @@ inline int msa_tmax(const dellyhip_params& P, int wanted) {
 // resident slot, two or four when it does not (DELLYHIP_MSA_TEAM overrides; `delly sr` hands over 10^3 .. 10^4 per chromosome)
 inline int msa_team_waves(int n_junctions, int slots, int forced) {
   if (forced == 1 || forced == 2 || forced == 4) return forced;
-  if ((long long)n_junctions * 4 <= slots) return 4;
-  if ((long long)n_junctions * 2 <= slots + slots / 16) return 2;
+  // Round 5: one wavefront per junction now runs two merges per Gotoh pass (msa_body.inc, gotoh_pass_pair), the teams one:
+  // measured on 20-read junctions (tools/msa_rate.py) 500 per launch 1.19 / 1.04 / 0.79 ms with 1 / 2 / 4 wavefronts per
+  // junction, 1 000: 1.25 / 1.26 / 1.34, 2 000: 1.66 / 1.86 / 2.17 -- a team only pays while the chip is less than a fifth full.
+  if ((long long)n_junctions * 16 <= (long long)slots * 3) return 4;
   return 1;
 }
 inline uint64_t msa_team_stride(int nmax, int team) { return team <= 1 ? ((MsaWs::bytes(nmax) + 255) & ~255ull) : ((MsaTeamWs::bytes(nmax, team) + 255) & ~255ull); }
@@ -389,6 +392,7 @@ inline int msa_single(hipStream_t s, const dellyhip_params& P, int tmax, int n_r
   A.defer_counter = dcnt + 1;
   A.big_counter = dcnt + 2;
   A.tmax = msa_tmax(P, tmax);
+  A.pair = 1;
   msa_launch(A, 1, plan.nmax, s, wsb, plan.big_ws_stride, 1, plan.big_nmax);
   hipError_t e = hipStreamSynchronize(s);
   int rc = (e == hipSuccess) ? 0 : DELLYHIP_E_RUNTIME;
