@@ -33,6 +33,7 @@ cells = r["mismatches"].astype(np.float64)
 steps = r["cons_left"].astype(np.float64)
 print("DP cells per junction %.0f; row-steps issued %.0f x 64 lanes = %.0f lane-cells (%.0f %% useful); leaf x leaf merges %.1f of %d"
       % (cells.mean(), steps.mean(), steps.mean() * 64, 100 * cells.mean() / (steps.mean() * 64), r["score_best"].mean(), nr - 1))
+print("  of the first line: read offsets / lengths %.1f us, match masks + matrix init %.1f us, all-pairs LCS %.1f us" % (r["sv_start"].mean() / 100, r["sv_end"].mean() / 100, r["ins_len"].mean() / 100))
 print("paired passes per junction %.2f; their tracebacks %.1f us per junction (inside 'Gotoh DP + traceback')" % (r["ci_wiggle"].mean(), r["hom_len"].mean() / 100))
 t0 = r["ref_left"].astype(np.int64)
 span = (t0.max() - t0.min()) / 100.0
