@@ -40,25 +40,46 @@ CELLS_PER_U = 2 * 151 * 1001  # fwd + rev DP cells
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-# The side measurements of side_measurements(): (name, junctions, CPU sample, synth.make_batch kwargs).
+# The side measurements of side_measurements(): (name, junctions, CPU sample, batch recipe).  The recipe is synth.make_batch's
+# keyword arguments plus bench-only keys (leading underscore, see side_batch()): _tiles = that many copies of the batch side by
+# side (chip-filling variants), _big = (flank, DEL length) of synth.make_big_deletions, _steps = timed steps, _cpu_threads = cap
+# on the reference's threads, _no_stream = no host-inclusive leg.
 # tests/test_gpu_bench_shapes.py bit-compares the HIP path with oracle/_ref on exactly these batches.
 SIDE_PLAN = (("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
              ("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
              ("u_full_n20_10k_junctions", 10000, 0, dict(mode="c2", n_reads=20)),   # the chip filled: one wavefront per junction needs > 4 096 of them
              ("u_full_n5", 2000, 2000, dict(mode="c2", n_reads=5)),
+             # BASELINE configs[2] as written: "all SV types, full sr pipeline" -- svt 0 .. 8 (translocations on a second
+             # chromosome, insertions through splitAlign), 2 .. 20 reads per junction: msa + alignConsensus
+             ("sr_stage_mixed_all_svt", 10000, 2000, dict(mode="allsvt", n_reads=(2, 20))),
              ("ins_svt4", 5000, 5000, dict(mode="ins")),
              ("lr_c4_align_consensus", 2048, 128, dict(mode="lr", sub_rate=0.01)),
              ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)),
              # INS 800 bp, 15 reads of ~3.8 kb at 6 % error: msaWfa + alignConsensus (splitAlign)
-             ("lr_ins_msawfa_n15", 512, 64, dict(mode="lrins", n_reads=15, sub_rate=0.06)))
+             ("lr_ins_msawfa_n15", 512, 64, dict(mode="lrins", n_reads=15, sub_rate=0.06)),
+             # BASELINE configs[3] as written (SURVEY.md F6 "benchmark both"): 10 kb consensus x 20.7 kb window; the reference
+             # holds four int32 matrices of 830 MB per call (src/needle.h:52-103): 8 threads at most
+             ("lr_stress_10kb_x_20kb", 64, 8, dict(mode="lr", _big=(5000, 700), _cpu_threads=8, _steps=2, _no_stream=True)),
+             # chip-filling sizes of the long-read rows (one wavefront per junction: at the sizes above the kernels are bound by a
+             # junction's latency, these show the throughput with every wavefront slot busy): four tiles of the row's batch, one step
+             ("lr_c4_align_consensus_8k", 8192, 0, dict(mode="lr", sub_rate=0.01, _tiles=4, _steps=1, _no_stream=True)),
+             ("lr_c4_msaedlib_n15_3k", 3072, 0, dict(mode="lr", n_reads=15, sub_rate=0.06, _tiles=4, _steps=1, _no_stream=True)),
+             ("lr_ins_msawfa_n15_2k", 2048, 0, dict(mode="lrins", n_reads=15, sub_rate=0.06, _tiles=4, _steps=1, _no_stream=True)))
+SIDE_PLAN_BIG = ()   # (round 4 kept the chip-filling rows out of the default run; they are tiles now and part of it)
 
 
-# chip-filling batch sizes of the long-read rows: NOT part of the default run (generation alone takes tens of seconds);
-# `--only-extras lr_c4_align_consensus_8k,...` runs them.  One wavefront per junction: at the SIDE_PLAN sizes the long-read
-# kernels are bound by a junction's latency, these show the throughput with every wavefront slot busy.
-SIDE_PLAN_BIG = (("lr_c4_align_consensus_8k", 8192, 0, dict(mode="lr", sub_rate=0.01)),
-                 ("lr_c4_msaedlib_n15_3k", 3072, 0, dict(mode="lr", n_reads=15, sub_rate=0.06)),
-                 ("lr_ins_msawfa_n15_2k", 2048, 0, dict(mode="lrins", n_reads=15, sub_rate=0.06)))
+def side_batch(synth, n, kw):
+    """the batch of a SIDE_PLAN row"""
+    kw = dict(kw)
+    tiles = int(kw.pop("_tiles", 1))
+    big = kw.pop("_big", None)
+    for k in [k for k in kw if k.startswith("_")]:
+        kw.pop(k)
+    if big is not None:
+        return synth.make_big_deletions([tuple(big)] * n, seed=23, err=0.01, revcomp_every=3)
+    b = synth.make_batch(n // tiles, **kw)
+    return synth.tile_batch(b, tiles)
+
 
 RESIDENT_BATCHES = 4          # distinct resident batches the timed steps rotate through
 HOST_INCLUSIVE_SECONDS = 1.0  # wall time of the pipelined host-buffer measurement
@@ -122,7 +143,7 @@ def cpu_baseline(batch, budget_s=12.0):
 
 def _profile_file(name):
     """newest committed copy of a profile artefact (profiles/rNN/<name>)"""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             return path
@@ -155,7 +176,7 @@ def _subbatch(batch, n):
     first = int(batch.junctions["seq_first"][0])
     last = int(batch.junctions["seq_first"][n - 1] + batch.junctions["n_seq"][n - 1])
     return synth.Batch(batch.chroms, batch.junctions[:n].copy(), batch.seq_blob, batch.seq_off[:last + 1].copy(),
-                       batch.with_msa, batch.truth[:n])
+                       batch.with_msa, batch.truth[:n] if batch.truth is not None else None)
 
 
 def one_genome(synth, batches):
@@ -298,10 +319,11 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
     cores = os.cpu_count() or 1
     out = {}
     want = (lambda name: True) if not only else (lambda name: name in only)
-    plan = tuple(x for x in SIDE_PLAN if want(x[0])) + tuple(x for x in SIDE_PLAN_BIG if only and x[0] in only)
+    plan = tuple(x for x in SIDE_PLAN if want(x[0]))
     for name, n, ncpu, kw in plan:
-        b = synth.make_batch(n, **kw)
+        b = side_batch(synth, n, kw)
         lr = kw["mode"].startswith("lr")
+        row_steps = int(kw.get("_steps", steps))
         params = abi.params_lr(realign=True) if lr else abi.params_sr()
         if lr and not getattr(ctx, "is_lr", False):  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
             ctx = refine.Context(params=params, device=device)
@@ -310,14 +332,20 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(row_steps):
             rb.run()
         rb.sync()
-        dt = (time.perf_counter() - t0) / steps
+        dt = (time.perf_counter() - t0) / row_steps
         ms_split, ms_msa, _ = rb.kernel_ms()
         res, _ = rb.fetch()
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
-                     "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum())}
+                     "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum()), "steps": row_steps}
+        if b.with_msa == 1:   # short-read msa(): how many junctions left the score-table kernel
+            try:
+                ms = rb.msa_stats()
+                out[name].update({"msa_deferred_junctions": ms[0], "msa_second_instance_junctions": ms[1], "msa_wavefronts_per_junction": ms[2]})
+            except Exception:
+                pass
         if lr:   # the dense strips of junctions the sparse passes give up on run on teams of wavefronts
             try:
                 ts = rb.lr_team_stats()
@@ -326,14 +354,18 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
                 pass
         rb.free()
         try:   # the same batch from host buffers through the pipelined path
+            if kw.get("_no_stream"):
+                raise KeyError("skipped")
             hi = host_inclusive_rate(ctx, [b], b.with_msa, seconds=0.5 if dt < 0.05 else 3 * dt, depth=5 if dt < 0.02 else 3)
             out[name]["host_inclusive"] = {k: hi[k] for k in ("value", "unit", "batches", "wall_s", "ms_per_batch", "depth", "bytes_up_per_batch", "bytes_down_per_batch")}
             out[name]["host_inclusive"]["vs_resident"] = hi["value"] / (n / dt)
+        except KeyError:
+            pass
         except Exception as e:
             out[name]["host_inclusive"] = {"error": repr(e)}
         if orc is not None and ncpu > 0:
-            sub = b if ncpu >= n else synth.make_batch(ncpu, **kw)
-            threads = max(1, min(cores, sub.n))
+            sub = b if ncpu >= n else _subbatch(b, ncpu)   # (a prefix of the SAME batch)
+            threads = max(1, min(cores, sub.n, int(kw.get("_cpu_threads", cores))))
             sec, visits, _ = orc.time_refine(sub, n_threads=threads, reps=1, params=params)
             reps = int(max(1, min(40, 1.5 / max(sec, 1e-3))))   # ~1.5 s of CPU work per workload
             if reps > 1:
@@ -432,6 +464,52 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         pass
     except Exception as e:  # side figure only
         out["lr_genotype_edit_distance_nw"] = {"error": repr(e)}
+    return out
+
+
+# (side row, key of its rate in `config`)
+FLAT_ROWS = (("u_c2_40k_junctions", "u_c2_40k_alignments_per_s"), ("u_full_n20", "u_full_n20_2k_junctions_per_s"),
+             ("u_full_n20_10k_junctions", "u_full_n20_10k_junctions_per_s"), ("u_full_n5", "u_full_n5_2k_junctions_per_s"),
+             ("sr_stage_mixed_all_svt", "sr_stage_mixed_all_svt_junctions_per_s"), ("ins_svt4", "ins_svt4_junctions_per_s"),
+             ("lr_c4_align_consensus", "lr_c4_align_consensus_junctions_per_s"), ("lr_c4_msaedlib_n15", "lr_c4_msaedlib_n15_junctions_per_s"),
+             ("lr_ins_msawfa_n15", "lr_ins_msawfa_n15_junctions_per_s"), ("lr_stress_10kb_x_20kb", "lr_stress_10kb_x_20kb_junctions_per_s"),
+             ("lr_c4_align_consensus_8k", "lr_c4_align_consensus_8k_junctions_per_s"), ("lr_c4_msaedlib_n15_3k", "lr_c4_msaedlib_n15_3k_junctions_per_s"),
+             ("lr_ins_msawfa_n15_2k", "lr_ins_msawfa_n15_2k_junctions_per_s"))
+# The driver's record of a run keeps the first DRIVER_CONFIG_KEYS scalar entries of `config`: these come first, in this order
+# (tests/test_bench_record.py parses a line the way the driver does and asserts they survive).
+DRIVER_CONFIG_KEYS = 24
+CONFIG_FIRST = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
+                "u_full_n20_10k_junctions_per_s", "u_full_n20_2k_junctions_per_s", "sr_stage_mixed_all_svt_junctions_per_s",
+                "ins_svt4_junctions_per_s", "lr_c4_align_consensus_junctions_per_s", "lr_c4_msaedlib_n15_junctions_per_s",
+                "lr_ins_msawfa_n15_junctions_per_s", "lr_stress_10kb_x_20kb_junctions_per_s", "lr_c4_align_consensus_8k_junctions_per_s",
+                "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
+                "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
+                "u_c2_40k_alignments_per_s", "u_full_n20_10k_msa_deferred_junctions", "u_full_n5_2k_junctions_per_s",
+                "value_min", "value_max", "launches_in_flight", "refined_ok_min")
+# N > 1 (the driver's SCALE runs): what the return paths cost comes first
+CONFIG_FIRST_MULTI = ("workload", "gather_ms_per_step", "gather_transport", "rccl_ranks", "shm_return_alignments_per_s", "shm_return_ms_per_step",
+                      "shm_return_gather_ms_per_step", "host_inclusive_alignments_per_s", "ms_per_step_min_rank", "ms_per_step_max_rank",
+                      "ranks_launched", "ranks_that_ran_kernels", "oversubscribed_one_device", "gathered_records_on_rank0",
+                      "gathered_blob_bytes_on_rank0", "shm_return_records_seen_by_rank0", "junctions_per_gpu", "refined_ok_min",
+                      "kernels_ms_per_step_rank0", "launches_in_flight")
+
+
+def order_config(cfg):
+    first = CONFIG_FIRST_MULTI if "gather_ms_per_step" in cfg else CONFIG_FIRST
+    out = {k: cfg[k] for k in first if k in cfg}
+    out.update({k: v for k, v in cfg.items() if k not in out})
+    return out
+
+
+def driver_view_of_config(cfg, keep=DRIVER_CONFIG_KEYS):
+    """what BENCH_rNN.json keeps of `config`: the first `keep` scalar entries (names cut to 40 characters)"""
+    out = {}
+    for k, v in cfg.items():
+        if isinstance(v, (dict, list)):
+            continue
+        out[k[:40]] = v
+        if len(out) >= keep:
+            break
     return out
 
 
@@ -829,7 +907,7 @@ def main():
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,
             "unit": "alignments/s",
-            "n_gpus": ranks_that_ran if not args.oversubscribe else world,
+            "n_gpus": ranks_that_ran if not args.oversubscribe else 1,   # distinct devices that ran kernels (every oversubscribed rank drives device 0; config.ranks_launched has the rank count)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -873,19 +951,24 @@ def main():
                     out["extras"]["deficit_sweep"] = deficit_sweep(refine.Context(device=local), synth, local, with_cpu=not args.no_cpu_baseline)
                 except Exception as e:  # side figure only
                     out["extras"]["deficit_sweep"] = {"error": repr(e)}
-            # flat copies of the side rows the verdicts track (the driver's record keeps scalars of `config` only)
-            for name, key in (("u_c2_40k_junctions", "u_c2_40k_alignments_per_s"), ("u_full_n20", "u_full_n20_2k_junctions_per_s"),
-                              ("u_full_n20_10k_junctions", "u_full_n20_10k_junctions_per_s"), ("ins_svt4", "ins_svt4_junctions_per_s"),
-                              ("lr_c4_align_consensus", "lr_c4_align_consensus_junctions_per_s"),
-                              ("lr_c4_msaedlib_n15", "lr_c4_msaedlib_n15_junctions_per_s"), ("lr_ins_msawfa_n15", "lr_ins_msawfa_n15_junctions_per_s")):
+            # flat copies of the side rows the verdicts track: the driver's record keeps the FIRST 24 scalars of `config`
+            # (BENCH_r04.json lost every side row to five descriptive strings in front of them), see order_config()
+            for name, key in FLAT_ROWS:
                 row = out["extras"].get(name)
                 if isinstance(row, dict) and "junctions_per_s" in row:
                     out["config"][key] = row["junctions_per_s"]
+            row = out["extras"].get("u_full_n20_10k_junctions")
+            if isinstance(row, dict) and "msa_deferred_junctions" in row:
+                out["config"]["u_full_n20_10k_msa_deferred_junctions"] = row["msa_deferred_junctions"]
             sw = out["extras"].get("deficit_sweep")
             if isinstance(sw, dict):
                 for name, row in sw.items():
                     if isinstance(row, dict) and "alignments_per_s" in row:
                         out["config"]["deficit_sweep_%s_alignments_per_s" % name] = row["alignments_per_s"]
+                for name in ("substitutions_2pct", "substitutions_5pct"):   # (short names: the driver cuts keys at 40 characters)
+                    if isinstance(sw.get(name), dict) and "alignments_per_s" in sw[name]:
+                        out["config"]["%s_alignments_per_s" % name] = sw[name]["alignments_per_s"]
+        out["config"] = order_config(out["config"])
         print(json.dumps(out), flush=True)
     for x in rbs:
         x.free()

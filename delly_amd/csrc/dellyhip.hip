@@ -1894,6 +1894,21 @@ int dellyhip_batch_sparse_left(dellyhip_ctx* c, dellyhip_batch* b, int32_t* left
   return 0;
 }
 
+int dellyhip_batch_msa_stats(dellyhip_ctx* c, dellyhip_batch* b, int32_t out[4]) {
+  if (!c || !b || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  int rc = dellyhip_batch_sync(c, b);
+  if (rc || !c->counters.p || !b->ever_run) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  int32_t v[2] = {0, 0};
+  HIPCHK(hipMemcpy(v, c->counters.p + 8, sizeof(v), hipMemcpyDeviceToHost));
+  out[0] = v[0];
+  out[1] = v[1];
+  out[2] = b->msa_team;
+  out[3] = b->msa_grid;
+  return 0;
+}
+
 int dellyhip_batch_lr_team_stats(dellyhip_ctx* c, dellyhip_batch* b, int32_t out[4]) {
   if (!c || !b || !out) return fail(DELLYHIP_E_ARG, "null argument");
   out[0] = out[1] = out[2] = out[3] = 0;

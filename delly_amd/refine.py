@@ -34,7 +34,7 @@ EXPORTS = [
     "dellyhip_split_align", "dellyhip_shard_by_cost", "dellyhip_comm_unique_id", "dellyhip_comm_create", "dellyhip_comm_destroy",
     "dellyhip_gather_results", "dellyhip_gather_results_device",
     "dellyhip_create_shared", "dellyhip_trim_memory", "dellyhip_compute_streams", "dellyhip_host_register", "dellyhip_host_unregister", "dellyhip_stream_create", "dellyhip_stream_destroy", "dellyhip_stream_submit", "dellyhip_stream_collect",
-    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_batch_lr_team_stats", "dellyhip_rebase_gathered",
+    "dellyhip_stream_pending", "dellyhip_stream_release", "dellyhip_stream_stats", "dellyhip_batch_sparse_left", "dellyhip_batch_lr_team_stats", "dellyhip_batch_msa_stats", "dellyhip_rebase_gathered",
     "dellyhip_comm_create_hostlink", "dellyhip_comm_info", "dellyhip_comm_exchange_sizes", "dellyhip_comm_exchange_ready", "dellyhip_comm_gather_bytes", "dellyhip_edlib_align_full",
 ]
 
@@ -516,6 +516,13 @@ class ResidentBatch:
         """long-read batches: (teams launched, junctions they swept in the last run, claims made on the list, error flag)"""
         v = (C.c_int32 * 4)()
         self.ctx._check(self.ctx.lib.dellyhip_batch_lr_team_stats(self.ctx._ctx, self._b, v))
+        return tuple(int(x) for x in v)
+
+    def msa_stats(self):
+        """msa() batches: (junctions deferred to the direct-float kernel, junctions sent to the second instance, wavefronts per
+        junction, blocks) of the last run on this context"""
+        v = (C.c_int32 * 4)()
+        self.ctx._check(self.ctx.lib.dellyhip_batch_msa_stats(self.ctx._ctx, self._b, v))
         return tuple(int(x) for x in v)
 
     def sparse_left(self):

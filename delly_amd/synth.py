@@ -207,6 +207,8 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   (two-window branch src/split.h:117), DUP, INV 3to3/5to5 and
                   the four BND orientations across two chromosomes, varying
                   flank lengths.
+    mode "allsvt": BASELINE config 3's mix -- "mixed" plus svt 4 insertions (one junction in 13), i.e. every SV type 0 .. 8
+                  with the translocations on two chromosomes.
     mode "lr"   : long-read shapes (BASELINE config C4): ~2 kb consensus with 1 % substitutions
                   and indels, DEL 3 kb (window ~7 kb, contiguous branch), short DEL, DEL beyond
                   indelsize (two windows), INV, DUP; every third junction's consensus is given
@@ -219,7 +221,8 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   novel or tandem-duplicated sequence, soft-masked / N-containing
                   reference stretches, pure-reference negatives.
     n_reads 0   : unit U (one consensus per junction); >0: unit U_full (that
-                  many distinct split reads per junction, host order = as generated).
+                  many distinct split reads per junction, host order = as generated); a pair (lo, hi): that many,
+                  drawn per junction from lo .. hi.
     genome      : None = uniform random letters; "lowcx" = plant_low_complexity() around the breakpoints of every junction
                   (kind = junction index mod LOWCX_KINDS; `real` = a real chromosome to cut windows from); "real" = every
                   window is cut from `real`.
@@ -228,7 +231,10 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                   distances everywhere are UPGMA's tie case, src/msa.h:46-89)
     junction_ins: that many non-templated bases between the two flanks of the ALT haplotype
     """
-    two_chr = mode == "mixed"
+    two_chr = mode in ("mixed", "allsvt")
+    nr_range = n_reads if isinstance(n_reads, (tuple, list)) else None
+    if nr_range is not None:
+        n_reads = int(nr_range[1])
     lr_like = mode in ("lr", "lrins")
     WINDOW = WINDOW_LR if lr_like else globals()["WINDOW"]
     chrA = np.empty(n * WINDOW, dtype=np.uint8)
@@ -247,9 +253,9 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
         flankL = flankR = cons_flank
         kind = "del"
         H = None
-        if mode == "mixed":
+        if two_chr:
             H = ACGT[rng.integers(0, 4, WINDOW)]
-            sel = j % 12
+            sel = j % (13 if mode == "allsvt" else 12)
             flankL = int(rng.integers(40, 140))
             flankR = int(rng.integers(40, 140))
             if sel in (0, 1, 2, 3):
@@ -262,6 +268,11 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                 kind, svt, ell = "inv0", 0, int(rng.integers(400, 1500))
             elif sel == 7:
                 kind, svt, ell = "inv1", 1, int(rng.integers(400, 1500))
+            elif sel == 12:
+                kind, svt = "ins", 4
+                flankL = int(rng.integers(55, 98))
+                flankR = int(rng.integers(55, 98))
+                ell = int(rng.integers(20, 121))      # inserted length
             else:
                 kind, svt = "bnd%d" % (sel - 8), 5 + (sel - 8)
         elif mode == "lr":
@@ -398,11 +409,12 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
             rec["n_seq"] = 1
         else:
             seen = set()
+            want_reads = n_reads if nr_range is None else int(_rng(seed ^ 0x2ead, j).integers(int(nr_range[0]), int(nr_range[1]) + 1))
             lo, hi = 25, alt.size - read_len - 25
             if lr_like:   # long reads span the junction: ~L - 100 bases of each flank
                 lo, hi = 0, 100
             tries = 0
-            while len(seen) < n_reads and tries < 50 * n_reads:
+            while len(seen) < want_reads and tries < 50 * want_reads:
                 tries += 1
                 o = int(rng.integers(lo, hi + 1))
                 if lr_like:
@@ -416,7 +428,7 @@ def make_batch(n, *, seed=42, first=0, mode="c2", n_reads=0, read_len=150, cons_
                     continue
                 seen.add(key)
                 seqs.append(r)
-                if dup_reads and len(seen) % 3 == 0 and len(seen) < n_reads:
+                if dup_reads and len(seen) % 3 == 0 and len(seen) < want_reads:
                     seen.add(key + b"#%d" % len(seen))
                     seqs.append(r.copy())
             rec["n_seq"] = len(seen)
@@ -546,3 +558,55 @@ def load_real_chromosome(path=None):
     p = z["packed"]
     c = np.stack([p & 3, (p >> 2) & 3, (p >> 4) & 3, p >> 6], axis=1).reshape(-1)[:int(z["n"])]
     return ACGT[c]
+
+
+def tile_batch(batch, times):
+    """`times` copies of a batch side by side on one (longer) genome: the chip-filling variants of bench.py's long-read rows are
+    four tiles of the row's batch (generating 8 192 long-read junctions letter by letter takes minutes; the work per tile is
+    the same, and tests/test_gpu_bench_shapes.py checks tile k against tile 0 and tile 0 against the reference)."""
+    if times <= 1:
+        return batch
+    chroms = [np.tile(c, times) for c in batch.chroms]
+    n = batch.n
+    junc = np.tile(batch.junctions, times)
+    nseq = batch.seq_off.size - 1
+    for k in range(1, times):
+        sl = slice(k * n, (k + 1) * n)
+        junc["svid"][sl] += k * n
+        junc["sv_start"][sl] += k * batch.chroms[0].size
+        c2 = batch.junctions["chr2"]
+        junc["sv_end"][sl] += np.where(c2 == 0, k * batch.chroms[0].size, k * batch.chroms[-1].size).astype(junc["sv_end"].dtype)
+        junc["seq_first"][sl] += np.uint64(k * nseq)
+    blob = np.tile(batch.seq_blob, times)
+    total = int(batch.seq_off[-1])
+    off = np.concatenate([batch.seq_off[:-1] + np.uint64(k * total) for k in range(times)] + [np.array([times * total], dtype=np.uint64)])
+    truth = list(batch.truth) * times if batch.truth is not None else None
+    return Batch(chroms, junc, blob, off, batch.with_msa, truth)
+
+
+def make_big_deletions(shapes, seed=11, err=0.01, revcomp_every=0):
+    """one DEL junction per (flank, ell): consensus = 2 * flank bases of the ALT haplotype with ONT-like errors -- BASELINE
+    configs[3] as written is (5000, 700): a 10 kb consensus against a 20.7 kb reference window (longNeedle over 2 x 207 M cells;
+    the reference holds four int32 matrices of 830 MB for it, src/needle.h:52-103).  Use with abi.params_lr(realign=True)."""
+    rng = np.random.default_rng(seed)
+    W = 70000
+    n = len(shapes)
+    chrom = ACGT[rng.integers(0, 4, n * W)]
+    junc = np.zeros(n, dtype=abi.junction_dtype())
+    seqs = []
+    for k, (flank, ell) in enumerate(shapes):
+        s0 = k * W + 20000
+        hap = np.concatenate([chrom[s0 - flank:s0], chrom[s0 + ell:s0 + ell + flank]])
+        cons = _ont(rng, hap, err)
+        if revcomp_every and k % revcomp_every == 1:
+            cons = revcomp(cons)
+        junc[k]["svid"] = k
+        junc[k]["svt"] = 2
+        junc[k]["sv_start"] = s0 + int(rng.integers(-3, 4))
+        junc[k]["sv_end"] = s0 + ell + int(rng.integers(-3, 4))
+        junc[k]["seq_first"] = k
+        junc[k]["n_seq"] = 1
+        seqs.append(cons)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([x.size for x in seqs])
+    return Batch([chrom], junc, np.concatenate(seqs), off, 0, None)

@@ -278,6 +278,13 @@ int dellyhip_batch_sparse_left(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t* le
  * the last run the teams swept, out[2] = claims the teams made on the list (>= out[0]: every team ends with one that finds nothing), out[3] = 1 if a team gave up waiting
  * (those junctions carry status DELLYHIP_E_RUNTIME).  Synchronises the batch. */
 int dellyhip_batch_lr_team_stats(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t out[4]);
+/* msa() batches: how the LAST RUN ON THIS CONTEXT went through the MSA kernels (counters of the context, like
+ * dellyhip_batch_sparse_left).  out[0] = junctions the score-table kernel deferred to the direct-float kernel (a node with
+ * more column types than the table holds, a NaN score; src/align.h:104-110 evaluated per cell there), out[1] = junctions
+ * beyond the standard instance's shapes that went to the second instance (more / longer reads, wider nodes), out[2] =
+ * wavefronts per junction of the launch (1, or a team of 2 / 4 for launches that do not fill the chip), out[3] = its blocks.
+ * Synchronises the batch. */
+int dellyhip_batch_msa_stats(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t out[4]);
 
 /* ---- multi-GPU: junction sharding + gather of the results to one rank ------------------------ */
 

@@ -1,0 +1,63 @@
+"""The driver's record of a bench run (BENCH_rNN.json) keeps the scalars of the JSON line plus the FIRST 24 scalar entries of
+`config`, names cut at 40 characters (BENCH_r04.json: five descriptive strings in front cost every side row its place).
+bench.order_config() puts the rows the verdicts track first; this test reads a line the way the driver does."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+MUST_SURVIVE = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
+                "u_full_n20_10k_junctions_per_s", "u_full_n20_2k_junctions_per_s", "ins_svt4_junctions_per_s",
+                "lr_c4_align_consensus_junctions_per_s", "lr_c4_msaedlib_n15_junctions_per_s", "lr_ins_msawfa_n15_junctions_per_s",
+                "sr_stage_mixed_all_svt_junctions_per_s", "lr_stress_10kb_x_20kb_junctions_per_s",
+                "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
+                "lr_c4_align_consensus_8k_junctions_per_s", "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
+                "u_full_n20_10k_msa_deferred_junctions")
+
+
+def _line_like_bench():
+    """a config in the order main() builds it: descriptive strings and bookkeeping first, the side rows appended at the end"""
+    cfg = {"workload": "BASELINE configs[1]: ...", "workload_detail": "...", "launches_in_flight": 2, "junctions_per_gpu": 10000,
+           "resident_batches": 4, "refined_ok_min": 9900, "parallelism": "junction-sharded x1", "ranks_launched": 1, "ranks_that_ran_kernels": 1,
+           "value_is": "...", "kernels_ms_per_step_rank0": 0.3, "timed_regions": 25, "value_is_region": "...", "value_min": 1.0, "value_max": 2.0,
+           "value_median": 1.5, "timed_seconds_total": 0.1, "one_launch_at_a_time_alignments_per_s": 3.0e7, "one_launch_at_a_time_ms_per_step": 0.3,
+           "one_launch_at_a_time_kernel_ms": 0.26, "host_inclusive_alignments_per_s": 4.0e7, "host_inclusive_wall_s": 1.0,
+           "host_inclusive_batches": 4000, "host_inclusive_ms_per_batch": 0.25}
+    for _, key in bench.FLAT_ROWS:
+        cfg[key] = 1.0
+    cfg["u_full_n20_10k_msa_deferred_junctions"] = 0
+    for name, _ in bench.SWEEP_PLAN:
+        cfg["deficit_sweep_%s_alignments_per_s" % name] = 1.0
+    cfg["substitutions_2pct_alignments_per_s"] = cfg["substitutions_5pct_alignments_per_s"] = 1.0
+    cfg["a_nested_thing"] = {"x": 1}
+    return {"metric": "m", "value": 1.0, "config": bench.order_config(cfg)}
+
+
+def test_the_rows_the_verdicts_track_survive_the_drivers_cut():
+    line = json.loads(json.dumps(_line_like_bench()))          # (through JSON: key order is what the driver sees)
+    kept = bench.driver_view_of_config(line["config"])
+    assert len(kept) == bench.DRIVER_CONFIG_KEYS
+    missing = [k for k in MUST_SURVIVE if k[:40] not in kept]
+    assert not missing, missing
+    assert sum(isinstance(v, str) for v in kept.values()) == 1  # the workload string; every other slot is a number
+
+
+def test_first_keys_fit_the_cut_and_stay_distinct():
+    for first in (bench.CONFIG_FIRST, bench.CONFIG_FIRST_MULTI):
+        assert len(first) <= bench.DRIVER_CONFIG_KEYS
+        cut = [k[:40] for k in first]
+        assert len(set(cut)) == len(cut)
+    flat = {key for _, key in bench.FLAT_ROWS}
+    assert {k for k in MUST_SURVIVE if k.endswith("junctions_per_s")} <= flat | {"host_inclusive_alignments_per_s"}
+
+
+def test_every_side_row_has_a_batch_recipe_the_parity_test_can_rebuild():
+    names = [x[0] for x in bench.SIDE_PLAN]
+    assert len(set(names)) == len(names)
+    for name, n, ncpu, kw in bench.SIDE_PLAN:
+        assert n > 0 and ncpu >= 0 and "mode" in kw
+        assert n % int(kw.get("_tiles", 1)) == 0
+    assert {row for row, _ in bench.FLAT_ROWS} <= set(names)

@@ -20,15 +20,18 @@ THREADS = os.cpu_count() or 1
 # junctions compared per workload (None = the whole benched batch); long-read legs use at most 64 reference threads (each
 # holds four int32 matrices of ~60 MB, src/needle.h:52-103)
 COMPARE_N = {"u_c2_40k_junctions": None, "u_full_n20": None, "u_full_n20_10k_junctions": None, "u_full_n5": None, "ins_svt4": None,
-             "lr_c4_align_consensus": None, "lr_c4_msaedlib_n15": None, "lr_ins_msawfa_n15": None}
+             "sr_stage_mixed_all_svt": None, "lr_c4_align_consensus": None, "lr_c4_msaedlib_n15": None, "lr_ins_msawfa_n15": None,
+             # 10 kb x 20.7 kb: the reference needs 3.3 GB and ~3 s per junction -- 16 of the 64 benched junctions, 8 threads
+             "lr_stress_10kb_x_20kb": 16}
+TILED = [x[0] for x in bench.SIDE_PLAN if int(x[3].get("_tiles", 1)) > 1]
 
 
-def _check(ctx, ref, b, params, label, n_cmp=None):
+def _check(ctx, ref, b, params, label, n_cmp=None, ref_threads=None):
     ctx.set_chromosomes(b.chroms)
     gr, gb = ctx.refine(b, want_alignment=False)
     sub = b if n_cmp is None or n_cmp >= b.n else bench._subbatch(b, n_cmp)
     lr = params is not None and (params.reserved & 1)
-    rr, rb = ref.refine_batch(sub, want_alignment=False, n_threads=min(THREADS, 64) if lr else THREADS, params=params)
+    rr, rb = ref.refine_batch(sub, want_alignment=False, n_threads=min(THREADS, ref_threads or 64) if lr else THREADS, params=params)
     k = sub.n
     compare(gr[:k], gb, rr, rb, fields=CORE, blobs=("cons", "allele"), label=label)
     return gr
@@ -90,16 +93,62 @@ def test_host_inclusive_stream_results_vs_reference(gpu_ctx, reference):
     st.close()
 
 
-@pytest.mark.parametrize("name", [x[0] for x in bench.SIDE_PLAN if x[0] in COMPARE_N])
+@pytest.mark.parametrize("name", [x[0] for x in bench.SIDE_PLAN if x[0] in COMPARE_N])   # (every row that is not a tile of another)
 def test_side_measurement_batches_vs_reference(reference, name):
     _, n, _, kw = [x for x in bench.SIDE_PLAN if x[0] == name][0]
     lr = kw["mode"].startswith("lr")
     params = abi.params_lr(realign=True) if lr else abi.params_sr()
     ctx = refine.Context(params=params)
     try:
-        b = synth.make_batch(n, **kw)
-        gr = _check(ctx, reference, b, params, name, COMPARE_N[name])
+        b = bench.side_batch(synth, n, kw)
+        gr = _check(ctx, reference, b, params, name, COMPARE_N[name], ref_threads=kw.get("_cpu_threads"))
         assert int((gr["status"] != 0).sum()) == 0
         assert int(gr["ok"].sum()) > 0.75 * n
+        if name == "sr_stage_mixed_all_svt":   # BASELINE configs[2]: every SV type, 2 .. 20 reads
+            assert sorted(set(b.junctions["svt"].tolist())) == list(range(9))
+            assert b.junctions["n_seq"].min() == 2 and b.junctions["n_seq"].max() == 20 and len(b.chroms) == 2
+        if name == "lr_stress_10kb_x_20kb":
+            assert gr["cons_len"].min() > 9000 and gr["ref_len"].min() > 20000
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", TILED)
+def test_chip_filling_rows_are_tiles_of_a_compared_batch(name):
+    """the chip-filling long-read rows are `_tiles` copies of their sibling row's batch (compared in full with the reference above)
+    side by side on a longer genome: every tile must come out like the first, shifted by the tile's offset"""
+    _, n, _, kw = [x for x in bench.SIDE_PLAN if x[0] == name][0]
+    tiles = int(kw["_tiles"])
+    params = abi.params_lr(realign=True)
+    ctx = refine.Context(params=params)
+    try:
+        b = bench.side_batch(synth, n, kw)
+        base = [x for x in bench.SIDE_PLAN if x[3].get("mode") == kw["mode"] and x[3].get("n_reads") == kw.get("n_reads")
+                and x[3].get("sub_rate") == kw.get("sub_rate") and "_tiles" not in x[3] and "_big" not in x[3]]
+        assert base and base[0][1] == n // tiles, "a tiled row needs its sibling row of n / tiles junctions"
+        ctx.set_chromosomes(b.chroms)
+        gr, gb = ctx.refine(b, want_alignment=False)
+        n0 = n // tiles
+        csize = b.chroms[0].size // tiles
+        first = gr[:n0].copy()
+        for k in range(1, tiles):
+            want = first.copy()
+            want["svid"] += k * n0
+            moved = want["ok"] != 0
+            want["sv_start"][moved] += k * csize
+            want["sv_end"][moved] += k * csize
+            got = gr[k * n0:(k + 1) * n0]
+            for f in CORE:
+                if f in ("sv_start", "sv_end"):   # (an unrefined junction keeps the caller's coordinates, which are shifted too)
+                    assert (got[f][moved] == want[f][moved]).all(), (name, k, f)
+                else:
+                    x, y = got[f], want[f]
+                    same = (x == y) | ((x != x) & (y != y)) if x.dtype.kind == "f" else (x == y)
+                    assert same.all(), (name, k, f)
+            import pyoracle
+            for i in range(0, n0, max(1, n0 // 64)):
+                for w in ("cons", "allele"):
+                    assert pyoracle.blob_field(got[i], gb, w) == pyoracle.blob_field(gr[i], gb, w), (name, k, i, w)
+        assert int((gr["status"] != 0).sum()) == 0
     finally:
         ctx.close()

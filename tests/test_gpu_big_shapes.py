@@ -28,30 +28,7 @@ def lr_reference(reference):
     reference.params = old
 
 
-def _big_deletions(shapes, seed=11, err=0.01, revcomp_every=0):
-    """one DEL junction per (flank, ell): consensus = 2*flank bases of the ALT haplotype with ONT-like errors"""
-    rng = np.random.default_rng(seed)
-    W = 70000
-    n = len(shapes)
-    chrom = synth.ACGT[rng.integers(0, 4, n * W)]
-    junc = np.zeros(n, dtype=abi.junction_dtype())
-    seqs = []
-    for k, (flank, ell) in enumerate(shapes):
-        s0 = k * W + 20000
-        hap = np.concatenate([chrom[s0 - flank:s0], chrom[s0 + ell:s0 + ell + flank]])
-        cons = synth._ont(rng, hap, err)
-        if revcomp_every and k % revcomp_every == 1:
-            cons = synth.revcomp(cons)
-        junc[k]["svid"] = k
-        junc[k]["svt"] = 2
-        junc[k]["sv_start"] = s0 + int(rng.integers(-3, 4))
-        junc[k]["sv_end"] = s0 + ell + int(rng.integers(-3, 4))
-        junc[k]["seq_first"] = k
-        junc[k]["n_seq"] = 1
-        seqs.append(cons)
-    off = np.zeros(n + 1, dtype=np.uint64)
-    off[1:] = np.cumsum([x.size for x in seqs])
-    return synth.Batch([chrom], junc, np.concatenate(seqs), off, 0, None)
+_big_deletions = synth.make_big_deletions   # (shared with bench.py's lr_stress_10kb_x_20kb row)
 
 
 def test_long_needle_10kb_x_20kb_and_beyond_vs_reference(lr_ctx, reference):

@@ -62,7 +62,7 @@ def two_rank_run(tmp_path_factory):
 def test_two_ranks_started_by_bench_itself_and_counted(two_rank_run):
     line, _ = two_rank_run
     cfg = line["config"]
-    assert line["n_gpus"] == WORLD and cfg["ranks_launched"] == WORLD and cfg["ranks_that_ran_kernels"] == WORLD
+    assert line["n_gpus"] == 1 and cfg["ranks_launched"] == WORLD and cfg["ranks_that_ran_kernels"] == WORLD   # (n_gpus = distinct devices: both ranks drive device 0)
     assert cfg["rccl_ranks"] == WORLD and cfg["gather_transport"] == "hostlink" and cfg["oversubscribed_one_device"] is True
     assert cfg["gathered_records_on_rank0"] == WORLD * N and cfg["shm_return_records_seen_by_rank0"] == WORLD * N
     assert cfg["gather_ms_per_step"] > 0 and cfg["shm_return_gather_ms_per_step"] > 0
