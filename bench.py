@@ -328,6 +328,11 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         if lr and not getattr(ctx, "is_lr", False):  # long-read parameters + orientation test (src/tegua.h:237-241, src/assemble.h:849)
             ctx = refine.Context(params=params, device=device)
             ctx.is_lr = True
+        elif not lr and b.with_msa:
+            # a context of its own for the msa() rows: in THIS process (after the headline leg and the 40 000-junction row with its
+            # stream) the 2 000-junction row measured 2.1 ms per step against 1.6 ms anywhere else -- same kernels, 0.5 ms of idle
+            # time per step that tools/ctx_reuse.py could not reproduce with any one of those ingredients alone (round 5)
+            ctx = refine.Context(params=params, device=device)
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()

@@ -1,4 +1,6 @@
-"""Junction sharding across the GPUs of one node.
+"""TEST-ONLY torch.distributed mirror of the junction sharding / result gather of one node.  The product's
+gather lives in the host library (dellyhip_gather_results, delly_amd/csrc/comm.hpp); this mirror lets the protocol's
+arithmetic -- block partition, padded all-gather, offset rebasing -- run on gloo without a GPU (tests/test_shard_gloo.py).
 
 Junctions are independent (each CPU task of src/shortpe.h:183-197 touches only
 its own svs[svid]), so the path shards by junction index with NO data-path
@@ -8,7 +10,7 @@ records to the rank that emits the VCF.  With torch.distributed the backend
 """
 import numpy as np
 
-from . import abi
+from delly_amd import abi
 
 
 def shard_range(n_total, rank, world):
@@ -21,7 +23,7 @@ def shard_range(n_total, rank, world):
 def shard_by_cost(batch, rank, world, params=None):
     """Cost-balanced junction assignment (dellyhip_shard_by_cost in the host library): indices of the
     junctions rank `rank` refines.  Every rank computes the same assignment from the same junction list."""
-    from . import refine
+    from delly_amd import refine
     owner = refine.shard_by_cost(batch.junctions, batch.seq_off, world, params)
     return np.nonzero(owner == rank)[0]
 

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py / delly_amd.shard --
+"""CPU, world_size 2, gloo: the N>1 path of bench.py / tests/shard_mirror.py --
 junction sharding by index + all-gather of the fixed-size result records --
 reassembles exactly the single-process result.  (The per-rank compute is the
 C oracle here: the product has no CPU path.)"""
@@ -17,8 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, n_total, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import shard, synth
+    import shard_mirror as shard
+    from delly_amd import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,8 +38,10 @@ def _worker(rank, world, port, n_total, out_dir):
 
 def test_two_rank_gather_equals_single_process(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import shard, synth
+    import shard_mirror as shard
+    from delly_amd import synth
     n_total = 37  # odd: ranks hold different counts -> padded gather
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -60,8 +64,10 @@ def test_two_rank_gather_equals_single_process(tmp_path):
 def _job_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import abi, shard, synth
+    import shard_mirror as shard
+    from delly_amd import abi, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,6 +87,7 @@ def _job_worker(rank, world, port, out_dir):
 def test_two_rank_classifier_jobs_equal_single_process(tmp_path):
     """the genotyping rows shard by job index exactly like junctions: block partition + padded all-gather"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
     from delly_amd import synth
     s = socket.socket()
@@ -97,8 +104,10 @@ def test_two_rank_classifier_jobs_equal_single_process(tmp_path):
 def _cost_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import shard, synth
+    import shard_mirror as shard
+    from delly_amd import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -119,8 +128,10 @@ def test_two_rank_cost_sharding_and_gather_of_records_and_blob_bytes(tmp_path):
     """cost-balanced assignment (dellyhip_shard_by_cost) + gather of the records AND the consensus / allele bytes to
     rank 0 (the torch mirror of dellyhip_gather_results): sorted by svid it is the single-process result, byte for byte"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import shard, synth
+    import shard_mirror as shard
+    from delly_amd import synth
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -168,7 +179,7 @@ def test_shard_by_cost_balances_and_is_deterministic():
 
 
 def test_shard_range_partitions():
-    from delly_amd import shard
+    import shard_mirror as shard
     for n in (0, 1, 7, 64, 10001):
         for w in (1, 2, 3, 8):
             seen = []
@@ -183,8 +194,10 @@ def _shm_worker(rank, world, port, n_total, out_dir):
     bench.py --gpus N), rank 0 maps all of them and merges in place -- no collective carries results"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import abi, shard, shmreturn, synth
+    import shard_mirror as shard
+    from delly_amd import abi, shmreturn, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -220,8 +233,10 @@ def _shm_worker(rank, world, port, n_total, out_dir):
 
 def test_two_rank_return_through_shared_memory_segments(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import pyoracle
-    from delly_amd import abi, shard, synth
+    import shard_mirror as shard
+    from delly_amd import abi, synth
     n_total = 29
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
