@@ -331,6 +331,10 @@ struct dellyhip_batch {
   int lazy = 0;                      // stream slot: dense routing of the sparse kernel's leftovers happens at collect time
   bool lazy_pending = false;         // ... and has not happened yet for the current run
   int32_t* pin_cons_len = nullptr;   // stream slot: pinned destination of the consensus lengths (msa() batches)
+  int32_t* own_pin_len = nullptr;    // resident batches: the same, owned by the batch (an asynchronous download into PAGEABLE memory goes
+                                     // through the runtime's staging path and was measured to add 0.5 ms per step in a process that had
+                                     // used several streams before -- bench.py's u_full row after the headline leg, round 5)
+  size_t own_pin_bytes = 0, own_pin_count = 0;
   int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
   int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
@@ -345,6 +349,7 @@ struct dellyhip_batch {
   int lr_teams = 0;                  // teams of lr_dense_team_kernel for this batch (0: none)
   DevBuf<int32_t> lr_team_state;     // dh::LRT_* counters + the list of junctions handed to the teams
   hipEvent_t lr_fork = nullptr, lr_join = nullptr;
+  bool lr_aux_used = false;          // lr_dense_team_kernel of this batch was launched on the context's auxiliary stream
   // long-read insertions (svt 4 beyond the short-read shapes)
   int lri_first = 0, lri_count = 0, lri_blocks = 0;
   dh::LrInsArgs lri{};
@@ -635,9 +640,16 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
     } else if (aux) {   // the teams run beside lr_kernel; the batch's stream goes on when both are through
       HIPCHK(hipStreamWaitEvent(aux, b->lr_fork, 0));
       hipLaunchKernelGGL(dh::lr_dense_team_kernel, dim3(b->lr_teams), dim3(dh::WAVE * dh::LR_TEAM_W), 0, aux, a, lr);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(b->lr_join, aux));
-      HIPCHK(hipStreamWaitEvent(s, b->lr_join, 0));
+      // from here on a failure must not leave the teams running behind the caller's back (they poll the batch's workspace and
+      // team state for up to ten minutes; batch_free / the next run only know the batch's own stream): join before returning
+      hipError_t e1 = hipGetLastError();
+      if (e1 == hipSuccess) e1 = hipEventRecord(b->lr_join, aux);
+      if (e1 == hipSuccess) e1 = hipStreamWaitEvent(s, b->lr_join, 0);
+      if (e1 != hipSuccess) {
+        (void)hipStreamSynchronize(aux);
+        return fail(DELLYHIP_E_RUNTIME, "long-read teams: launch / join", e1);
+      }
+      b->lr_aux_used = true;
     }
   }
   if (b->lri_count > 0 && !direct) {
@@ -1150,6 +1162,17 @@ struct PinBuf {
   }
 };
 
+// the batch's own pinned block for the downloaded consensus lengths (n ints, grown and kept)
+static int batch_pin_len(dellyhip_batch* b) {
+  const size_t want = (size_t)std::max(b->n, 1);
+  if (b->own_pin_len && b->own_pin_count >= want) return 0;
+  if (b->own_pin_len) PinPool::get().give(b->own_pin_len, b->own_pin_bytes);
+  b->own_pin_len = static_cast<int32_t*>(PinPool::get().take((want + want / 4 + 64) * sizeof(int32_t), &b->own_pin_bytes));
+  if (!b->own_pin_len) { b->own_pin_bytes = b->own_pin_count = 0; return fail(DELLYHIP_E_NOMEM, "hipHostMalloc", hipErrorOutOfMemory); }
+  b->own_pin_count = b->own_pin_bytes / sizeof(int32_t);
+  return 0;
+}
+
 // Staging arena of a stream slot: one pinned host block and one device block with the SAME layout.  Everything a batch
 // uploads (junction records, offsets, sequence bytes, work lists) is appended to the host block, the batch's device pointers
 // are borrowed from the device block at the same offsets, and ONE asynchronous copy moves the used prefix.
@@ -1396,9 +1419,14 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!b) return;
   if (c) (void)hipSetDevice(c->device);
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
+  // (a batch run on a caller's stream, or whose run failed after the teams were launched: the batch's workspace and team state
+  //  must not be released while lr_dense_team_kernel may still poll them)
+  if (b->lr_aux_used && c && c->lr_aux) (void)hipStreamSynchronize(c->lr_aux);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
   b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
+  if (b->own_pin_len) PinPool::get().give(b->own_pin_len, b->own_pin_bytes);
+  b->own_pin_len = nullptr;
   if (b->lr_fork) (void)hipEventDestroy(b->lr_fork);
   if (b->lr_join) (void)hipEventDestroy(b->lr_join);
   for (auto e : b->ev) (void)hipEventDestroy(e);
@@ -1745,8 +1773,10 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
       hipLaunchKernelGGL(dh::lrwfa_kernel, dim3(b->wfa_blocks), dim3(dh::WAVE), 0, s, W);
       HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if ((rc = batch_pin_len(b))) return rc;
+    HIPCHK(hipMemcpyAsync(b->own_pin_len, b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    memcpy(b->h_cons_len.data(), b->own_pin_len, (size_t)b->n * sizeof(int32_t));
     // "take care of small inversions" (src/assemble.h:840-848): align only the middle svSize letters
     {
       std::vector<SmallInv> si;
@@ -1809,8 +1839,12 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
       return 0;
     }
     // consensus lengths decide the K bin of the split kernel
-    HIPCHK(hipMemcpyAsync((b->lazy && b->pin_cons_len) ? b->pin_cons_len : b->h_cons_len.data(), b->cons_len.p, b->n * sizeof(int32_t),
-                          hipMemcpyDeviceToHost, s));
+    int32_t* len_dst = (b->lazy && b->pin_cons_len) ? b->pin_cons_len : nullptr;
+    if (!len_dst) {
+      if ((rc = batch_pin_len(b))) return rc;
+      len_dst = b->own_pin_len;
+    }
+    HIPCHK(hipMemcpyAsync(len_dst, b->cons_len.p, b->n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (b->lazy) {
       // stream slot: every junction goes through split_sparse_kernel; what it leaves behind (counters[31]) is routed to the
       // dense kernels when the results are collected (finish_lazy) -- no host synchronisation inside the run
@@ -1829,6 +1863,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     } else {
       HIPCHK(hipStreamSynchronize(s));
     }
+    if (!b->lazy) memcpy(b->h_cons_len.data(), b->own_pin_len, (size_t)b->n * sizeof(int32_t));
     if (!b->lazy && (rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
   }
   if (!ev1_done) HIPCHK(hipEventRecord(e3[1], s));
@@ -1874,6 +1909,14 @@ int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   b->pending = false;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "kernel execution", e);
+  if (b->lr_teams > 0 && b->lr_team_state.p) {
+    // a team of lr_dense_team_kernel that gave up waiting (for its list entry, for lr_kernel, inside its own pipe) leaves junctions
+    // with the "not refined, status 0" record lr_kernel wrote when it deferred them: the batch must not be handed out as good
+    int32_t flag = 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(&flag, b->lr_team_state.p + dh::LRT_ERROR, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) return fail(DELLYHIP_E_RUNTIME, "a long-read team of wavefronts gave up waiting: the junctions it was to sweep are not refined");
+  }
   return 0;
 }
 

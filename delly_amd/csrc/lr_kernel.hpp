@@ -1182,9 +1182,13 @@ __global__ __launch_bounds__(WAVE * LR_TEAM_W) void lr_dense_team_kernel(SplitAr
     process_lr<true>(A, R, j, L, ws, lane, &C);
     DH_SYNC();
     LRT_MARK(9, j);
-    if (rfl(*(volatile int*)&C.bail) && lane == 0) {   // a wait inside the team ran out: the junction's record is not to be trusted
-      A.res[j].status = DELLYHIP_E_RUNTIME;
-      atomicExch(&ts[LRT_ERROR], 1);
+    if (rfl(*(volatile int*)&C.bail)) {   // a wait inside the team ran out: the junction's record is not to be trusted
+      if (lane == 0) {
+        A.res[j].status = DELLYHIP_E_RUNTIME;
+        atomicExch(&ts[LRT_ERROR], 1);
+      }
+      break;   // (the team ends here: its command pipe is in an unknown state.  The flag fails the whole batch on the host,
+               //  dellyhip_batch_sync, so the junctions still on the list are not handed out as "not refined")
     }
   }
   if (lane == 0) { C.cmd = LRC_EXIT; }

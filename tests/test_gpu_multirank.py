@@ -95,6 +95,38 @@ def test_what_rank0_reads_from_both_segments_is_the_reference_answer(two_rank_ru
         compare(rec, blob, rr, rb, fields=CORE, blobs=("cons", "allele"), label="segment of rank %d" % r)
 
 
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="needs two GPUs: RCCL refuses a communicator whose ranks share a device")
+def test_two_ranks_two_devices_rccl(tmp_path, reference):
+    """The product transport with more than one rank: bench.py --gpus 2, one process per GPU, NOT oversubscribed -- the gather
+    runs RcclLink (ncclAllGather of the sizes, grouped ncclSend / ncclRecv of records and blob bytes over xGMI, comm.hpp).  What
+    rank 0 holds after each return path is compared with oracle/_ref like in the one-device test above.  (No box the builder
+    could reach in rounds 1-5 had two GPUs: this test is armed for the driver's multi-GPU node.)"""
+    out = str(tmp_path / "rank0_rccl.npz")
+    p = _bench(["--gpus", str(WORLD), "--steps", str(STEPS), "--warmup", str(WARM), "--junctions", str(N), "--no-cpu-baseline", "--no-extras",
+                "--no-host-inclusive", "--dump-rank0-view", out])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line, view = json.loads(lines[0]), np.load(out)
+    cfg = line["config"]
+    assert line["n_gpus"] == WORLD and cfg["ranks_launched"] == WORLD and cfg["ranks_that_ran_kernels"] == WORLD
+    assert cfg["gather_transport"] == "rccl" and cfg["rccl_ranks"] == WORLD and cfg["oversubscribed_one_device"] is False
+    assert cfg["gathered_records_on_rank0"] == WORLD * N and cfg["shm_return_records_seen_by_rank0"] == WORLD * N
+    idx = (WARM + STEPS) % 2
+    rec, blob = view["rccl_records"], view["rccl_blob"]
+    assert rec.shape[0] == WORLD * N
+    for r in range(WORLD):
+        chroms, b = _rank_batches(r, idx)
+        rr, rb = reference.refine_batch(b, want_alignment=False, n_threads=THREADS)
+        compare(rec[r * N:(r + 1) * N], blob, rr, rb, fields=CORE, blobs=("cons", "allele"), label="RCCL-gathered share of rank %d" % r)
+        compare(view["shm_records_%d" % r], view["shm_blob_%d" % r], rr, rb, fields=CORE, blobs=("cons", "allele"), label="segment of rank %d (two devices)" % r)
+
+
 def test_launcher_contract_world_size_must_match_gpus():
     p = _bench(["--gpus", "2", "--steps", "1"], env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -38,3 +38,13 @@ print("paired passes per junction %.2f; their tracebacks %.1f us per junction (i
 t0 = r["ref_left"].astype(np.int64)
 span = (t0.max() - t0.min()) / 100.0
 print("first..last junction start %.0f us" % span)
+# the slowest junctions: what kind, when did they start, which phase
+order = np.argsort(-tot)[:8]
+for j in order:
+    print("  slow junction %5d kind %-8s start %6.0f us total %6.0f us: lcs %5.0f upgma %4.0f tables %4.0f dp %5.0f emit %4.0f; paired passes %d, leaf merges %d, cells %d, row-steps %d" % (
+        j, b.truth[j]["kind"], (t0[j] - t0.min()) / 100.0, tot[j] / 100, r["c_start"][j] / 100, r["c_end"][j] / 100, r["r_start"][j] / 100, r["r_end"][j] / 100,
+        r["hom_left"][j] / 100, r["ci_wiggle"][j], r["score_best"][j], r["mismatches"][j], r["cons_left"][j]))
+q = np.percentile(tot, [10, 50, 90, 99, 99.9]) / 100
+print("percentiles of the per-junction wavefront time: p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f us" % tuple(q))
+late = t0 - t0.min() > 0.8 * (t0.max() - t0.min())
+print("junctions started in the last fifth of the launch: %d, mean time %.0f us (all: %.0f)" % (late.sum(), tot[late].mean() / 100, tot.mean() / 100))
