@@ -349,7 +349,8 @@ struct dellyhip_batch {
   int lr_teams = 0;                  // teams of lr_dense_team_kernel for this batch (0: none)
   DevBuf<int32_t> lr_team_state;     // dh::LRT_* counters + the list of junctions handed to the teams
   hipEvent_t lr_fork = nullptr, lr_join = nullptr;
-  bool lr_aux_used = false;          // lr_dense_team_kernel of this batch was launched on the context's auxiliary stream
+  bool lr_aux_used = false;          // a kernel of this batch was launched on the context's auxiliary stream
+  hipEvent_t lri_fork = nullptr, lri_join = nullptr;   // lr_ins_kernel beside the dense / insertion kernels (run_split_dense)
   // long-read insertions (svt 4 beyond the short-read shapes)
   int lri_first = 0, lri_count = 0, lri_blocks = 0;
   dh::LrInsArgs lri{};
@@ -527,6 +528,15 @@ int ensure_lr_aux(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!b->lr_fork) HIPCHK(hipEventCreateWithFlags(&b->lr_fork, hipEventDisableTiming));
   if (!b->lr_join) HIPCHK(hipEventCreateWithFlags(&b->lr_join, hipEventDisableTiming));
   if (c->lr_aux) return 0;
+  // ONE auxiliary stream per device and process, found by the first context that needs one: the slots of a dellyhip_stream are
+  // contexts of their own, and every stream a process creates competes for the few hardware queues
+  static std::mutex aux_mu;
+  static std::map<int, hipStream_t> aux_of_device;
+  std::lock_guard<std::mutex> aux_guard(aux_mu);
+  {
+    auto it = aux_of_device.find(c->device);
+    if (it != aux_of_device.end()) { c->lr_aux = it->second; return 0; }
+  }
   int* probe = nullptr;
   const bool can_probe = !getenv("DELLYHIP_STREAM_NO_PROBE") && dh::dev_alloc((void**)&probe, 2 * sizeof(int)) == hipSuccess;
   hipStream_t pick = nullptr;
@@ -540,6 +550,7 @@ int ensure_lr_aux(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!pick && !c->lr_aux_all.empty()) pick = c->lr_aux_all[0];
   if (!pick) return fail(DELLYHIP_E_RUNTIME, "no stream for the long-read teams");
   c->lr_aux = pick;
+  aux_of_device[c->device] = pick;
   return 0;
 }
 
@@ -571,7 +582,46 @@ dh::SplitArgs make_split_args(dellyhip_ctx* c, dellyhip_batch* b, bool direct) {
   return a;
 }
 
+static bool env_on(const char* name) {
+  const char* t = getenv(name);
+  return t && atoi(t) != 0;
+}
+
 int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct, dh::SplitArgs a, bool mid_done) {
+  // Long insertions (svt 4 beyond the short-read shapes: a consensus of 20 reads over a 60-120 bp insertion is 320-420 bp) are
+  // few per batch and take ~0.8 ms each on one wavefront: a latency chain, not a load.  Round 5: lr_ins_kernel starts FIRST, on
+  // the context's auxiliary stream, beside the dense / insertion kernels of the other bins (disjoint junctions, its own
+  // workspace; it must follow the sparse kernel, which rewrites the default record of every junction it is offered) and the
+  // batch's stream joins it at the end: the all-SV-types row of bench.py 2.1 -> 1.4 ms of split stage per 10 000 junctions
+  // (DELLYHIP_LRI_SERIAL=1: on the batch's own stream, after everything else, as before).
+  bool lri_side = false;
+  if (b->lri_count > 0 && !direct && !env_on("DELLYHIP_LRI_SERIAL") && ensure_lr_aux(c, b) == 0 && c->lr_aux != s) {
+    if (!b->lri_fork) HIPCHK(hipEventCreateWithFlags(&b->lri_fork, hipEventDisableTiming));
+    if (!b->lri_join) HIPCHK(hipEventCreateWithFlags(&b->lri_join, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(b->lri_fork, s));
+    HIPCHK(hipStreamWaitEvent(c->lr_aux, b->lri_fork, 0));
+    dh::SplitArgs ai = a;
+    ai.sps_left = nullptr;
+    ai.work_list = b->work.p + b->lri_first;
+    ai.n_work = b->lri_count;
+    const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
+    const int grid = (b->lri_count + rounds - 1) / rounds;
+    dh::LrInsArgs li = b->lri;
+    li.realign = ((c->params.reserved & 1) && b->with_msa != 2) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions
+    hipLaunchKernelGGL(dh::lr_ins_kernel, dim3(grid), dim3(dh::WAVE), 0, c->lr_aux, ai, li);
+    hipError_t e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipEventRecord(b->lri_join, c->lr_aux);
+    if (e1 != hipSuccess) {
+      (void)hipStreamSynchronize(c->lr_aux);
+      return fail(DELLYHIP_E_RUNTIME, "lr_ins_kernel on the auxiliary stream", e1);
+    }
+    b->lr_aux_used = true;
+    lri_side = true;
+  }
+  struct JoinSide {   // every return path below joins the side launch
+    dellyhip_ctx* c; dellyhip_batch* b; hipStream_t s; bool on;
+    ~JoinSide() { if (on && hipStreamWaitEvent(s, b->lri_join, 0) != hipSuccess) (void)hipStreamSynchronize(c->lr_aux); }
+  } join_side{c, b, s, lri_side};
   bool any_bin = false;
   for (int K = 1; K <= dh::KMAX; ++K) {
     int cnt = b->bin_count[K];
@@ -652,7 +702,7 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
       b->lr_aux_used = true;
     }
   }
-  if (b->lri_count > 0 && !direct) {
+  if (b->lri_count > 0 && !direct && !lri_side) {
     a.work_list = b->work.p + b->lri_first;
     a.n_work = b->lri_count;
     const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
@@ -1381,7 +1431,8 @@ void dellyhip_destroy(dellyhip_ctx* c) {
   c->scratch.release();
   c->counters.release();
   if (c->serial_ev) (void)hipEventDestroy(c->serial_ev);
-  for (auto q : c->lr_aux_all) (void)hipStreamDestroy(q);
+  for (auto q : c->lr_aux_all)
+    if (q != c->lr_aux) (void)hipStreamDestroy(q);   // (the one that was picked serves every context of the device until the process ends)
   if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1429,6 +1480,8 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   b->own_pin_len = nullptr;
   if (b->lr_fork) (void)hipEventDestroy(b->lr_fork);
   if (b->lr_join) (void)hipEventDestroy(b->lr_join);
+  if (b->lri_fork) (void)hipEventDestroy(b->lri_fork);
+  if (b->lri_join) (void)hipEventDestroy(b->lri_join);
   for (auto e : b->ev) (void)hipEventDestroy(e);
   for (auto e : b->ev_free) (void)hipEventDestroy(e);
   if (b->len_ev) (void)hipEventDestroy(b->len_ev);
