@@ -326,6 +326,8 @@ struct dellyhip_batch {
   // msa() batches: the sparse kernel runs on every non-insertion junction straight behind the MSA kernels (it reads the
   // consensus lengths on the device) while the host routes the batch from the downloaded lengths
   DevBuf<int32_t> early_list;
+  DevBuf<int32_t> msa_order;         // msa() batches whose junctions differ in cost: the order the MSA kernels take them in (most expensive first)
+  bool msa_ordered = false;
   int early_count = 0;
   bool early_done = false;           // this run: split_sparse_kernel has been launched already
   int lazy = 0;                      // stream slot: dense routing of the sparse kernel's leftovers happens at collect time
@@ -1475,7 +1477,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->lr_aux_used && c && c->lr_aux) (void)hipStreamSynchronize(c->lr_aux);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->msa_order.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
   if (b->own_pin_len) PinPool::get().give(b->own_pin_len, b->own_pin_bytes);
   b->own_pin_len = nullptr;
   if (b->lr_fork) (void)hipEventDestroy(b->lr_fork);
@@ -1731,6 +1733,28 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       // case (a node of the standard instance growing beyond its 512 columns)
       b->msa_big_grid = mp.big_count > 0 ? std::min(mp.big_count, c->n_cu * 2) : std::min(std::max(n, 1), 8);
       if ((rc = b->msa_big_ws.reserve(std::max<uint64_t>(1, mp.big_ws_stride * (uint64_t)b->msa_big_grid)))) return bail(rc);
+      {
+        // Longest-processing-time first: a junction of 20 reads costs ~15x one of 5 (pairs x length^2 + merges x length^2), and
+        // a long one that starts last IS the tail of the launch.  Junctions are independent (src/shortpe.h:183-197: every task
+        // writes only its own record), so the order the kernel takes them in is free.  Skipped when all cost the same.
+        std::vector<std::pair<uint64_t, int32_t>> cost(n);
+        uint64_t lo = ~0ull, hi = 0;
+        for (int i = 0; i < n; ++i) {
+          const uint64_t nr = (uint64_t)std::max(junc[i].n_seq, 0);
+          const uint64_t len = nr ? (seq_off[junc[i].seq_first + nr] - seq_off[junc[i].seq_first]) / nr : 0;
+          const uint64_t cst = (nr * (nr - (nr ? 1 : 0)) / 2 + 6 * nr) * len * len;
+          cost[i] = {cst, i};
+          lo = std::min(lo, cst);
+          hi = std::max(hi, cst);
+        }
+        b->msa_ordered = n > 1 && hi > lo + lo / 8 && !getenv("DELLYHIP_MSA_NO_ORDER");
+        if (b->msa_ordered) {
+          std::stable_sort(cost.begin(), cost.end(), [](const std::pair<uint64_t, int32_t>& x, const std::pair<uint64_t, int32_t>& y) { return x.first > y.first; });
+          std::vector<int32_t> order(n);
+          for (int i = 0; i < n; ++i) order[i] = cost[i].second;
+          if ((rc = push(b->msa_order, order.data(), order.size(), 0, "H2D msa order"))) return bail(rc);
+        }
+      }
       if (c->sr_sparse && !(c->params.reserved & 1)) {   // (long-read parameters route every junction to the strip kernel)
         std::vector<int32_t> el;
         for (int i = 0; i < n; ++i)
@@ -1875,6 +1899,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     ma.defer_counter = c->counters.p + 8;
     ma.tmax = dh::msa_tmax(c->params, c->msa_tmax);
     ma.pair = c->msa_pair;
+    ma.order = b->msa_ordered ? b->msa_order.p : nullptr;
     if ((rc = dh::msa_launch(ma, b->msa_grid, b->msa_plan.nmax, s, b->msa_big_ws.p, b->msa_plan.big_ws_stride, b->msa_big_grid,
                              b->msa_plan.big_nmax, b->msa_team)))
       return fail(rc, "msa_launch");

@@ -65,6 +65,7 @@ struct MsaArgs {
   int32_t* defer_counter; // junctions handed to the direct-float kernel
   int32_t* big_counter;   // junctions beyond the limits of the standard instance (-> msa_big kernel); may be null
   int32_t out_cons_cap;   // bytes of the consensus slot at out_blob + j*out_stride
+  const int32_t* order;   // the junction the w-th claim of the work counter gets (most expensive first), or null: junction w
   int32_t pair;           // 1: two merges of a junction share a Gotoh pass where they fit (gotoh_pass_pair); 0: one merge per pass
   // single-item gotoh mode (dellyhip_gotoh): two given alignments
   const uint8_t* g_a1;
