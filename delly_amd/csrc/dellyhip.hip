@@ -289,6 +289,9 @@ struct dellyhip_ctx {
   std::vector<hipStream_t> lr_aux_all;
   int sps_waves = 16;        // wavefronts of split_sparse_kernel per CU (env DELLYHIP_SPS_WAVES; 16 = what LDS and registers allow)
   int sr_sparse = 1;         // short-read shapes through split_sparse_kernel first (env DELLYHIP_SR_SPARSE=0: dense kernels only)
+  int sr_wide = 1;           // ... and the shapes beyond its byte tile through split_sparse_wide_kernel (env DELLYHIP_SR_WIDE=0: dense kernels, A/B)
+  DevBuf<uint32_t> spw_scratch;   // its per-block tables (allocated at first use)
+  int spw_blocks = 0;
   int sparse_cost = 160;     // predicted deficit up to which the sparse passes go on (env DELLYHIP_SPARSE_COST; tuning)
   int use_sparse = 1;        // sparse (furthest-reaching) longNeedle in the strip kernel (env DELLYHIP_SPARSE=0: dense passes only)
   int use_quad = 1;          // four junctions per wavefront where they fit (env DELLYHIP_QUAD=0: packed pairs only)
@@ -338,6 +341,8 @@ struct dellyhip_batch {
                                      // used several streams before -- bench.py's u_full row after the headline leg, round 5)
   size_t own_pin_bytes = 0, own_pin_count = 0;
   int sps_first = 0, sps_count = 0;  // junctions split_sparse_kernel tries first (they also sit in a dense bin)
+  int spw_first = 0, spw_count = 0;  // ... and those beyond its byte tile that split_sparse_wide_kernel tries first (they sit in a dense bin too)
+  bool sr_wide = false;
   int sr_sparse = 1;
   // four-junctions-per-wavefront bins (|consensus| <= 159): work[qbin_first[Kq] .. ) holds 4 indices per item
   std::vector<int32_t> qbin_first, qbin_count, qbin_pairs;   // per KQ: offset, quad items, pair items behind them
@@ -481,6 +486,23 @@ void launch_quad(dh::SplitArgs a, int n_quads, int n_pairs, int max_blocks, int3
 dh::SplitArgs make_split_args(dellyhip_ctx* c, dellyhip_batch* b, bool direct);
 int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct, dh::SplitArgs a, bool mid_done);
 
+// split_sparse_wide_kernel over a list, behind split_sparse_kernel on the same stream (counted: see the kernel)
+int launch_sparse_wide(dellyhip_ctx* c, dh::SplitArgs a, const int32_t* list, int count, int counted, hipStream_t s) {
+  if (count <= 0) return 0;
+  if (!c->spw_scratch.p) {
+    c->spw_blocks = std::max(64, std::min(512, c->n_cu * 2));
+    int rc = c->spw_scratch.alloc((size_t)(dh::spw_scratch_bytes() / 4) * c->spw_blocks);
+    if (rc) return rc;
+  }
+  a.work_list = list;
+  a.n_work = count;
+  a.work_counter = nullptr;
+  hipLaunchKernelGGL(dh::split_sparse_wide_kernel, dim3(std::min(count, c->spw_blocks)), dim3(dh::WAVE), 0, s, a, c->spw_scratch.p,
+                     (uint64_t)(dh::spw_scratch_bytes() / 4), counted);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // msa() batches: split_sparse_kernel on every non-insertion junction, enqueued straight behind the MSA kernels
 int launch_early_sparse(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s) {
   int rc;
@@ -493,6 +515,9 @@ int launch_early_sparse(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s) {
   hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->early_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
   HIPCHK(hipGetLastError());
   if (b->mid) HIPCHK(hipEventRecord(b->mid, s));
+  // (the consensus lengths are still on the device: the wide kernel looks at every junction the first one left and takes
+  //  those whose shape was beyond it)
+  if (b->sr_wide && (rc = launch_sparse_wide(c, a, b->early_list.p, b->early_count, 1, s))) return rc;
   b->early_done = true;
   return 0;
 }
@@ -517,8 +542,13 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.sps_left = c->counters.p + 31;
     hipLaunchKernelGGL(dh::split_sparse_kernel, dim3(std::min({b->sps_count, c->scratch_blocks, c->n_cu * c->sps_waves})), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
-    if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to the sparse kernel
+    if (b->spw_count > 0 && (rc = launch_sparse_wide(c, a, b->work.p + b->spw_first, b->spw_count, 0, s))) return rc;
+    if (!b->sps_all) a.sps_left = nullptr;   // some junction of the dense bins was never offered to a sparse kernel
     else if (b->mid) { HIPCHK(hipEventRecord(b->mid, s)); mid_done = true; }   // dp_kernel_ms = the sparse kernel (the dominant one)
+  } else if (b->spw_count > 0 && !direct) {   // (no junction for the byte-tile kernel at all)
+    a.sps_left = c->counters.p + 31;
+    if ((rc = launch_sparse_wide(c, a, b->work.p + b->spw_first, b->spw_count, 0, s))) return rc;
+    a.sps_left = nullptr;
   }
   return run_split_dense(c, b, s, direct, a, mid_done);
 }
@@ -750,9 +780,14 @@ int host_window_len(const dellyhip_params& P, const dellyhip_junction& J, int m,
 
 // long-read kernels: shapes beyond the short-read limits, and every junction when the orientation test
 // (realign, src/split.h:564-572) is requested -- only they implement it
+// Short-read junctions beyond what the sparse kernel's byte tile holds (consensus 255 .. 319 bp, windows 1281 .. 2048) have two
+// homes: the packed dense kernels (~1 ms for a handful of junctions: a latency chain) and the strip kernel, whose own
+// sparse passes take int16 tables.  DELLYHIP_LR_FROM_M / DELLYHIP_LR_FROM_N move the border (svt 4 keeps the insertion kernels).
+static int lr_from_m() { static const int v = [] { const char* t = getenv("DELLYHIP_LR_FROM_M"); return t ? std::max(1, atoi(t)) : dh::MMAX + 1; }(); return v; }
+static int lr_from_n() { static const int v = [] { const char* t = getenv("DELLYHIP_LR_FROM_N"); return t ? std::max(1, atoi(t)) : dh::NMAX + 1; }(); return v; }
 bool is_lr_shape(const dellyhip_params& P, const dellyhip_junction& J, int m, int n) {
-  (void)J;
-  return (P.reserved & 1) || m > dh::MMAX || n > dh::NMAX;
+  if ((P.reserved & 1) || m > dh::MMAX || n > dh::NMAX) return true;
+  return J.svt != 4 && (m >= lr_from_m() || n >= lr_from_n());
 }
 
 // Long-read workspaces are per resident wavefront and grow with the product of the batch's longest consensus and
@@ -928,7 +963,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL,
   b->qbin_first.assign(7, 0);
   b->qbin_count.assign(7, 0);
   b->qbin_pairs.assign(7, 0);
-  std::vector<int32_t> ins, lrv, lriv, sparse;
+  std::vector<int32_t> ins, lrv, lriv, sparse, wide;
   const bool direct = b->ref_blob.p != nullptr;
   for (int i = 0; i < b->n; ++i) {
     int m = b->h_cons_len[i];
@@ -953,6 +988,9 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL,
     if (!b->h_win_len.empty()) approx = b->h_win_len[i];
     const bool eligible = b->sr_sparse && !direct && m >= 1 && m <= dh::SPS_MMAX && approx <= dh::SPS_NMAX && approx + m + 1 <= dh::SPS_ND;
     if (eligible && mode != BINS_LEFTOVER) sparse.push_back(i);
+    // (beyond the byte tile, within the dense kernels' shapes: split_sparse_wide_kernel first; like the sparse list these
+    //  junctions keep their seat in a dense bin, whose kernels skip what is finished)
+    if (!eligible && b->sr_sparse && b->sr_wide && !direct && m >= 1 && m <= dh::MMAX && approx <= dh::NMAX && mode != BINS_LEFTOVER) wide.push_back(i);
     if ((mode == BINS_LAZY && eligible) || (mode == BINS_LEFTOVER && !eligible)) continue;
     if (b->use_quad && !direct && m + 1 <= dh::HALF * 5 && approx <= dh::QNMAX) {
       const int kq = std::max(1, (m + 1 + dh::HALF - 1) / dh::HALF);
@@ -1040,9 +1078,12 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL,
     for (auto& v : bins) dense += v.size();
     for (auto& v : qbins) dense += v.size();
     for (auto& v : qextra) dense += v.size();
-    b->sps_all = mode == BINS_ALL && !sparse.empty() && sparse.size() == dense;
+    b->sps_all = mode == BINS_ALL && !sparse.empty() && sparse.size() + wide.size() == dense;   // (every seat was offered to one of the two sparse kernels)
   }
   work.insert(work.end(), sparse.begin(), sparse.end());
+  b->spw_first = (int)work.size();
+  b->spw_count = (int)wide.size();
+  work.insert(work.end(), wide.begin(), wide.end());
   if (work_out) {
     work_out->swap(work);
     return 0;
@@ -1267,7 +1308,7 @@ void batch_reset(dellyhip_batch* b) {
   b->out_stride = 0;
   b->out_cons_cap = dh::OUT_CONS_CAP; b->out_allele_cap = dh::OUT_ALLELE_CAP; b->out_aln_cap = dh::OUT_ALN_CAP;
   b->bin_first.clear(); b->bin_count.clear(); b->qbin_first.clear(); b->qbin_count.clear(); b->qbin_pairs.clear();
-  b->ins_first = b->ins_count = 0; b->sps_all = false; b->early_count = 0; b->early_done = false; b->sps_first = b->sps_count = 0;
+  b->ins_first = b->ins_count = 0; b->sps_all = false; b->early_count = 0; b->early_done = false; b->sps_first = b->sps_count = 0; b->spw_first = b->spw_count = 0;
   b->lr_first = b->lr_count = b->lr_blocks = 0; b->lri_first = b->lri_count = b->lri_blocks = 0;
   b->wfa_items = 0; b->wfa_pair_grid = 1; b->wfa_count = b->wfa_blocks = 0; b->small_inv_n = 0;
   b->lm_hbuf_half = 0; b->lm_pair_grid = 1; b->lm_items = b->lm_blocks = 0;
@@ -1368,6 +1409,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_MSA_WAVES")) c->msa_waves = std::max(1, std::min(16, atoi(t)));
   if (const char* t = getenv("DELLYHIP_MSA_TEAM")) c->msa_team = atoi(t);
   if (const char* t = getenv("DELLYHIP_MSA_PAIR")) c->msa_pair = atoi(t) != 0;
+  if (const char* t = getenv("DELLYHIP_SR_WIDE")) c->sr_wide = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MSA_TMAX")) c->msa_tmax = std::max(0, std::min(atoi(t), (int)dh::TMAXC));  // tuning / test knob
   if (borrowed) {
     c->stream = borrowed;
@@ -1431,6 +1473,7 @@ void dellyhip_destroy(dellyhip_ctx* c) {
   c->d_chr_ptr.release();
   c->d_chr_len.release();
   c->scratch.release();
+  c->spw_scratch.release();
   c->counters.release();
   if (c->serial_ev) (void)hipEventDestroy(c->serial_ev);
   for (auto q : c->lr_aux_all)
@@ -1525,6 +1568,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   b->use_quad = c->use_quad;
   b->quad_mix = c->quad_mix;
   b->sr_sparse = c->sr_sparse;
+  b->sr_wide = c->sr_wide != 0;
   b->n_simd = c->n_cu * 4;
   b->h_junc.assign(junc, junc + n);
   int lr_m = 0, lr_n = 0, lr_cnt = 0, lri_m = 0, lri_n = 0, lri_cnt = 0;
@@ -2769,7 +2813,7 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
     S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
     S.ctx->lr_waves = c->lr_waves; S.ctx->lr_teams = c->lr_teams; S.ctx->lr_team_serial = c->lr_team_serial; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
-    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team; S.ctx->msa_pair = c->msa_pair;
+    S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team; S.ctx->msa_pair = c->msa_pair; S.ctx->sr_wide = c->sr_wide;
   }
   *out = st.release();
   return 0;

@@ -193,4 +193,130 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
   }
 }
 
+
+// ---- the same for the short-read shapes beyond the byte tile (round 5) ------------------------------------------------------
+// split_sparse_kernel stops at a 254 bp consensus (rows in a byte) and 1 280 window letters.  A consensus of 20 reads over an
+// insertion-free junction is 200-320 bp, mixed SV types have windows up to 4 |consensus|: in BASELINE's "all SV types" batch one
+// junction in seven fell to the packed dense kernels, and a HANDFUL of junctions there costs the step the ~1 ms a dense
+// wavefront takes (a latency chain: DESIGN.md 0).  This kernel runs the general form of the sparse longNeedle -- int16 rows,
+// tiles of 960 diagonals with a halo, tables in the wavefront's HBM workspace: what the strip kernel of lr_kernel.hpp runs,
+// with the four strings in LDS -- on every shape the dense kernels take (consensus <= 319, window <= 2 048), one junction
+// per wavefront, and what it does not resolve within 32 levels still goes to the dense kernels.
+constexpr int SPW_SMAX = 32;
+constexpr int SPW_LIST = 2048;
+constexpr int SPW_NDP = (NMAX + MMAX + 2 + 63) & ~63;
+typedef SpTileT<960, 0, int16_t, 2> SpwTile;
+
+struct __attribute__((aligned(16))) StrLdsW {
+  static constexpr bool has_rc = true;
+  static constexpr int ref_cap = NMAX;
+  static constexpr int cons_cap = MMAX + 9;
+  uint8_t cons[MMAX + 9];
+  uint8_t rcons[MMAX + 9];
+  uint8_t ref[NMAX];
+  uint8_t rref[NMAX + 16];   // (+ slack: the compares read 8 letters from any position <= n)
+};
+struct __attribute__((aligned(16))) SpwLds {
+  StrLdsW s;
+  union {
+    PostLdsS p;
+    SpwTile t;
+  } u;
+  int16_t reachF[SPW_SMAX + 2], reachR[SPW_SMAX + 2];
+};
+
+__host__ __device__ inline uint64_t spw_scratch_bytes() {
+  return 4ull * SPW_LIST * 4 + 2ull * (SPW_SMAX + 1) * SPW_NDP * 2 + 2ull * (SPW_SMAX + 1) * (MMAX + 1) * 4 + 256;
+}
+__host__ __device__ inline bool sps_narrow_shape(int m, int n) { return m >= 1 && m <= SPS_MMAX && n <= SPS_NMAX && n + m + 1 <= SPS_ND; }
+
+// 0: not this kernel's junction (finished already, or a shape split_sparse_kernel was offered), 1: finished, 2: left to the dense kernels
+__device__ __forceinline__ int process_sparse_wide(const SplitArgs& A, int j, SpwLds& L, uint32_t* scratch, int lane) {
+  if (A.res[j].reserved == SPS_DONE) return 0;
+  JCtx X;
+  const int prior = A.res[j].status;
+  junction_setup<KMAX, true, StrLdsW, false, true>(A, j, L.s, X, lane);
+  if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
+    const int st = X.out->status;
+    const bool final = st == 0;
+    if (lane == 0 && final) X.out->reserved = SPS_DONE;
+    if (lane == 0 && st != 0 && prior == 0) X.out->status = 0;   // (a limit of THIS kernel's buffers only: the dense kernels start afresh)
+    return final ? 1 : 2;
+  }
+  const int m = X.m, n = X.n;
+  if (m < 1 || n < 1 || m > MMAX || n > NMAX) return 2;
+  if (sps_narrow_shape(m, n)) return 0;   // (split_sparse_kernel had it: what it left needs more than 32 levels, or has unclean letters)
+  if (X.dirty) return 2;
+  SparseWs W;
+  W.ndp = (n + m + 2 + 63) & ~63;
+  W.smax = SPW_SMAX;
+  W.pred_cap = 1 << 20;
+  W.runs_cap = SPW_LIST;
+  uint8_t* sp = reinterpret_cast<uint8_t*>(scratch);
+  W.runsF = reinterpret_cast<int32_t*>(sp);
+  W.runsR = W.runsF + SPW_LIST;
+  W.listF = W.runsR + SPW_LIST;
+  W.listR = W.listF + SPW_LIST;
+  sp += 4ull * SPW_LIST * 4;
+  W.frF = reinterpret_cast<int16_t*>(sp);
+  W.frR = W.frF + (size_t)(SPW_SMAX + 1) * W.ndp;
+  W.cF = reinterpret_cast<int32_t*>(W.frR + (size_t)(SPW_SMAX + 1) * W.ndp);
+  W.cR = W.cF + (size_t)(SPW_SMAX + 1) * (m + 1);
+  __syncthreads();
+  const SparseRes sr = sparse_long_needle<SpwTile, true>(L.s.cons, L.s.rcons, L.s.ref, L.s.rref, m, n, W, L.u.t, L.reachF, L.reachR, 8, lane);
+  __syncthreads();
+  if (!sr.resolved) return 2;
+  if (lane == 0) {
+    X.out->score_unsplit = sr.unsplit;
+    X.out->score_best = sr.best;
+    X.out->cons_left = sr.found ? sr.consLeft : 0;
+    X.out->ref_left = sr.found ? sr.refLeft : 0;
+    X.out->ref_right = sr.found ? sr.refRight : n;
+  }
+  X.consLeft = sr.found ? sr.consLeft : 0;
+  X.refLeft = sr.found ? sr.refLeft : 0;
+  X.refRight = sr.found ? sr.refRight : 0;
+  X.consRight = m - X.consLeft;
+  X.go = sr.found != 0;
+  int Ltot = 0, posC = 0, pre_ma = -1, pre_mm = -1;
+  if (sr.found) {
+    const int gapref = (n - sr.refRight) - sr.refLeft;
+    if (A.want_alignment) {
+      Ltot = sparse_masks_t(L.u.p, RunsMem{W.runsF}, sr.nrunsF, RunsMem{W.runsR}, sr.nrunsR, gapref, MASKW, lane, posC,
+                            [](PostLdsS& l, int pos, int cnt, unsigned long long v, unsigned long long r, int ln) { mask_append(l, pos, cnt, v, r, ln); });
+      masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
+    } else {
+      int both = 0;
+      Ltot = sparse_masks_counts_t(L.u.p, RunsMem{W.runsF}, sr.nrunsF, RunsMem{W.runsR}, sr.nrunsR, gapref, MASKW, lane, posC, both);
+      pre_mm = rfl(sr.mmF + sr.mmR);
+      pre_ma = rfl(both) - pre_mm;
+    }
+  }
+  X.uniformize();
+  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm, true);
+  if (lane == 0) X.out->reserved = SPS_DONE;
+  return 1;
+}
+
+// counted != 0: every junction of the list was offered to split_sparse_kernel before, which counted what it left in *sps_left
+// (msa() batches: the lengths are not known on the host when the sparse kernels are enqueued) -- a junction finished here is
+// taken off that count; counted == 0: the list holds junctions that kernel never saw -- what is left HERE is added.
+__global__ __launch_bounds__(WAVE, 3) void split_sparse_wide_kernel(SplitArgs A, uint32_t* wscratch, uint64_t wwords, int counted) {
+  __shared__ SpwLds L;
+  const int lane = threadIdx.x;
+  uint32_t* scratch = wscratch + (size_t)blockIdx.x * wwords;
+  for (int w = (int)blockIdx.x; w < A.n_work; w += (int)gridDim.x) {
+    const int j = A.work_list[w];
+    if (j < 0) continue;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int r = process_sparse_wide(A, j, L, scratch, ln);
+    if (lane == 0 && A.sps_left) {
+      if (counted && r == 1) atomicSub(A.sps_left, 1);
+      if (!counted && r == 2) atomicAdd(A.sps_left, 1);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace dh
