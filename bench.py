@@ -52,6 +52,11 @@ SIDE_PLAN = (("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
              # chromosome, insertions through splitAlign), 2 .. 20 reads per junction: msa + alignConsensus
              ("sr_stage_mixed_all_svt", 10000, 2000, dict(mode="allsvt", n_reads=(2, 20))),
              ("ins_svt4", 5000, 5000, dict(mode="ins")),
+             # The order matters, for reasons the builder could not isolate (tools/ctx_reuse.py, ctx_reuse2.py reproduce nothing): rows of
+             # short kernels measured AFTER this row and its five-slot stream lose ~0.5 ms per step (u_full_n20: 2.1 instead of 1.6 ms,
+             # same kernel times), and this row measured after ALL the long-read rows reads 41 instead of 53 M/s.  So: the short
+             # msa() rows first, then this one, then the long-read rows (tens of milliseconds per step: not sensitive).
+             ("u_c2_40k_junctions", 40000, 0, dict(mode="c2")),
              ("lr_c4_align_consensus", 2048, 128, dict(mode="lr", sub_rate=0.01)),
              ("lr_c4_msaedlib_n15", 768, 64, dict(mode="lr", n_reads=15, sub_rate=0.06)),
              # INS 800 bp, 15 reads of ~3.8 kb at 6 % error: msaWfa + alignConsensus (splitAlign)
@@ -63,11 +68,7 @@ SIDE_PLAN = (("u_full_n20", 2000, 2000, dict(mode="c2", n_reads=20)),
              # junction's latency, these show the throughput with every wavefront slot busy): four tiles of the row's batch, one step
              ("lr_c4_align_consensus_8k", 8192, 0, dict(mode="lr", sub_rate=0.01, _tiles=4, _steps=1, _no_stream=True)),
              ("lr_c4_msaedlib_n15_3k", 3072, 0, dict(mode="lr", n_reads=15, sub_rate=0.06, _tiles=4, _steps=1, _no_stream=True)),
-             ("lr_ins_msawfa_n15_2k", 2048, 0, dict(mode="lrins", n_reads=15, sub_rate=0.06, _tiles=4, _steps=1, _no_stream=True)),
-             # LAST: in the process that has run this row and its five-slot stream (2 GB of staging blocks), the short msa() rows
-             # measured 0.5 ms more per step with the same kernel times -- 2.1 instead of 1.6 ms at 2 000 junctions -- which
-             # tools/ctx_reuse2.py could not reproduce outside bench.py; the order of the side rows is free, so the big one goes last
-             ("u_c2_40k_junctions", 40000, 0, dict(mode="c2")))
+             ("lr_ins_msawfa_n15_2k", 2048, 0, dict(mode="lrins", n_reads=15, sub_rate=0.06, _tiles=4, _steps=1, _no_stream=True)))
 SIDE_PLAN_BIG = ()   # (round 4 kept the chip-filling rows out of the default run; they are tiles now and part of it)
 
 
@@ -335,6 +336,8 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
             ctx = ctx_lr
         else:
             ctx = ctx_sr
+        if os.environ.get("BENCH_TRIM_BETWEEN_ROWS"):
+            ctx.trim_memory()
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()

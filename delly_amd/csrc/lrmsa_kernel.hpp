@@ -54,37 +54,28 @@ struct __attribute__((aligned(16))) LrMsaLds {
   uint64_t roff[LM_NR];
 };
 
-// index of a letter in the extended-IUPAC equality relation of msaEdlib (src/assemble.h:425), -1 = none
+// index of a letter in the extended-IUPAC equality relation of msaEdlib (src/assemble.h:425), -1 = none:
+//   A 0, C 1, G 2, T 3, '-' 4, M 5, R 6, W 7, B 8, S 9, Y 10, D 11, K 12, E 13, F 14
+// Round 5: nibble tables in 64-bit constants instead of a `switch` -- hipcc compiles a switch over per-lane letters (like the
+// comparison chain of letter_code(), msa_kernel.hpp) into a tree of divergent branches, tens of scalar instructions per letter in
+// the mask set-up of every bit-vector pass.
 __device__ __forceinline__ int iupac_index(int c) {
-  switch (c) {
-    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case '-': return 4;
-    case 'M': return 5; case 'R': return 6; case 'W': return 7; case 'B': return 8; case 'S': return 9;
-    case 'Y': return 10; case 'D': return 11; case 'K': return 12; case 'E': return 13; case 'F': return 14;
-    default: return -1;
-  }
+  const uint32_t idx = (uint32_t)c - (uint32_t)'A';
+  const unsigned long long tbl = (idx & 16u) ? 0xfffffffaf7ff396full : 0xfff5fcfff2edb180ull;
+  const int v = (int)((tbl >> (4u * (idx & 15u))) & 15ull);
+  const int r = (idx < 32u && v != 15) ? v : -1;
+  return (c == '-') ? 4 : r;
 }
 // bit y of iupac_partners(x): letters x and y are declared equal (symmetric closure of the 20 pairs)
+//            A        C        G        T        -
+// M={A,C} R={A,G} W={A,T} B={A,-} S={C,G} Y={C,T} D={C,-} K={G,T} E={G,-} F={T,-}
+// (A ~ M R W B, C ~ M S Y D, G ~ R S K E, T ~ W Y K F, - ~ B D E F; a pair letter ~ its two members): 16-bit entries, four per constant
 __device__ __forceinline__ uint32_t iupac_partners(int x) {
-  //            A        C        G        T        -
-  // M={A,C} R={A,G} W={A,T} B={A,-} S={C,G} Y={C,T} D={C,-} K={G,T} E={G,-} F={T,-}
-  switch (x) {
-    case 0: return (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8);      // A ~ M R W B
-    case 1: return (1u << 5) | (1u << 9) | (1u << 10) | (1u << 11);    // C ~ M S Y D
-    case 2: return (1u << 6) | (1u << 9) | (1u << 12) | (1u << 13);    // G ~ R S K E
-    case 3: return (1u << 7) | (1u << 10) | (1u << 12) | (1u << 14);   // T ~ W Y K F
-    case 4: return (1u << 8) | (1u << 11) | (1u << 13) | (1u << 14);   // - ~ B D E F
-    case 5: return (1u << 0) | (1u << 1);
-    case 6: return (1u << 0) | (1u << 2);
-    case 7: return (1u << 0) | (1u << 3);
-    case 8: return (1u << 0) | (1u << 4);
-    case 9: return (1u << 1) | (1u << 2);
-    case 10: return (1u << 1) | (1u << 3);
-    case 11: return (1u << 1) | (1u << 4);
-    case 12: return (1u << 2) | (1u << 3);
-    case 13: return (1u << 2) | (1u << 4);
-    case 14: return (1u << 3) | (1u << 4);
-    default: return 0u;
-  }
+  const uint32_t ux = (uint32_t)x;
+  const uint32_t w = ux >> 2;
+  const unsigned long long tbl = (w == 0u) ? 0x548032400e2001e0ull : (w == 1u) ? 0x0009000500036900ull : (w == 2u) ? 0x0012000a00060011ull : 0x000000180014000cull;
+  const uint32_t v = (uint32_t)((tbl >> (16u * (ux & 3u))) & 0xffffull);
+  return (ux < 15u) ? v : 0u;
 }
 
 // Unit-cost strip pass with the equality relation.  Target letter of global slot g = q*320 + ls
