@@ -1010,15 +1010,17 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
       for (int step = 1; step < nsel && !status; ++step) {
         // consensusEdlib (:198-259)
         for (int col = lane; col < acols; col += WAVE) {
-          int count[5] = {0, 0, 0, 0, 0};
+          // (the five counts as bytes of one word, the letter's slot from a nibble table: an if-else chain over per-lane letters is a tree of
+          //  divergent branches; rows <= 255)
+          unsigned long long packed = 0ull;
           for (int r = 0; r < arows; ++r) {
             const uint8_t ch = cur[(size_t)r * acap + col];
-            if (ch == 'A' || ch == 'a') ++count[0];
-            else if (ch == 'C' || ch == 'c') ++count[1];
-            else if (ch == 'G' || ch == 'g') ++count[2];
-            else if (ch == 'T' || ch == 't') ++count[3];
-            else ++count[4];
+            const int v = letter_code_bf((uint8_t)(ch & 0xDF));   // A/a 0, C/c 1, G/g 2, T/t 3; N/n, '-' and everything else: slot 4
+            packed += 1ull << (8 * ((v < 0) ? 4 : v));
           }
+          int count[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) count[i] = (int)((packed >> (8 * i)) & 0xffull);
           int maxIdx = 0, sndIdx = 1;
           if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
 #pragma unroll

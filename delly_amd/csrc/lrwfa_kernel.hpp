@@ -47,7 +47,10 @@ struct LrWfaArgs {
 };
 
 __device__ __forceinline__ uint32_t wfa_char_to_int(uint8_t c) {   // charToInt, assemble.h:475-498
-  return (c == 'A' || c == 'B') ? 0u : (c == 'C' || c == 'D') ? 1u : (c == 'G' || c == 'E') ? 2u : (c == 'T' || c == 'F') ? 3u : 0u;
+  // A, B -> 0; C, D -> 1; G, E -> 2; T, F -> 3; anything else 0: a 2-bit table over 'A' .. 'A' + 31 in one 64-bit constant (the
+  // chain of comparisons compiles to divergent branches, eleven letters per k-mer and a k-mer per read position)
+  const uint32_t idx = (uint32_t)c - (uint32_t)'A';
+  return (idx < 32u) ? (uint32_t)((0xc000002e50ull >> (2u * idx)) & 3ull) : 0u;
 }
 __device__ __forceinline__ uint32_t wfa_hash(const uint8_t* s, int p) {
   uint32_t h = 0;
@@ -442,17 +445,18 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         }
         __syncthreads();
         for (int col = lane; col < acols; col += WAVE) {
-          int count[5] = {0, 0, 0, 0, 0};
+          // (the five counts as bytes of one word, the letter's slot from a nibble table: an if-else chain over per-lane letters is a tree
+          //  of divergent branches; rows <= 255)
+          unsigned long long packed = 0ull;
           for (int r = 0; r < arows; ++r) {
-            if (col >= L.first[r] && col <= L.last[r]) {
-              const uint8_t ch = cur[(size_t)r * acap + col];
-              if (ch == 'A' || ch == 'a') ++count[0];
-              else if (ch == 'C' || ch == 'c') ++count[1];
-              else if (ch == 'G' || ch == 'g') ++count[2];
-              else if (ch == 'T' || ch == 't') ++count[3];
-              else ++count[4];
-            }
+            const uint8_t ch = cur[(size_t)r * acap + col];
+            const int v = letter_code_bf((uint8_t)(ch & 0xDF));   // A/a 0, C/c 1, G/g 2, T/t 3; N/n, '-' and everything else: slot 4
+            const unsigned long long one = (col >= L.first[r] && col <= L.last[r]) ? 1ull : 0ull;
+            packed += one << (8 * ((v < 0) ? 4 : v));
           }
+          int count[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) count[i] = (int)((packed >> (8 * i)) & 0xffull);
           int maxIdx = 0, sndIdx = 1;
           if (count[maxIdx] < count[sndIdx]) { maxIdx = 1; sndIdx = 0; }
 #pragma unroll
