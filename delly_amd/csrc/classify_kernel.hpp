@@ -40,7 +40,8 @@ struct ClsLds {
 };
 
 __device__ __forceinline__ int cls_code(int c) {
-  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5;
+  const int v = ((unsigned)c > 255u) ? -1 : letter_code_bf((uint8_t)c);
+  return v < 0 ? 5 : v;
 }
 
 // exact equality mask of probe rows [64w, 64w+64) for a byte outside ACGTN (only reached when a probe

@@ -76,20 +76,8 @@ struct MsaArgs {
 };
 
 // ---- K1: bit-parallel LCS (Crochemore et al. / Hyyro): V' = (V + (V & M)) | (V & ~M) ----
-__device__ __forceinline__ int letter_code(uint8_t c) {
-  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1;
-}
+__device__ __forceinline__ int letter_code(uint8_t c) { return letter_code_bf(c); }   // A 0, C 1, G 2, T 3, N 4, anything else -1
 
-
-// the same without branches (a nibble table over 'A' .. 'Z' + 6): written as a chain of comparisons the compiler turns
-// letter_code() into a tree of divergent branches -- ~60 scalar instructions per letter in the LCS loop, which took 245 of a
-// junction's 1 750 us (round 5, tools/msa_phases.py)
-__device__ __forceinline__ int letter_code_bf(uint8_t c) {
-  const uint32_t idx = (uint32_t)c - (uint32_t)'A';
-  const unsigned long long tbl = (idx & 16u) ? 0xffffffffffff3fffull : 0xff4ffffff2fff1f0ull;
-  const int v = (int)((tbl >> (4u * (idx & 15u))) & 15ull);
-  return (idx < 32u && v != 15) ? v : -1;
-}
 
 // ---- alignment node descriptor ------------------------------------------------
 struct Node {

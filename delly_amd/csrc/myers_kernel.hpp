@@ -24,7 +24,7 @@ struct MyersWord {
 };
 
 __device__ __forceinline__ int myers_code(int c) {
-  return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : -1;
+  return ((unsigned)c > 255u) ? -1 : letter_code_bf((uint8_t)c);   // (NOMATCH and other non-bytes: none)
 }
 
 // equality mask of a 32-row word for a text byte outside ACGTN (rare; kept out of line so that

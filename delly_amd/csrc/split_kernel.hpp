@@ -122,10 +122,28 @@ __device__ __forceinline__ uint32_t ld_scratch(const uint32_t* p) {
   // L1-bypassing load: scratch words are re-written by this wave for every junction
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the same without branches (a nibble table over 'A' .. 'Z' + 6): written as a chain of comparisons the compiler turns
+// letter_code() into a tree of divergent branches -- ~60 scalar instructions per letter in the LCS loop, which took 245 of a
+// junction's 1 750 us (round 5, tools/msa_phases.py)
+__device__ __forceinline__ int letter_code_bf(uint8_t c) {
+  const uint32_t idx = (uint32_t)c - (uint32_t)'A';
+  const unsigned long long tbl = (idx & 16u) ? 0xffffffffffff3fffull : 0xff4ffffff2fff1f0ull;
+  const int v = (int)((tbl >> (4u * (idx & 15u))) & 15ull);
+  return (idx < 32u && v != 15) ? v : -1;
+}
+
 __device__ __forceinline__ uint8_t upc(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 // complement of an (already upper-cased) base; 0 when outside ACGTN
+// (without branches: a nibble table over 'A' .. 'A' + 31 says whether the byte is one of A, C, G, T, N -- 0 .. 4 -- and A <-> T is
+//  x ^ 0x15, C <-> G is x ^ 0x04, bit 1 of the byte tells the two pairs apart; the chain of comparisons this replaces compiled into a
+//  tree of divergent branches per letter, round 5)
 __device__ __forceinline__ uint8_t comp_acgtn(uint8_t u) {
-  return u == 'A' ? 'T' : u == 'C' ? 'G' : u == 'G' ? 'C' : u == 'T' ? 'A' : u == 'N' ? 'N' : 0;
+  const uint32_t idx = (uint32_t)u - (uint32_t)'A';
+  const unsigned long long tbl = (idx & 16u) ? 0xffffffffffff3fffull : 0xff4ffffff2fff1f0ull;
+  const uint32_t v = (uint32_t)((tbl >> (4u * (idx & 15u))) & 15ull);
+  const bool ok = idx < 32u && v != 15u;
+  const uint8_t sw = (uint8_t)(u ^ ((u & 2u) ? 0x04u : 0x15u));
+  return ok ? ((v == 4u) ? (uint8_t)'N' : sw) : (uint8_t)0;
 }
 // byte i of reverseComplement(str) (util.h:549-563): complement of the upper-cased mirrored
 // byte, or the ORIGINAL byte i when that is not one of ACGTN
