@@ -1043,6 +1043,26 @@ __device__ __forceinline__ bool sps_lists_small(const FRV& frF, const FRV& frR, 
   return true;
 }
 
+// One row of the join with at most nine levels in registers (needle.h:96-115): lo_[d] = first column the forward side reaches
+// with d deficits, c2_[q] = first column of the reverse side with q.  The minimal e for a d is the number of levels whose reverse
+// column is still too far right.  Written without branches: as nested ifs over per-lane data this compiled to exec-mask trees.
+__device__ __forceinline__ void sps_row_best(const int (&lo_)[9], const int (&c2_)[9], int SE, int n, int r, long long& kb, int& db) {
+  int thr[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) thr[q] = (q <= SE) ? ((c2_[q] > n) ? -1 : n - c2_[q]) : SP_INF;   // level q is "too far" iff lo > thr[q]
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {
+    const int lo = lo_[d];
+    int e = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) e += (int)(lo > thr[q]);
+    const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
+    const bool take = (bool)((int)(d <= SE) & (int)(lo <= n) & (int)(e <= SE) & (int)(d + e <= SE) & (int)(kk <= kb));
+    kb = take ? kk : kb;
+    db = take ? d : db;
+  }
+}
+
 // join over the rows rlo .. rhi (needle.h:96-115) from the registers of sps_lists_small: key = (total deficit << 40) | (row << 20)
 // | column of the winner (0x7fff... : none), dsel = its forward deficit.  Same arithmetic as the table version below.
 __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, int SE, int rlo, int rhi, long long& key, int& dsel, int lane) {
@@ -1062,7 +1082,7 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
       for (int d = 0; d < 9; ++d) {
         if (d <= SE) {
           const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
-          lo_[d] = (on && v >= r) ? min(lo_[d], r + k) : lo_[d];
+          lo_[d] = min(lo_[d], ((int)on & (int)(v >= r)) ? r + k : SP_INF);   // (`on && ..` came out as divergent branches)
         }
       }
     }
@@ -1075,26 +1095,14 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
       for (int d = 0; d < 9; ++d) {
         if (d <= SE) {
           const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
-          c2_[d] = (on && v >= rr) ? min(c2_[d], rr + k) : c2_[d];
+          c2_[d] = min(c2_[d], ((int)on & (int)(v >= rr)) ? rr + k : SP_INF);
         }
       }
     }
     if (r <= rhi) {
       long long kb = 0x7fffffffffffffffll;
       int db = 0;
-#pragma unroll
-      for (int d = 0; d < 9; ++d) {
-        const int lo = lo_[d];
-        if (d <= SE && lo <= n) {
-          int e = 0;
-#pragma unroll
-          for (int q = 0; q < 9; ++q) e += (q <= SE && (c2_[q] > n || lo > n - c2_[q])) ? 1 : 0;
-          if (e <= SE && d + e <= SE) {
-            const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
-            if (kk <= kb) { kb = kk; db = d; }
-          }
-        }
-      }
+      sps_row_best(lo_, c2_, SE, n, r, kb, db);
       if (kb < key) { key = kb; dbest = db; }
     }
   }
@@ -1234,19 +1242,7 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
               lo_[q] = (q <= SE) ? sp_ld32(cf + (size_t)q * (m + 1)) : SP_INF;
               c2_[q] = (q <= SE) ? sp_ld32(cr + (size_t)q * (m + 1)) : SP_INF;
             }
-#pragma unroll
-            for (int d = 0; d < 9; ++d) {
-              const int lo = lo_[d];
-              if (d <= SE && lo <= n) {
-                int e = 0;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) e += (q <= SE && (c2_[q] > n || lo > n - c2_[q])) ? 1 : 0;
-                if (e <= SE && d + e <= SE) {
-                  const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
-                  if (kk <= kb) { kb = kk; db = d; }
-                }
-              }
-            }
+            sps_row_best(lo_, c2_, SE, n, r, kb, db);
           } else {
           // two pointers: minimal e for every d (first columns shrink with d, last allowed columns grow with e)
           int e = SE + 1;
