@@ -13,11 +13,15 @@ timed region and result records stay in HBM: that is `value` (the bench
 contract).  The quantity SURVEY.md 8d defines -- host buffers in, host buffers out,
 marshalling + H2D + kernels + D2H -- is measured in the same run through the
 pipelined path (dellyhip_stream) over >= 1 s of batches and reported beside it as
-`host_inclusive`.  For N > 1 junctions shard across ranks; the records and bytes
-of step k - 1 reach the host inside step k (`config.gather_ms_per_step`): by
-default every rank downloads its own share into a pinned POSIX shared-memory
-segment that rank 0 has mapped (no collective, every PCIe link used);
-`--gather rccl` gathers them to rank 0's HBM over RCCL and downloads there.
+`host_inclusive`.  For N > 1 junctions shard across ranks and the results of
+every step reach host memory rank 0 can read, inside the timed region, in two
+ways that are timed one after the other: `value` with the pipelined per-rank
+return (dellyhip_batch_fetch_begin / _end: step k queues the return of step k - 1
+behind its kernels, a kernel writes records and bytes over the rank's own PCIe
+link into a pinned POSIX shared-memory segment rank 0 has mapped; no collective,
+two launches in flight as at N = 1), and `config.gather_*` with the blocking gather
+to rank 0 (dellyhip_gather_results over RCCL, then one download there).
+`--gather shm` / `--gather rccl` time one of them only.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -86,6 +90,7 @@ def side_batch(synth, n, kw):
 
 
 RESIDENT_BATCHES = 4          # distinct resident batches the timed steps rotate through
+MULTI_RESIDENT_BATCHES = 4   # N > 1: a batch is run again four steps later, long after its return (queued one step after its run) has left
 HOST_INCLUSIVE_SECONDS = 1.0  # wall time of the pipelined host-buffer measurement
 STREAM_DEPTH = 6
 
@@ -497,15 +502,15 @@ CONFIG_FIRST = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch
                 "u_c2_40k_alignments_per_s", "u_full_n20_10k_msa_deferred_junctions", "u_full_n5_2k_junctions_per_s",
                 "value_min", "value_max", "launches_in_flight", "refined_ok_min")
 # N > 1 (the driver's SCALE runs): what the return paths cost comes first
-CONFIG_FIRST_MULTI = ("workload", "gather_ms_per_step", "gather_transport", "rccl_ranks", "shm_return_alignments_per_s", "shm_return_ms_per_step",
-                      "shm_return_gather_ms_per_step", "host_inclusive_alignments_per_s", "ms_per_step_min_rank", "ms_per_step_max_rank",
+CONFIG_FIRST_MULTI = ("workload", "value_return_path", "gather_alignments_per_s", "gather_step_ms", "gather_ms_per_step", "gather_transport", "rccl_ranks",
+                      "shm_return_alignments_per_s", "shm_return_ms_per_step", "shm_return_gather_ms_per_step", "host_inclusive_alignments_per_s", "ms_per_step_min_rank", "ms_per_step_max_rank",
                       "ranks_launched", "ranks_that_ran_kernels", "oversubscribed_one_device", "gathered_records_on_rank0",
                       "gathered_blob_bytes_on_rank0", "shm_return_records_seen_by_rank0", "junctions_per_gpu", "refined_ok_min",
                       "kernels_ms_per_step_rank0", "launches_in_flight")
 
 
 def order_config(cfg):
-    first = CONFIG_FIRST_MULTI if "gather_ms_per_step" in cfg else CONFIG_FIRST
+    first = CONFIG_FIRST_MULTI if "value_return_path" in cfg else CONFIG_FIRST
     out = {k: cfg[k] for k in first if k in cfg}
     out.update({k: v for k, v in cfg.items() if k not in out})
     return out
@@ -579,16 +584,17 @@ def main():
     ap.add_argument("--no-alone", action="store_true", help="skip the one-launch-at-a-time pass behind the timed region (profiling runs)")
     ap.add_argument("--only-extras", default="", help="comma-separated names: run just these side measurements")
     ap.add_argument("--gather", choices=("both", "shm", "rccl"), default="both",
-                    help="N > 1: how the results of a step reach rank 0 -- rccl: dellyhip_gather_results to rank 0's HBM (RCCL "
-                         "ncclSend / ncclRecv over xGMI) + D2H there, the all-gatherv BASELINE's north_star names: this is `value`; shm: "
-                         "every rank downloads its own share into a POSIX shared-memory segment rank 0 has mapped (no collective): "
-                         "`config.shm_return_*`; both (default): the two timed regions one after the other in the same run")
+                    help="N > 1: how the results of a step reach rank 0 -- shm: every rank returns its own share into a POSIX shared-memory "
+                         "segment rank 0 has mapped, pipelined (dellyhip_batch_fetch_begin / _end; no collective): this is `value` and "
+                         "`config.shm_return_*`; rccl: the blocking dellyhip_gather_results to rank 0's HBM (RCCL ncclSend / ncclRecv over xGMI, "
+                         "the all-gatherv BASELINE's north_star names) + D2H there: `config.gather_*` (`value` when it is the only path); "
+                         "both (default): the two timed regions one after the other in the same run")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="development / the two-process test on a one-GPU box: every rank drives device 0, torch.distributed runs on gloo, "
                          "and the gather protocol runs on the shared-memory transport (dellyhip_comm_create_hostlink) because RCCL "
                          "refuses a communicator whose ranks share a device")
     ap.add_argument("--force-comm", action="store_true",
-                    help="development: take the N > 1 code path (two resident batches, RCCL communicator, gather of step k-1 "
+                    help="development: take the N > 1 code path (MULTI_RESIDENT_BATCHES resident batches, RCCL communicator, gather of step k-1 "
                          "overlapping step k) on ONE GPU with a one-rank communicator")
     ap.add_argument("--dump-rank0-view", default="", help="N > 1: rank 0 writes what it holds after the last step of each return path "
                                                           "(records + blob per path) to this .npz (tests compare it with the checker)")
@@ -631,7 +637,7 @@ def main():
     import numpy as np
     n = args.junctions
     multi = world > 1 or args.force_comm
-    n_res = 2 if multi else RESIDENT_BATCHES
+    n_res = MULTI_RESIDENT_BATCHES if multi else RESIDENT_BATCHES
     # weak scaling: rank r owns the junctions [(k * world + r) * n, +n) of the synthetic stream, k = 0 .. n_res - 1
     raw = [synth.make_batch(n, mode="c2", first=(k * world + rank) * n) for k in range(n_res)]
     chroms, batches = one_genome(synth, raw)
@@ -647,7 +653,7 @@ def main():
     # (one 10 000-junction launch alone: 2.4 wavefronts per resident slot, a 50 us ramp and a 180 us tail of 0.40 ms).
     # That is how the pipelined host path runs them too (dellyhip_stream).  N > 1: the return of step k - 1's results overlaps
     # the kernels of step k.
-    # (N > 1 too: the two resident batches live in two contexts, so the return of step k - 1's results -- compaction kernels
+    # (N > 1 too: the resident batches alternate between two contexts, so the return of step k - 1's results -- compaction kernels
     #  and downloads on that batch's own stream -- is not queued behind the kernels of step k)
     ctxs = [ctx, refine.Context(device=local, share_with=ctx)]
     streams = list(ctx.compute_streams())[:len(ctxs)]
@@ -704,11 +710,13 @@ def main():
         "rccl": ("dellyhip_gather_results: %s of records + consensus/allele bytes to rank 0's HBM, then D2H into its pinned host memory, all "
                  "inside the step; gather of step k-1 overlaps the kernels of step k"
                  % ("shared-memory transport (hostlink; RCCL refuses ranks that share a device)" if args.oversubscribe else "RCCL ncclSend/ncclRecv over xGMI")),
-        "shm": ("per-rank D2H (dellyhip_batch_fetch) into a pinned POSIX shared-memory segment mapped by rank 0, inside the step; download of "
-                "step k-1 overlaps the kernels of step k; no collective"),
+        "shm": ("per-rank return (dellyhip_batch_fetch_begin / _end: compaction + a kernel that writes over the rank's own PCIe link) into a pinned "
+                "POSIX shared-memory segment mapped by rank 0; step k queues the return of step k-1 behind its kernels and publishes the return "
+                "of step k-2; no collective, no host wait on the two youngest steps"),
         None: "none (one GPU: results stay in HBM; host_inclusive has the rate with H2D / D2H)"}
     gathered_n = [0, 0]
     gather_s = [0.0]
+    in_flight = [None]
     k_step = [0]
     mode = [paths[0] if paths else None]
 
@@ -717,18 +725,29 @@ def main():
         cur = rbs[i]
         cur.run(streams[i % len(streams)])
         if mode[0] == "rccl" and k_step[0] > 0:
-            prev = rbs[(k_step[0] + 1) % 2]
+            prev = rbs[(k_step[0] - 1) % len(rbs)]
             tg = time.perf_counter()
             gathered_n[0], gathered_n[1] = prev.gather_into(comm, 0, pinned)   # (waits for prev's kernels, not for cur's)
             gather_s[0] += time.perf_counter() - tg
         elif mode[0] == "shm" and k_step[0] > 0:
-            prev = rbs[(k_step[0] + 1) % 2]
+            # pipelined: the return of step k - 2 (queued in step k - 1) is waited for and published, then the return of step k - 1 is
+            # QUEUED behind its kernels (dellyhip_batch_fetch_begin: compaction + a kernel that writes into the pinned segment) --
+            # no host wait on anything younger than two steps, two launches in flight as at N = 1
+            prev = rbs[(k_step[0] - 1) % len(rbs)]
             tg = time.perf_counter()
+            drain()
             seg.begin()
-            used = prev.fetch_into(seg.records_view(), seg.blob_view())        # (waits for prev's kernels, not for cur's)
-            seg.commit(prev.n, used)
+            prev.fetch_begin(seg.records_view(), seg.blob_view())
+            in_flight[0] = prev
             gather_s[0] += time.perf_counter() - tg
         k_step[0] += 1
+
+    def drain():
+        """the fetch in flight (if any) has arrived and is published in the segment"""
+        if in_flight[0] is not None:
+            used = in_flight[0].fetch_end()
+            seg.commit(in_flight[0].n, used)
+            in_flight[0] = None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -741,12 +760,16 @@ def main():
         k_step[0] = 0
         for _ in range(warm):
             step()
+        drain()
         torch.cuda.synchronize()
         gather_s[0] = 0.0
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        tg = time.perf_counter()
+        drain()              # (inside the timed region: the last step's return has reached the segment too)
+        gather_s[0] += time.perf_counter() - tg
         sync_all()
         return time.perf_counter() - t0, gather_s[0]
 
@@ -802,7 +825,8 @@ def main():
             elif rank == 0 and args.dump_rank0_view:
                 nr, nb = gathered_n
                 rank0_view["rccl"] = (np.frombuffer(pinned[0].numpy()[:nr * rb_bytes].tobytes(), dtype=abi.result_dtype()), pinned[1].numpy()[:nb].copy())
-    first = paths[0] if paths else None
+    # N > 1: `value` is the pipelined per-rank return (shm) when it was timed; the blocking gather is timed beside it (config.gather_*)
+    first = ("shm" if "shm" in paths else paths[0]) if paths else None
     dt = region[first]["dt"]
     per_rank_ms = [x / args.steps * 1e3 for x in region[first]["per_rank"]]
     kms = [x.kernel_ms() for x in rbs]          # (sync + averages over each batch's launches; N > 1: of the last return path)
@@ -874,7 +898,7 @@ def main():
         cfg = {"workload": "BASELINE configs[1]: %d synthetic DEL junctions per GPU and step, 150 bp consensus x 1 kb ref window" % n,
                "workload_detail": "alignConsensus (longNeedle + split detection), bit-exact; steps rotate through %d different resident batches%s"
                                   % (len(batches), "" if multi else ", consecutive steps on two contexts / two HIP streams (two launches in flight)"),
-               "launches_in_flight": 1 if multi else 2,
+               "launches_in_flight": 1 if (multi and first != "shm") else 2,
                "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok_min": min(n_ok), "parallelism": "junction-sharded x%d" % world,
                "ranks_launched": world, "ranks_that_ran_kernels": ranks_that_ran,
                "value_is": "inputs resident in HBM, results left in HBM (bench contract)" if not multi else
@@ -891,23 +915,29 @@ def main():
                             "one_launch_at_a_time_kernel_ms": alone["kernel_ms"]})
         else:
             cfg["return_path"] = path_text[first]
-            cfg["gather_ms_per_step"] = region[first]["gather_s"] / max(args.steps, 1) * 1e3
-            cfg["gathered_records_on_rank0"] = region[first]["records"]
-            cfg["gathered_blob_bytes_on_rank0"] = region[first]["blob_bytes"]
+            cfg["value_return_path"] = first
             cfg["ms_per_step_min_rank"] = min(per_rank_ms)
             cfg["ms_per_step_max_rank"] = max(per_rank_ms)
             if comm_info is not None:
                 cfg["rccl_ranks"] = comm_info["transport_ranks"]     # ncclCommCount (hostlink: attached processes)
                 cfg["gather_transport"] = comm_info["kind"]
             cfg["oversubscribed_one_device"] = bool(args.oversubscribe)
-            for pth in paths[1:]:
-                r = region[pth]
-                cfg["%s_return_alignments_per_s" % pth] = total_units / r["dt"]
-                cfg["%s_return_ms_per_step" % pth] = r["dt"] / args.steps * 1e3
-                cfg["%s_return_gather_ms_per_step" % pth] = r["gather_s"] / max(args.steps, 1) * 1e3
-                cfg["%s_return_records_seen_by_rank0" % pth] = r["records"]
-                cfg["%s_return_blob_bytes_seen_by_rank0" % pth] = r["blob_bytes"]
-                cfg["%s_return_path" % pth] = path_text[pth]
+            if "rccl" in region:   # the blocking gather to rank 0 (dellyhip_gather_results), its own timed region
+                r = region["rccl"]
+                cfg["gather_alignments_per_s"] = total_units / r["dt"]
+                cfg["gather_step_ms"] = r["dt"] / args.steps * 1e3
+                cfg["gather_ms_per_step"] = r["gather_s"] / max(args.steps, 1) * 1e3
+                cfg["gathered_records_on_rank0"] = r["records"]
+                cfg["gathered_blob_bytes_on_rank0"] = r["blob_bytes"]
+                cfg["gather_path"] = path_text["rccl"]
+            if "shm" in region:    # the pipelined per-rank return into shared memory
+                r = region["shm"]
+                cfg["shm_return_alignments_per_s"] = total_units / r["dt"]
+                cfg["shm_return_ms_per_step"] = r["dt"] / args.steps * 1e3
+                cfg["shm_return_gather_ms_per_step"] = r["gather_s"] / max(args.steps, 1) * 1e3
+                cfg["shm_return_records_seen_by_rank0"] = r["records"]
+                cfg["shm_return_blob_bytes_seen_by_rank0"] = r["blob_bytes"]
+                cfg["shm_return_path"] = path_text["shm"]
         if isinstance(hi, dict) and "value" in hi:
             cfg["host_inclusive_alignments_per_s"] = hi["value"]       # SURVEY.md 8d's definition: host buffers in -> host buffers out
             cfg["host_inclusive_wall_s"] = hi["wall_s"]

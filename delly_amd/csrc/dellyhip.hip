@@ -386,6 +386,14 @@ struct dellyhip_batch {
   // dellyhip_batch_fetch: device-side compaction
   DevBuf<uint64_t> blob_off;
   DevBuf<uint8_t> blob_compact;
+  // dellyhip_batch_fetch_begin / _end: the same compaction queued behind the batch's kernels, its output written by a kernel into
+  // the caller's pinned host memory
+  hipStream_t run_stream = nullptr;  // the stream of the last dellyhip_batch_run
+  hipStream_t fetch_stream = nullptr;
+  hipEvent_t fetch_ev = nullptr;
+  bool fetch_pending = false;
+  uint64_t* fetch_status = nullptr;  // pinned: [0] = blob bytes, [1] = flags (1: the caller's blob area is too small, 2: a long-read team gave up)
+  size_t fetch_status_bytes = 0;
   // direct (single longNeedle) mode
   DevBuf<uint8_t> ref_blob;
   DevBuf<uint64_t> ref_off;
@@ -1166,8 +1174,9 @@ __global__ __launch_bounds__(1024) void blob_offsets_kernel(const dellyhip_resul
   if (t == 1023) off[n] = at;
 }
 // one wavefront per junction: its three pieces, back to back, at out + off[i]
-__global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n) {
+__global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n, uint64_t cap) {
   const int lane = threadIdx.x;
+  if (off[n] > cap) return;   // (dellyhip_batch_fetch_begin: the size is not known on the host when this is queued)
   for (int i = blockIdx.x; i < n; i += gridDim.x) {
     const dellyhip_result R = res[i];
     uint8_t* dst = out + off[i];
@@ -1177,6 +1186,49 @@ __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* bl
       for (int q = lane; q < len[k]; q += dh::WAVE) dst[q] = blob[src[k] + q];
       dst += len[k];
     }
+  }
+}
+
+// dellyhip_batch_fetch_begin: what dellyhip_batch_fetch does on the host after its downloads, done on the device with the CALLER's
+// pinned host memory as the destination.  Record i leaves as the first 36 lanes' dwords of one wavefront store, its blob offsets
+// rebased to the compacted layout (rebase_offsets below) and `reserved` cleared; then the compacted bytes in 16-byte pieces.
+// status[0] = blob bytes, status[1] = flags (1: they do not fit `cap`, nothing of the blob written; 2: *lrt_error is set).
+__global__ __launch_bounds__(256) void fetch_out_kernel(const dellyhip_result* res, const uint64_t* off, int n, const uint8_t* compact,
+                                                        dellyhip_result* h_res, uint8_t* h_blob, uint64_t cap, uint64_t* status,
+                                                        const int32_t* lrt_error) {
+  constexpr int RW = (int)(sizeof(dellyhip_result) / 4);
+  static_assert(sizeof(dellyhip_result) % 4 == 0 && RW <= dh::WAVE, "one record = one wavefront store");
+  constexpr int W_CONS_LEN = (int)(offsetof(dellyhip_result, cons_len) / 4), W_ALLELE_LEN = (int)(offsetof(dellyhip_result, allele_len) / 4),
+                W_ALN_LEN = (int)(offsetof(dellyhip_result, aln_len) / 4), W_CONS_OFF = (int)(offsetof(dellyhip_result, cons_off) / 4),
+                W_ALLELE_OFF = (int)(offsetof(dellyhip_result, allele_off) / 4), W_ALN_OFF = (int)(offsetof(dellyhip_result, aln_off) / 4),
+                W_RESERVED = (int)(offsetof(dellyhip_result, reserved) / 4);
+  const uint64_t used = off[n];
+  const bool fits = used <= cap;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+  const int lane = (int)(threadIdx.x & 63);
+  for (uint64_t i = tid >> 6; i < (uint64_t)n; i += nthr >> 6) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(res + i);
+    uint32_t w = lane < RW ? src[lane] : 0u;
+    const uint64_t l0 = (uint64_t)max(__builtin_amdgcn_readlane((int)w, W_CONS_LEN), 0), l1 = (uint64_t)max(__builtin_amdgcn_readlane((int)w, W_ALLELE_LEN), 0),
+                   l2 = 2ull * (uint64_t)max(__builtin_amdgcn_readlane((int)w, W_ALN_LEN), 0);
+    const uint64_t at = off[i];
+    const uint64_t o0 = l0 ? at : 0, o1 = l1 ? at + l0 : 0, o2 = l2 ? at + l0 + l1 : 0;
+    w = lane == W_CONS_OFF ? (uint32_t)o0 : lane == W_CONS_OFF + 1 ? (uint32_t)(o0 >> 32) : w;
+    w = lane == W_ALLELE_OFF ? (uint32_t)o1 : lane == W_ALLELE_OFF + 1 ? (uint32_t)(o1 >> 32) : w;
+    w = lane == W_ALN_OFF ? (uint32_t)o2 : lane == W_ALN_OFF + 1 ? (uint32_t)(o2 >> 32) : w;
+#ifndef DH_LR_TIMING
+    w = lane == W_RESERVED ? 0u : w;
+#endif
+    if (lane < RW) reinterpret_cast<uint32_t*>(h_res + i)[lane] = w;
+  }
+  if (fits) {
+    const uint64_t n16 = ((reinterpret_cast<uintptr_t>(h_blob) | reinterpret_cast<uintptr_t>(compact)) & 15) ? 0 : used >> 4;
+    for (uint64_t q = tid; q < n16; q += nthr) reinterpret_cast<uint4*>(h_blob)[q] = reinterpret_cast<const uint4*>(compact)[q];
+    for (uint64_t q = (n16 << 4) + tid; q < used; q += nthr) h_blob[q] = compact[q];
+  }
+  if (tid == 0) {
+    status[0] = used;
+    status[1] = (fits ? 0u : 1u) | ((lrt_error && *lrt_error) ? 2u : 0u);
   }
 }
 
@@ -1441,7 +1493,7 @@ int dellyhip_create_shared(dellyhip_ctx* share_with, const dellyhip_params* para
 int dellyhip_host_register(dellyhip_ctx* c, void* p, uint64_t bytes) {
   if (!c || !p || !bytes) return fail(DELLYHIP_E_ARG, "null argument");
   HIPCHK(hipSetDevice(c->device));
-  hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable);
+  hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
   if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "hipHostRegister", e);
   return 0;
 }
@@ -1515,6 +1567,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!b) return;
   if (c) (void)hipSetDevice(c->device);
   if (b->pending && c) (void)hipStreamSynchronize(c->stream);
+  if (b->fetch_pending && b->fetch_ev && c) (void)hipEventSynchronize(b->fetch_ev);   // (its kernels write into the caller's memory and read the batch's)
   // (a batch run on a caller's stream, or whose run failed after the teams were launched: the batch's workspace and team state
   //  must not be released while lr_dense_team_kernel may still poll them)
   if (b->lr_aux_used && c && c->lr_aux) (void)hipStreamSynchronize(c->lr_aux);
@@ -1523,6 +1576,9 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->msa_order.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
   if (b->own_pin_len) PinPool::get().give(b->own_pin_len, b->own_pin_bytes);
   b->own_pin_len = nullptr;
+  if (b->fetch_status) PinPool::get().give(b->fetch_status, b->fetch_status_bytes);
+  b->fetch_status = nullptr;
+  if (b->fetch_ev) (void)hipEventDestroy(b->fetch_ev);
   if (b->lr_fork) (void)hipEventDestroy(b->lr_fork);
   if (b->lr_join) (void)hipEventDestroy(b->lr_join);
   if (b->lri_fork) (void)hipEventDestroy(b->lri_fork);
@@ -1837,6 +1893,9 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   if (b->n == 0) return 0;
+  // a fetch begun and not ended reads the results this run overwrites: same stream -> ordered already
+  if (b->fetch_pending && b->fetch_ev && b->fetch_stream != s) HIPCHK(hipStreamWaitEvent(s, b->fetch_ev, 0));
+  b->run_stream = s;
   int rc;
   hipEvent_t e3[4];
   bool ev1_done = false;
@@ -2131,6 +2190,7 @@ static int compact_batch(dellyhip_ctx* c, dellyhip_batch* b, std::vector<uint64_
   *used = 0;
   off.assign((size_t)b->n + 1, 0);
   if (b->n == 0) return 0;
+  if (b->fetch_pending && b->fetch_ev) HIPCHK(hipEventSynchronize(b->fetch_ev));   // (it uses the same offset / compaction buffers)
   if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
   hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, b->res.p, b->n, b->blob_off.p);
   HIPCHK(hipGetLastError());
@@ -2140,7 +2200,7 @@ static int compact_batch(dellyhip_ctx* c, dellyhip_batch* b, std::vector<uint64_
   if (*used > 0) {
     if ((rc = b->blob_compact.reserve(*used))) return rc;
     hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, c->stream, b->res.p,
-                       b->out_blob.p, b->blob_off.p, b->blob_compact.p, b->n);
+                       b->out_blob.p, b->blob_off.p, b->blob_compact.p, b->n, ~0ull);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
   }
@@ -2186,6 +2246,71 @@ int dellyhip_batch_fetch(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* re
     }
   }
   if (out_blob_len) *out_blob_len = used;
+  return 0;
+}
+
+static hipStream_t device_download_stream(int device);   // (the device's download stream of the pipelined host path, below)
+
+int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_result* results, char* out_blob, uint64_t out_blob_cap) {
+  if (!c || !b || (!results && b->n)) return fail(DELLYHIP_E_ARG, "null argument");
+  if (b->lazy) return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch_begin: not for the slots of a dellyhip_stream");
+  if (b->n && !b->ever_run) return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch_begin: the batch has not been run");
+  if (b->fetch_pending) return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch_begin: a fetch of this batch is in flight (dellyhip_batch_fetch_end first)");
+  HIPCHK(hipSetDevice(c->device));
+  if (!b->fetch_status) {
+    b->fetch_status = static_cast<uint64_t*>(PinPool::get().take(64, &b->fetch_status_bytes));
+    if (!b->fetch_status) return fail(DELLYHIP_E_NOMEM, "hipHostMalloc (fetch status)");
+  }
+  b->fetch_status[0] = b->fetch_status[1] = 0;
+  if (b->n == 0) { b->fetch_pending = true; return 0; }
+  void *d_res = nullptr, *d_blob = nullptr, *d_status = nullptr;
+  if (hipHostGetDevicePointer(&d_res, results, 0) != hipSuccess || (out_blob && out_blob_cap && hipHostGetDevicePointer(&d_blob, out_blob, 0) != hipSuccess)) {
+    (void)hipGetLastError();
+    return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch_begin: results / out_blob must be pinned host memory (dellyhip_host_register, hipHostMalloc): kernels write into it");
+  }
+  HIPCHK(hipHostGetDevicePointer(&d_status, b->fetch_status, 0));
+  const uint64_t cap = d_blob ? out_blob_cap : 0;
+  int rc;
+  if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
+  // (the used bytes are not known here: room for the smaller of everything the batch can hold and what the caller can take)
+  if ((rc = b->blob_compact.reserve((size_t)std::max<uint64_t>(std::min<uint64_t>(cap, (uint64_t)b->n * b->out_stride), 16)))) return rc;
+  if (!b->fetch_ev) HIPCHK(hipEventCreateWithFlags(&b->fetch_ev, hipEventDisableTiming));
+  // on the device's download stream (the one dellyhip_stream returns its results on: verified to run beside the compute streams), behind
+  // the end of the batch's run: the next launch on the batch's compute stream does not queue behind a PCIe-bound kernel.
+  // DELLYHIP_FETCH_SAME_STREAM=1: on the stream of the run itself (A/B)
+  hipStream_t run_s = b->run_stream ? b->run_stream : c->stream;
+  hipStream_t s = env_on("DELLYHIP_FETCH_SAME_STREAM") ? run_s : device_download_stream(c->device);
+  if (!s) s = run_s;
+  if (s != run_s && b->pending && b->last) HIPCHK(hipStreamWaitEvent(s, b->last, 0));
+  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, b->n, b->blob_off.p);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p, b->blob_off.p,
+                     b->blob_compact.p, b->n, cap);
+  HIPCHK(hipGetLastError());
+  const int32_t* lrt = (b->lr_teams > 0 && b->lr_team_state.p) ? b->lr_team_state.p + dh::LRT_ERROR : nullptr;
+  hipLaunchKernelGGL(fetch_out_kernel, dim3(std::max(1, std::min(c->n_cu * 4, (b->n + 3) / 4))), dim3(256), 0, s, b->res.p, b->blob_off.p, b->n,
+                     b->blob_compact.p, static_cast<dellyhip_result*>(d_res), static_cast<uint8_t*>(d_blob), cap,
+                     static_cast<uint64_t*>(d_status), lrt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->fetch_ev, s));
+  b->fetch_stream = s;
+  b->fetch_pending = true;
+  return 0;
+}
+
+int dellyhip_batch_fetch_end(dellyhip_ctx* c, dellyhip_batch* b, uint64_t* out_blob_len) {
+  if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
+  if (!b->fetch_pending) return fail(DELLYHIP_E_ARG, "dellyhip_batch_fetch_end: no fetch of this batch is in flight");
+  HIPCHK(hipSetDevice(c->device));
+  b->fetch_pending = false;
+  if (out_blob_len) *out_blob_len = 0;
+  if (b->n == 0) return 0;
+  hipError_t e = hipEventSynchronize(b->fetch_ev);
+  if (e != hipSuccess) return fail(DELLYHIP_E_RUNTIME, "dellyhip_batch_fetch_end: kernel execution", e);
+  const uint64_t used = b->fetch_status[0], flags = b->fetch_status[1];
+  if (out_blob_len) *out_blob_len = used;
+  if (flags & 2) return fail(DELLYHIP_E_RUNTIME, "a long-read team of wavefronts gave up waiting: the junctions it was to sweep are not refined");
+  if (flags & 1) return fail(DELLYHIP_E_ARG, "out_blob too small");
   return 0;
 }
 
@@ -2760,6 +2885,8 @@ static DeviceStreams& ensure_device_streams(int device) {
   }
   return D;
 }
+
+static hipStream_t device_download_stream(int device) { return ensure_device_streams(device).down; }
 
 int dellyhip_compute_streams(dellyhip_ctx* c, void* out[2]) {
   if (!c || !out) return fail(DELLYHIP_E_ARG, "null argument");

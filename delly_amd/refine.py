@@ -25,7 +25,7 @@ EXPORTS = [
     "dellyhip_create", "dellyhip_destroy", "dellyhip_last_error", "dellyhip_default_params_sr",
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
-    "dellyhip_batch_fetch", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
+    "dellyhip_batch_fetch", "dellyhip_batch_fetch_begin", "dellyhip_batch_fetch_end", "dellyhip_batch_free", "dellyhip_batch_kernel_ms", "dellyhip_batch_device_results", "dellyhip_batch_dp_kernel_ms", "dellyhip_long_needle",
     "dellyhip_lcs", "dellyhip_gotoh", "dellyhip_msa", "dellyhip_abi_info", "dellyhip_edlib_align", "dellyhip_refine_batch_lr", "dellyhip_msa_edlib", "dellyhip_msa_wfa",
     "dellyhip_classify_reads", "dellyhip_jobs_upload", "dellyhip_jobs_run", "dellyhip_jobs_sync", "dellyhip_jobs_fetch",
     "dellyhip_jobs_free", "dellyhip_jobs_kernel_ms",
@@ -544,6 +544,23 @@ class ResidentBatch:
         used = C.c_uint64(0)
         self.ctx._check(self.ctx.lib.dellyhip_batch_fetch(self.ctx._ctx, self._b, C.c_void_p(records.ctypes.data), C.c_void_p(blob.ctypes.data),
                                                           C.c_uint64(blob.nbytes), C.byref(used)))
+        return int(used.value)
+
+    def fetch_begin(self, records, blob):
+        """dellyhip_batch_fetch_begin: queue the return of this batch's results into PINNED caller memory (uint8 arrays as for
+        fetch_into, e.g. the views of a registered shared-memory segment) behind its kernels; does not wait"""
+        assert records.dtype == np.uint8 and blob.dtype == np.uint8 and records.nbytes >= self.n * abi.result_dtype().itemsize
+        self.ctx._check(self.ctx.lib.dellyhip_batch_fetch_begin(self.ctx._ctx, self._b, C.c_void_p(records.ctypes.data), C.c_void_p(blob.ctypes.data),
+                                                                C.c_uint64(blob.nbytes)))
+
+    def fetch_end(self):
+        """dellyhip_batch_fetch_end: wait for the fetch begun last -> bytes of blob used"""
+        used = C.c_uint64(0)
+        try:
+            self.ctx._check(self.ctx.lib.dellyhip_batch_fetch_end(self.ctx._ctx, self._b, C.byref(used)))
+        except DellyHipError as e:
+            e.blob_bytes_needed = int(used.value)
+            raise
         return int(used.value)
 
     def fetch(self):

@@ -249,6 +249,20 @@ int dellyhip_batch_run(dellyhip_ctx* ctx, dellyhip_batch* b, void* stream);
 int dellyhip_batch_sync(dellyhip_ctx* ctx, dellyhip_batch* b);
 int dellyhip_batch_fetch(dellyhip_ctx* ctx, dellyhip_batch* b, dellyhip_result* results,
                          char* out_blob, uint64_t out_blob_cap, uint64_t* out_blob_len);
+/* dellyhip_batch_fetch in two halves, for a caller that keeps the device busy while results travel (the N > 1 step of
+ * bench.py: every rank returns step k-1's records into its own pinned shared-memory segment while step k runs; the place
+ * of the reference's per-thread push into the shared svs vector, src/shortpe.h:175-201).
+ * _begin queues, on the stream of the batch's last run and therefore behind its kernels, the device-side compaction of
+ * dellyhip_batch_fetch followed by a kernel that WRITES the records (blob offsets rebased exactly as dellyhip_batch_fetch
+ * returns them) and the used blob bytes straight into `results` / `out_blob`; it returns without waiting.  Both areas must be
+ * pinned, device-visible host memory (dellyhip_host_register, hipHostMalloc): DELLYHIP_E_ARG otherwise.  They belong to the
+ * library until _end.  The batch may be run again before _end (the run is ordered behind the queued fetch); one fetch per
+ * batch may be in flight.
+ * _end waits for that fetch only (not for later runs), *out_blob_len = blob bytes; DELLYHIP_E_ARG "out_blob too small" (with
+ * the size needed in *out_blob_len; the records are complete, the blob area untouched) when out_blob_cap was not enough. */
+int dellyhip_batch_fetch_begin(dellyhip_ctx* ctx, dellyhip_batch* b, dellyhip_result* results,
+                               char* out_blob, uint64_t out_blob_cap);
+int dellyhip_batch_fetch_end(dellyhip_ctx* ctx, dellyhip_batch* b, uint64_t* out_blob_len);
 void dellyhip_batch_free(dellyhip_ctx* ctx, dellyhip_batch* b);
 /* Device pointer / byte size of the result records (n x dellyhip_result) left in
  * HBM by dellyhip_batch_run: lets a multi-GPU caller hand them to an RCCL

@@ -24,6 +24,7 @@ import bench  # noqa: E402
 
 N, STEPS, WARM, WORLD = 1500, 3, 1, 2
 THREADS = os.cpu_count() or 1
+LAST_RETURNED = (WARM + STEPS - 2) % bench.MULTI_RESIDENT_BATCHES   # (steps count from 0; step k returns the batch of step k - 1)
 
 
 def _env(**kw):
@@ -43,7 +44,7 @@ def _bench(args, env=None, timeout=600):
 
 def _rank_batches(rank, idx):
     """the resident batch `idx` of `rank` exactly as bench.py builds it (weak scaling, one concatenated genome per rank)"""
-    raw = [synth.make_batch(N, mode="c2", first=(k * WORLD + rank) * N) for k in range(2)]
+    raw = [synth.make_batch(N, mode="c2", first=(k * WORLD + rank) * N) for k in range(bench.MULTI_RESIDENT_BATCHES)]
     chroms, batches = bench.one_genome(synth, raw)
     return chroms, batches[idx]
 
@@ -73,7 +74,7 @@ def test_two_ranks_started_by_bench_itself_and_counted(two_rank_run):
 def test_what_rank0_holds_after_the_gather_is_the_reference_answer(two_rank_run, reference):
     """dellyhip_gather_results with world = 2: rank order, rebased blob offsets, both ranks' bytes -- vs oracle/_ref"""
     _, view = two_rank_run
-    idx = (WARM + STEPS) % 2          # the batch refined in the second-to-last step is the one the last step returned
+    idx = LAST_RETURNED               # the batch refined in the second-to-last step is the one the last step returned
     rec, blob = view["rccl_records"], view["rccl_blob"]
     assert rec.shape[0] == WORLD * N
     for r in range(WORLD):
@@ -86,7 +87,7 @@ def test_what_rank0_holds_after_the_gather_is_the_reference_answer(two_rank_run,
 
 def test_what_rank0_reads_from_both_segments_is_the_reference_answer(two_rank_run, reference):
     _, view = two_rank_run
-    idx = (WARM + STEPS) % 2
+    idx = LAST_RETURNED
     for r in range(WORLD):
         rec, blob = view["shm_records_%d" % r], view["shm_blob_%d" % r]
         assert rec.shape[0] == N
@@ -117,7 +118,7 @@ def test_two_ranks_two_devices_rccl(tmp_path, reference):
     assert line["n_gpus"] == WORLD and cfg["ranks_launched"] == WORLD and cfg["ranks_that_ran_kernels"] == WORLD
     assert cfg["gather_transport"] == "rccl" and cfg["rccl_ranks"] == WORLD and cfg["oversubscribed_one_device"] is False
     assert cfg["gathered_records_on_rank0"] == WORLD * N and cfg["shm_return_records_seen_by_rank0"] == WORLD * N
-    idx = (WARM + STEPS) % 2
+    idx = LAST_RETURNED
     rec, blob = view["rccl_records"], view["rccl_blob"]
     assert rec.shape[0] == WORLD * N
     for r in range(WORLD):
