@@ -2277,7 +2277,8 @@ int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_resu
   if (!b->fetch_ev) HIPCHK(hipEventCreateWithFlags(&b->fetch_ev, hipEventDisableTiming));
   // on the device's download stream (the one dellyhip_stream returns its results on: verified to run beside the compute streams), behind
   // the end of the batch's run: the next launch on the batch's compute stream does not queue behind a PCIe-bound kernel.
-  // DELLYHIP_FETCH_SAME_STREAM=1: on the stream of the run itself (A/B)
+  // DELLYHIP_FETCH_SAME_STREAM=1: on the stream of the run itself (A/B: 26.6 instead of 31.2 M junctions/s in bench.py's N > 1 step; the
+  // high-priority upload stream instead of the low-priority download stream: no difference, tools/gpu_r05_u.sh)
   hipStream_t run_s = b->run_stream ? b->run_stream : c->stream;
   hipStream_t s = env_on("DELLYHIP_FETCH_SAME_STREAM") ? run_s : device_download_stream(c->device);
   if (!s) s = run_s;
