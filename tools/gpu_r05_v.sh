@@ -1,4 +1,4 @@
-# round 5, call V: two returns in flight (two segments per rank), alternating transfer streams
+# round 5, call V: two returns in flight (two segments per rank), alternating transfer streams -- an experiment whose code is NOT in the tree (no gain: DESIGN.md 5)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
