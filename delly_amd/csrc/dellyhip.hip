@@ -1147,31 +1147,54 @@ __global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list,
 // ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
 // off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
 __global__ __launch_bounds__(1024) void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
-  // one block of 1024 threads, thread t owns the records [t * chunk, (t + 1) * chunk): its own sum, one scan over the
-  // wavefront (shuffles) and one over the 16 wavefront totals, then its offsets (one barrier; n = 10 000: chunk = 10)
+  // One block of 1024 threads; per round thread t owns the C records [base + t * C, + C): their lengths are loaded into registers
+  // with EVERY load of the round in flight at once (the index is clamped, not branched on: round 5 -- a loop over a run-time chunk
+  // took one memory latency per record and pass, 39 us for 10 000 records), then one scan over the wavefront (shuffles), one over
+  // the 16 wavefront totals, and the offsets from the registers.  Rounds of 16 384 records carry the running total.
+  constexpr int C = 16;
   __shared__ uint64_t wsum[16];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int chunk = (n + 1023) / 1024;
-  const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-  auto len_of = [&](int i) {
-    return (uint64_t)max(res[i].cons_len, 0) + (uint64_t)max(res[i].allele_len, 0) + 2ull * (uint64_t)max(res[i].aln_len, 0);
-  };
-  uint64_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += len_of(i);
-  uint64_t inc = sum;
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t v = __shfl_up(inc, d);
-    if (lane >= d) inc += v;
+  if (n <= 0) {
+    if (t == 0) off[0] = 0;
+    return;
   }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint64_t at = inc - sum;
-  for (int k = 0; k < w; ++k) at += wsum[k];
-  for (int i = lo; i < hi; ++i) {
-    off[i] = at;
-    at += len_of(i);
+  uint64_t carry = 0;
+  for (int base = 0; base < n; base += 1024 * C) {
+    const int lo = base + t * C;
+    uint64_t len[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      const int r = min(lo + i, n - 1);
+      const int l0 = res[r].cons_len, l1 = res[r].allele_len, l2 = res[r].aln_len;
+      const uint64_t v = (uint64_t)max(l0, 0) + (uint64_t)max(l1, 0) + 2ull * (uint64_t)max(l2, 0);
+      len[i] = (lo + i < n) ? v : 0ull;
+    }
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) sum += len[i];
+    uint64_t inc = sum;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t v = __shfl_up(inc, d);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint64_t at = carry + inc - sum, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint64_t v = wsum[k];
+      at += k < w ? v : 0ull;
+      total += v;
+    }
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+      if (lo + i < n) off[lo + i] = at;
+      at += len[i];
+    }
+    carry += total;
+    __syncthreads();   // (wsum is rewritten by the next round)
   }
-  if (t == 1023) off[n] = at;
+  if (t == 0) off[n] = carry;
 }
 // one wavefront per junction: its three pieces, back to back, at out + off[i]
 __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n, uint64_t cap) {
