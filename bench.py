@@ -500,7 +500,7 @@ CONFIG_FIRST = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch
                 "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
                 "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
                 "u_c2_40k_alignments_per_s", "u_full_n20_10k_msa_deferred_junctions", "u_full_n5_2k_junctions_per_s",
-                "value_min", "value_max", "launches_in_flight", "refined_ok_min")
+                "value_min", "value_max", "u_full_n20_10k_host_inclusive_per_s", "refined_ok_min")
 # N > 1 (the driver's SCALE runs): what the return paths cost comes first
 CONFIG_FIRST_MULTI = ("workload", "value_return_path", "gather_alignments_per_s", "gather_step_ms", "gather_ms_per_step", "gather_transport", "rccl_ranks",
                       "shm_return_alignments_per_s", "shm_return_ms_per_step", "shm_return_gather_ms_per_step", "host_inclusive_alignments_per_s", "ms_per_step_min_rank", "ms_per_step_max_rank",
@@ -1000,6 +1000,10 @@ def main():
             row = out["extras"].get("u_full_n20_10k_junctions")
             if isinstance(row, dict) and "msa_deferred_junctions" in row:
                 out["config"]["u_full_n20_10k_msa_deferred_junctions"] = row["msa_deferred_junctions"]
+            if isinstance(row, dict) and isinstance(row.get("host_inclusive"), dict) and "value" in row["host_inclusive"]:
+                # the same batch from host buffers to host buffers through dellyhip_stream: several launches in flight, the tail of one under
+                # the head of the next (the resident row above runs one launch at a time)
+                out["config"]["u_full_n20_10k_host_inclusive_per_s"] = row["host_inclusive"]["value"]
             sw = out["extras"].get("deficit_sweep")
             if isinstance(sw, dict):
                 for name, row in sw.items():

@@ -15,7 +15,7 @@ MUST_SURVIVE = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch
                 "sr_stage_mixed_all_svt_junctions_per_s", "lr_stress_10kb_x_20kb_junctions_per_s",
                 "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
                 "lr_c4_align_consensus_8k_junctions_per_s", "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
-                "u_full_n20_10k_msa_deferred_junctions")
+                "u_full_n20_10k_msa_deferred_junctions", "u_full_n20_10k_host_inclusive_per_s")
 
 
 def _line_like_bench():
@@ -29,6 +29,7 @@ def _line_like_bench():
     for _, key in bench.FLAT_ROWS:
         cfg[key] = 1.0
     cfg["u_full_n20_10k_msa_deferred_junctions"] = 0
+    cfg["u_full_n20_10k_host_inclusive_per_s"] = 1.0
     for name, _ in bench.SWEEP_PLAN:
         cfg["deficit_sweep_%s_alignments_per_s" % name] = 1.0
     cfg["substitutions_2pct_alignments_per_s"] = cfg["substitutions_5pct_alignments_per_s"] = 1.0
