@@ -62,3 +62,23 @@ def test_every_side_row_has_a_batch_recipe_the_parity_test_can_rebuild():
         assert n > 0 and ncpu >= 0 and "mode" in kw
         assert n % int(kw.get("_tiles", 1)) == 0
     assert {row for row, _ in bench.FLAT_ROWS} <= set(names)
+
+
+def test_an_n_gt_1_line_starts_with_what_the_return_paths_cost():
+    """bench.py --gpus N: `value` is the pipelined shared-memory return, the blocking gather is timed beside it -- both must be among
+    the scalars the driver keeps (SCALE_rNN.json is built from these lines)"""
+    cfg = {"workload": "BASELINE configs[1]: ...", "workload_detail": "...", "launches_in_flight": 2, "junctions_per_gpu": 10000, "resident_batches": 4,
+           "refined_ok_min": 9900, "parallelism": "junction-sharded x2", "ranks_launched": 2, "ranks_that_ran_kernels": 2, "value_is": "...",
+           "kernels_ms_per_step_rank0": 0.5, "return_path": "...", "value_return_path": "shm", "ms_per_step_min_rank": 0.3, "ms_per_step_max_rank": 0.32,
+           "rccl_ranks": 2, "gather_transport": "rccl", "oversubscribed_one_device": False, "gather_alignments_per_s": 2.0e7, "gather_step_ms": 0.9,
+           "gather_ms_per_step": 0.85, "gathered_records_on_rank0": 20000, "gathered_blob_bytes_on_rank0": 17000000, "gather_path": "...",
+           "shm_return_alignments_per_s": 6.0e7, "shm_return_ms_per_step": 0.32, "shm_return_gather_ms_per_step": 0.29,
+           "shm_return_records_seen_by_rank0": 20000, "shm_return_blob_bytes_seen_by_rank0": 17000000, "shm_return_path": "...",
+           "host_inclusive_alignments_per_s": 8.0e7, "segments_seen_by_rank0": [{"rank": 0}], "ms_per_step_per_rank": [0.3, 0.32]}
+    line = json.loads(json.dumps({"config": bench.order_config(cfg)}))
+    kept = bench.driver_view_of_config(line["config"])
+    for k in ("value_return_path", "gather_alignments_per_s", "gather_ms_per_step", "gather_transport", "rccl_ranks", "shm_return_alignments_per_s",
+              "shm_return_ms_per_step", "ranks_launched", "ranks_that_ran_kernels", "oversubscribed_one_device", "gathered_records_on_rank0",
+              "shm_return_records_seen_by_rank0", "host_inclusive_alignments_per_s"):
+        assert k[:40] in kept, k
+    assert list(kept)[0] == "workload" and list(kept)[1] == "value_return_path"
