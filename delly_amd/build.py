@@ -33,3 +33,17 @@ def build_lib(force=False, verbose=False, out=None, extra_flags=()):
 
 if __name__ == "__main__":
     build_lib(force=True, verbose=True)
+
+
+# The sources the headline's kernel (split_sparse_kernel) is compiled from.  profiles/rNN/pmc_traffic.json is stamped with their
+# hash when the counters are collected; bench.py compares it with the tree it runs from (`roofline.traffic_stale`).
+HEADLINE_KERNEL_SOURCES = ("sparse_needle.hpp", "split_sparse.hpp", "split_main.hpp", "split_kernel.hpp")
+
+
+def headline_kernel_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in HEADLINE_KERNEL_SOURCES:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]

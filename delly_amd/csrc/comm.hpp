@@ -227,7 +227,42 @@ struct HostLink final : Link {
       if (ok()) return true;
       if (spin < 2000) sched_yield();
       else usleep(50);
-      if ((spin & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+      if ((spin & 255) == 255) {
+        follow_replacement();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+      }
+    }
+  }
+  // a leftover control segment of a run that crashed BEFORE this rank attached (rank 0 attached, MAGIC set, this
+  // rank's slot untouched) passes the freshness test of init().  Rank 0 of the new run unlinks it and creates another one of the
+  // same name, so a rank that has not exchanged anything yet looks the name up again while it waits: a different inode is the
+  // live segment, and the rank moves over (re-publishing the words of a first size exchange it has already posted).
+  ino_t ctl_ino = 0;
+  uint64_t last_words[2] = {0, 0};
+  bool in_allgather = false;
+  void follow_replacement() {
+    if (rank == 0 || !ctl || last_dst >= 0 || !(round == 0 || (round == 1 && in_allgather))) return;
+    for (uint64_t v : seen_msg)
+      if (v) return;
+    const std::string cn = seg("ctl");
+    const int fd = shm_open(cn.c_str(), O_RDWR, 0600);
+    if (fd < 0) return;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_ino == ctl_ino || (size_t)st.st_size < ctl_bytes) { close(fd); return; }
+    void* p = mmap(nullptr, ctl_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return;
+    Ctl* c = static_cast<Ctl*>(p);
+    if (c->magic.load(std::memory_order_acquire) != MAGIC || c->world != (uint64_t)world) { munmap(p, ctl_bytes); return; }   // (not set up yet: next time)
+    munmap(ctl, ctl_bytes);
+    ctl = c;
+    ctl_ino = st.st_ino;
+    Slot& me = ctl->slot[rank];
+    me.attached.store(1, std::memory_order_release);
+    if (round == 1) {
+      me.words[1][0] = last_words[0];
+      me.words[1][1] = last_words[1];
+      me.round.store(1, std::memory_order_release);
     }
   }
 
@@ -267,6 +302,7 @@ struct HostLink final : Link {
         if (c->magic.load(std::memory_order_acquire) == MAGIC && c->slot[rank].attached.load(std::memory_order_acquire) == 0 &&
             c->slot[rank].round.load(std::memory_order_relaxed) == 0 && c->slot[0].attached.load(std::memory_order_acquire) != 2) {
           ctl = c;
+          ctl_ino = st.st_ino;
           return true;
         }
         munmap(p, ctl_bytes);
@@ -311,14 +347,19 @@ struct HostLink final : Link {
     Slot& me = ctl->slot[rank];
     me.words[k & 1][0] = mine[0];
     me.words[k & 1][1] = mine[1];
+    last_words[0] = mine[0];
+    last_words[1] = mine[1];
     me.round.store(k, std::memory_order_release);
     for (int r = 0; r < world; ++r) {
-      Slot& s = ctl->slot[r];
-      if (!wait_for([&] { return s.round.load(std::memory_order_acquire) >= k; })) {
+      in_allgather = true;    // (the wait may move this rank to the segment that replaced a leftover: ctl is looked up in the loop)
+      const bool got = wait_for([&] { return ctl->slot[r].round.load(std::memory_order_acquire) >= k; });
+      in_allgather = false;
+      if (!got) {
         char b[96];
         snprintf(b, sizeof b, "timed out waiting for rank %d in the size exchange", r);
         return fail(-3, b);
       }
+      Slot& s = ctl->slot[r];
       all[2 * r] = s.words[k & 1][0];
       all[2 * r + 1] = s.words[k & 1][1];
     }

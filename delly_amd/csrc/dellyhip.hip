@@ -306,6 +306,7 @@ struct SmallInv { int32_t j, full_len, offset, take; };   // long-read loop, sma
 
 struct dellyhip_batch {
   bool ever_run = false;
+  bool lr_failed = false;   // a long-read team gave up in the last run: every sync / fetch / gather until the next run fails
   int probe_mode = 0;   // _generateProbes flavour: no early length test (src/split.h:647), bit 1 of params.reserved on the device
   int32_t n = 0;
   uint64_t n_seq = 0;
@@ -497,10 +498,17 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
 // split_sparse_wide_kernel over a list, behind split_sparse_kernel on the same stream (counted: see the kernel)
 int launch_sparse_wide(dellyhip_ctx* c, dh::SplitArgs a, const int32_t* list, int count, int counted, hipStream_t s) {
   if (count <= 0) return 0;
-  if (!c->spw_scratch.p) {
-    c->spw_blocks = std::max(64, std::min(512, c->n_cu * 2));
-    int rc = c->spw_scratch.alloc((size_t)(dh::spw_scratch_bytes() / 4) * c->spw_blocks);
-    if (rc) return rc;
+  // per-block tables (~428 KB each): sized from the list, not from the chip -- the kernel normally sees a handful of junctions and
+  // every slot of a dellyhip_stream is a context of its own (512 blocks were 224 MB per context, 1.3 GB per depth-6
+  // stream).  Grows (rarely) behind a stream synchronisation; dellyhip_trim_memory releases it.
+  const int want = std::min(std::max(64, std::min(512, c->n_cu * 2)), std::max(32, count));
+  if (!c->spw_scratch.p || c->spw_blocks < want) {
+    if (c->spw_scratch.p) (void)hipDeviceSynchronize();   // (an earlier launch, on whatever stream, may still be using the smaller block)
+    int blocks = 32;
+    while (blocks < want) blocks *= 2;
+    int rc = c->spw_scratch.alloc((size_t)(dh::spw_scratch_bytes() / 4) * blocks);
+    if (rc) { c->spw_blocks = 0; return rc; }
+    c->spw_blocks = blocks;
   }
   a.work_list = list;
   a.n_work = count;
@@ -1245,9 +1253,14 @@ __global__ __launch_bounds__(256) void fetch_out_kernel(const dellyhip_result* r
     if (lane < RW) reinterpret_cast<uint32_t*>(h_res + i)[lane] = w;
   }
   if (fits) {
-    const uint64_t n16 = ((reinterpret_cast<uintptr_t>(h_blob) | reinterpret_cast<uintptr_t>(compact)) & 15) ? 0 : used >> 4;
-    for (uint64_t q = tid; q < n16; q += nthr) reinterpret_cast<uint4*>(h_blob)[q] = reinterpret_cast<const uint4*>(compact)[q];
-    for (uint64_t q = (n16 << 4) + tid; q < used; q += nthr) h_blob[q] = compact[q];
+    // 16-byte pieces between a byte-wise head and tail; the host side gives `compact` the destination's alignment mod 16 (ADVICE r05:
+    // an unaligned out_blob fell back to byte-wise stores over PCIe for the whole blob, silently)
+    const uintptr_t ah = reinterpret_cast<uintptr_t>(h_blob) & 15, ac = reinterpret_cast<uintptr_t>(compact) & 15;
+    const uint64_t head = (ah == ac) ? min(used, (uint64_t)((16 - ah) & 15)) : used;
+    const uint64_t n16 = (used - head) >> 4;
+    for (uint64_t q = tid; q < head; q += nthr) h_blob[q] = compact[q];
+    for (uint64_t q = tid; q < n16; q += nthr) reinterpret_cast<uint4*>(h_blob + head)[q] = reinterpret_cast<const uint4*>(compact + head)[q];
+    for (uint64_t q = head + (n16 << 4) + tid; q < used; q += nthr) h_blob[q] = compact[q];
   }
   if (tid == 0) {
     status[0] = used;
@@ -1534,6 +1547,8 @@ uint64_t dellyhip_trim_memory(dellyhip_ctx* c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  c->spw_scratch.release();   // (lazily re-allocated by the next launch of split_sparse_wide_kernel)
+  c->spw_blocks = 0;
   return (uint64_t)DevPool::get().trim(c->device) + (uint64_t)PinPool::get().trim(c->device);
 }
 
@@ -2082,6 +2097,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   c->serial_valid = true;
   b->last = e3[2];
   b->pending = true;
+  b->lr_failed = false;
   b->launches++;
   b->ever_run = true;
   return 0;
@@ -2089,7 +2105,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
 
 int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
-  if (!b->pending) return 0;
+  if (!b->pending)   // (sticky until the next run: a second sync, a fetch, a gather or a stream collect after the error must not hand the records out)
+    return b->lr_failed ? fail(DELLYHIP_E_RUNTIME, "a long-read team of wavefronts gave up waiting: the junctions it was to sweep are not refined") : 0;
   if (getenv("DELLYHIP_TRACE_SYNC")) {   // (debugging aid: a batch that does not finish says how far its stream got)
     const auto t0 = std::chrono::steady_clock::now();
     while (hipEventQuery(b->last) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) std::this_thread::sleep_for(std::chrono::milliseconds(5));
@@ -2119,7 +2136,10 @@ int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
     int32_t flag = 0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(&flag, b->lr_team_state.p + dh::LRT_ERROR, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag) return fail(DELLYHIP_E_RUNTIME, "a long-read team of wavefronts gave up waiting: the junctions it was to sweep are not refined");
+    if (flag) {
+      b->lr_failed = true;
+      return fail(DELLYHIP_E_RUNTIME, "a long-read team of wavefronts gave up waiting: the junctions it was to sweep are not refined");
+    }
   }
   return 0;
 }
@@ -2160,8 +2180,8 @@ int dellyhip_batch_lr_team_stats(dellyhip_ctx* c, dellyhip_batch* b, int32_t out
   if (!c || !b || !out) return fail(DELLYHIP_E_ARG, "null argument");
   out[0] = out[1] = out[2] = out[3] = 0;
   int rc = dellyhip_batch_sync(c, b);
-  if (rc || !b->ever_run || b->lr_teams <= 0 || !b->lr_team_state.p) return rc;
-  HIPCHK(hipSetDevice(c->device));
+  if ((rc && !b->lr_failed) || !b->ever_run || b->lr_teams <= 0 || !b->lr_team_state.p) return rc;
+  HIPCHK(hipSetDevice(c->device));   // (a team that gave up: out[] is filled -- out[3] = 1 -- and the sync error returned)
   int32_t v[4];
   HIPCHK(hipMemcpy(v, b->lr_team_state.p, sizeof(v), hipMemcpyDeviceToHost));
 #ifdef DH_LR_TEAM_DEBUG
@@ -2182,7 +2202,7 @@ int dellyhip_batch_lr_team_stats(dellyhip_ctx* c, dellyhip_batch* b, int32_t out
   out[1] = std::min(v[dh::LRT_COUNT], b->lr.team_cap);   // junctions the teams took (the list's capacity bounds it)
   out[2] = v[dh::LRT_TAKEN];
   out[3] = v[dh::LRT_ERROR];
-  return 0;
+  return rc;
 }
 
 int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* c, dellyhip_batch* b, double* ms_dp) {
@@ -2296,7 +2316,12 @@ int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_resu
   int rc;
   if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
   // (the used bytes are not known here: room for the smaller of everything the batch can hold and what the caller can take)
-  if ((rc = b->blob_compact.reserve((size_t)std::max<uint64_t>(std::min<uint64_t>(cap, (uint64_t)b->n * b->out_stride), 16)))) return rc;
+  // the kernels' cap is what was RESERVED here, not the caller's: a record with lengths beyond its out_stride share would
+  // otherwise pass `off[n] <= cap` and overrun blob_compact.  (+16: the compacted bytes start at the destination's alignment mod 16.)
+  const uint64_t room = std::max<uint64_t>(std::min<uint64_t>(cap, (uint64_t)b->n * b->out_stride), 16);
+  if ((rc = b->blob_compact.reserve((size_t)room + 16))) return rc;
+  const uint64_t kcap = std::min<uint64_t>(cap, room);
+  uint8_t* compact = b->blob_compact.p + (reinterpret_cast<uintptr_t>(d_blob) & 15);
   if (!b->fetch_ev) HIPCHK(hipEventCreateWithFlags(&b->fetch_ev, hipEventDisableTiming));
   // on the device's download stream (the one dellyhip_stream returns its results on: verified to run beside the compute streams), behind
   // the end of the batch's run: the next launch on the batch's compute stream does not queue behind a PCIe-bound kernel.
@@ -2309,11 +2334,11 @@ int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_resu
   hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, b->n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p, b->blob_off.p,
-                     b->blob_compact.p, b->n, cap);
+                     compact, b->n, kcap);
   HIPCHK(hipGetLastError());
   const int32_t* lrt = (b->lr_teams > 0 && b->lr_team_state.p) ? b->lr_team_state.p + dh::LRT_ERROR : nullptr;
   hipLaunchKernelGGL(fetch_out_kernel, dim3(std::max(1, std::min(c->n_cu * 4, (b->n + 3) / 4))), dim3(256), 0, s, b->res.p, b->blob_off.p, b->n,
-                     b->blob_compact.p, static_cast<dellyhip_result*>(d_res), static_cast<uint8_t*>(d_blob), cap,
+                     compact, static_cast<dellyhip_result*>(d_res), static_cast<uint8_t*>(d_blob), kcap,
                      static_cast<uint64_t*>(d_status), lrt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(b->fetch_ev, s));

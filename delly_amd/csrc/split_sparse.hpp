@@ -230,7 +230,9 @@ __host__ __device__ inline uint64_t spw_scratch_bytes() {
 }
 __host__ __device__ inline bool sps_narrow_shape(int m, int n) { return m >= 1 && m <= SPS_MMAX && n <= SPS_NMAX && n + m + 1 <= SPS_ND; }
 
-// 0: not this kernel's junction (finished already, or a shape split_sparse_kernel was offered), 1: finished, 2: left to the dense kernels
+// 0: finished already, 1: finished here, 2: left to the dense kernels, 3: not finished and not this kernel's shape (a shape
+// split_sparse_kernel takes: in a counted launch that kernel has counted it as left; in an uncounted launch the host routed a
+// narrow junction here -- its window lengths disagree with the device's -- and it must still reach the dense kernels)
 __device__ __forceinline__ int process_sparse_wide(const SplitArgs& A, int j, SpwLds& L, uint32_t* scratch, int lane) {
   if (A.res[j].reserved == SPS_DONE) return 0;
   JCtx X;
@@ -245,7 +247,7 @@ __device__ __forceinline__ int process_sparse_wide(const SplitArgs& A, int j, Sp
   }
   const int m = X.m, n = X.n;
   if (m < 1 || n < 1 || m > MMAX || n > NMAX) return 2;
-  if (sps_narrow_shape(m, n)) return 0;   // (split_sparse_kernel had it: what it left needs more than 32 levels, or has unclean letters)
+  if (sps_narrow_shape(m, n)) return 3;   // (split_sparse_kernel had it: what it left needs more than 32 levels, or has unclean letters)
   if (X.dirty) return 2;
   SparseWs W;
   W.ndp = (n + m + 2 + 63) & ~63;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(WAVE, 3) void split_sparse_wide_kernel(SplitArgs A,
     const int r = process_sparse_wide(A, j, L, scratch, ln);
     if (lane == 0 && A.sps_left) {
       if (counted && r == 1) atomicSub(A.sps_left, 1);
-      if (!counted && r == 2) atomicAdd(A.sps_left, 1);
+      if (!counted && r >= 2) atomicAdd(A.sps_left, 1);   // (r == 3: ADVICE r05 -- never leave a junction unrefined without saying so)
     }
     __syncthreads();
   }

@@ -292,7 +292,8 @@ int dellyhip_batch_sparse_left(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t* le
  * the last run the teams swept, out[2] = claims the teams made on the list (>= out[0]: every team ends with one that finds nothing), out[3] = 1 if a team gave up waiting
  * (the junction it was on carries status DELLYHIP_E_RUNTIME; since round 5 dellyhip_batch_sync -- and with it fetch, the stream
  * and the gather -- FAILS such a batch with DELLYHIP_E_RUNTIME: junctions still on the teams' list would otherwise come back
- * as "not refined", indistinguishable from a consensus the reference rejects).  Synchronises the batch. */
+ * as "not refined", indistinguishable from a consensus the reference rejects; the failure is sticky until the batch's next
+ * run).  Synchronises the batch; for such a batch out[] is filled (out[3] = 1) AND the sync's error code is returned. */
 int dellyhip_batch_lr_team_stats(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t out[4]);
 /* msa() batches: how the LAST RUN ON THIS CONTEXT went through the MSA kernels (counters of the context, like
  * dellyhip_batch_sparse_left).  out[0] = junctions the score-table kernel deferred to the direct-float kernel (a node with

@@ -53,6 +53,27 @@ def test_async_fetch_equals_blocking_fetch(gpu_ctx, mode, n):
     gpu_ctx.host_unregister(rec.ctypes.data); gpu_ctx.host_unregister(blob.ctypes.data)
 
 
+@pytest.mark.parametrize("shift", [1, 4, 9])
+def test_async_fetch_into_a_destination_that_is_not_16_byte_aligned(gpu_ctx, shift):
+    """an unaligned out_blob takes a byte-wise head, 16-byte pieces, a byte-wise tail -- same bytes"""
+    n = 1200
+    b = synth.make_batch(n, mode="c2", seed=13)
+    gpu_ctx.set_chromosomes(b.chroms)
+    rb = gpu_ctx.upload(b)
+    rb.run(); rb.sync()
+    want_r, want_b = rb.fetch()
+    keep_r, rec = _pinned(gpu_ctx, n * RB)
+    keep_b, blob0 = _pinned(gpu_ctx, n * 3100 + 4096)
+    blob = blob0[shift:]
+    rec[:] = 0xEE; blob0[:] = 0xEE
+    rb.fetch_begin(rec, blob)
+    used = rb.fetch_end()
+    _same(rec, blob, used, want_r, want_b)
+    assert (blob0[:shift] == 0xEE).all() and (blob[used:used + 64] == 0xEE).all()
+    rb.free()
+    gpu_ctx.host_unregister(rec.ctypes.data); gpu_ctx.host_unregister(blob0.ctypes.data)
+
+
 def test_async_fetch_vs_reference_through_a_segment_with_the_next_runs_queued(gpu_ctx, reference):
     """the step of bench.py --gpus N: two resident batches on two contexts / streams; run(k), publish the return of k - 2, queue the
     return of k - 1 -- what the segment holds after every step is the reference's answer for that batch"""

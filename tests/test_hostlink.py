@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _worker(name, rank, world, script, q):
+def _worker(name, rank, world, script, q, start_delay=0.0):
     try:
         os.environ["DELLYHIP_LINK_TIMEOUT_S"] = "20"
+        time.sleep(start_delay)
         from delly_amd import refine
         comm = refine.Comm(None, rank, world, hostlink=name)
         out = []
@@ -44,11 +45,11 @@ def _worker(name, rank, world, script, q):
         q.put((rank, [("crash", repr(e))]))
 
 
-def _run(world, script, timeout=60):
+def _run(world, script, timeout=60, name=None, start_delay=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    name = "t%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000000)
-    ps = [ctx.Process(target=_worker, args=(name, r, world, script, q)) for r in range(world)]
+    name = name or "t%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000000)
+    ps = [ctx.Process(target=_worker, args=(name, r, world, script, q, (start_delay or {}).get(r, 0.0))) for r in range(world)]
     for p in ps:
         p.start()
     got = {}
@@ -133,6 +134,31 @@ def test_alternating_roots_with_a_slow_sender():
             tag, (data, got_sz) = outs[k]
             assert tag == "ok" and got_sz == sz
             assert data == (want if r == root else None)
+
+
+def test_leftover_segment_of_a_run_that_crashed_before_the_peer_attached():
+    # a control segment left by a run that died after rank 0 attached and before rank 1 did looks fresh to rank 1
+    # (MAGIC set, its own slot untouched, rank 0 not marked "left").  Rank 1 starts first and attaches to the corpse; rank 0 of the
+    # new run then unlinks it and creates the live segment: rank 1 must move over instead of waiting out its deadline.
+    import struct
+    name = "stale%d_%d" % (os.getpid(), int(time.time() * 1e3) % 100000000)
+    path = "/dev/shm/dellyhip_%s_ctl" % name
+    slot = 8 + 8 + 32 + 64 * 8 + 64 * 8 + 8 + 8 + 8 * 8 + 64     # HostLink::Slot (comm.hpp)
+    corpse = bytearray(16 + 2 * slot)
+    struct.pack_into("<QQQ", corpse, 0, 0x64656c6c79686c31, 2, 1)  # magic, world, slot[0].attached = 1
+    with open(path, "wb") as f:
+        f.write(corpse)
+    try:
+        t0 = time.time()
+        got = _run(2, [("sizes", -1), ("gather", [10, 2000], 0, 1 << 20)], name=name, start_delay={0: 1.5})
+        assert time.time() - t0 < 15, "rank 1 waited for its deadline instead of following the replaced segment"
+        for r in range(2):
+            assert got[r][0] == ("ok", [(100, 1000), (101, 2000)]), got[r]
+            assert got[r][1][0] == "ok"
+        assert got[0][1][1][0] == b"A" * 10 + b"B" * 2000
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def test_a_missing_peer_is_an_error_not_a_hang():
