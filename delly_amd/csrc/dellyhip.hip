@@ -282,6 +282,8 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int lrc_waves = 2;         // resident wavefronts per SIMD of the long-read consensus kernels (lrmsa_kernel / lrwfa_kernel: one junction per wavefront,
+                             // 145 / 171 VGPRs = 3 / 2 per SIMD by registers; env DELLYHIP_LRC_WAVES; round 5 launched one per SIMD)
   int lr_waves = 8;          // resident wavefronts of the strip kernel per CU when the sparse passes are on (env DELLYHIP_LR_WAVES)
   int lr_team_serial = 0;    // env DELLYHIP_LR_TEAMS_SERIAL (A/B)
   int lr_teams = 64;         // teams of lr_dense_team_kernel at most (env DELLYHIP_LR_TEAMS; 0: the dense strips stay on lr_kernel's wavefronts)
@@ -1488,6 +1490,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LR_WAVES")) c->lr_waves = std::max(1, std::min(8, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_LRC_WAVES")) c->lrc_waves = std::max(1, std::min(4, atoi(t)));
   if (const char* t = getenv("DELLYHIP_LR_TEAMS")) c->lr_teams = std::max(0, std::min(256, atoi(t)));
   if (const char* t = getenv("DELLYHIP_LR_TEAMS_SERIAL")) c->lr_team_serial = atoi(t) ? 1 : 0;
   if (const char* t = getenv("DELLYHIP_SPS_WAVES")) c->sps_waves = std::max(1, std::min(20, atoi(t)));
@@ -1808,7 +1811,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         return bail(rc);
       dh::LrMsaArgs& M = b->lm;
       lm_layout(M, maxlen);
-      b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4));
+      b->lm_blocks = std::max(1, std::min(n, c->n_cu * 4 * c->lrc_waves));
       b->lm_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->lm_blocks, ws_budget_bytes() / std::max<uint64_t>(M.ws_stride, 1)));
       if ((rc = b->lm_ws.reserve((size_t)M.ws_stride * b->lm_blocks))) return bail(rc);
       M.ws = b->lm_ws.p;
@@ -1821,7 +1824,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
       b->wfa_count = (int)wl.size();
       if (b->wfa_count) {
         wfa_layout(b->wfa, maxlen);
-        b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 4));
+        b->wfa_blocks = std::max(1, std::min(b->wfa_count, c->n_cu * 4 * c->lrc_waves));
         b->wfa_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(b->wfa_blocks, ws_budget_bytes() / std::max<uint64_t>(b->wfa.ws_stride, 1)));
         if ((rc = push(b->wfa_list, wl.data(), wl.size(), 0, "H2D wfa list")) || (rc = b->wfa_ws.reserve((size_t)b->wfa.ws_stride * b->wfa_blocks))) return bail(rc);
         e = hipMemsetAsync(b->wfa_ws.p, 0, (size_t)b->wfa.ws_stride * b->wfa_blocks, c->stream);   // k-mer tables start (and are kept) all zero
@@ -2362,6 +2365,17 @@ int dellyhip_batch_fetch_end(dellyhip_ctx* c, dellyhip_batch* b, uint64_t* out_b
   if (flags & 1) return fail(DELLYHIP_E_ARG, "out_blob too small");
   return 0;
 }
+
+#ifdef DH_LR_TIMING
+// profiling builds only (tools/lrc_phases.py): the phase clocks of lrmsa_kernel / lrwfa_kernel (lrmsa_kernel.hpp), read and cleared
+extern "C" int dellyhip_debug_lrt(uint64_t* out, int n) {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dh::dh_lrt), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 32; ++i) out[i] = h[i];
+  memset(h, 0, sizeof h);
+  return hipMemcpyToSymbol(HIP_SYMBOL(dh::dh_lrt), h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef DH_SPS_DBG
 // profiling builds only (tools/sps_dbg.py): the counters of sparse_needle.hpp, read and cleared

@@ -21,6 +21,26 @@
 
 namespace dh {
 
+// DH_LR_TIMING builds (tools/lrc_phases.py): where a junction's wavefront spends its time, summed over the launch (100 MHz ticks).
+// Slots: 1 seeding (k-mer tables, diagonal votes), 2 superstring NW paths (whole), 3 buildSuperstring, 4 column votes (consensusWfa /
+// consensusEdlib), 5 forward location pass, 6 reverse location pass, 7 Hirschberg last-row passes, 8 direction fill of the base
+// rectangles, 9 tracebacks + op reversal, 10 convertAlignment, 11 final consensus + trimming, 12 Hirschberg split search,
+// 13 progressive NW / HW paths (whole), 14 junctions, 15 whole junction
+#ifdef DH_LR_TIMING
+__device__ unsigned long long dh_lrt[32];
+__device__ __forceinline__ unsigned long long& lrt_t0() {
+  __shared__ unsigned long long t0;
+  return t0;
+}
+#define LRT_START() do { if (lane == 0) lrt_t0() = wall_clock64(); } while (0)
+#define LRT_LAP(slot) do { if (lane == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&dh_lrt[slot], n_ - lrt_t0()); lrt_t0() = n_; } } while (0)
+#define LRT_ADD(slot, v) do { if (lane == 0) atomicAdd(&dh_lrt[slot], (unsigned long long)(v)); } while (0)
+#else
+#define LRT_START() do { } while (0)
+#define LRT_LAP(slot) do { } while (0)
+#define LRT_ADD(slot, v) do { } while (0)
+#endif
+
 constexpr int LM_NR = 32;                 // reads per junction (delly lr: maxReadPerSV = 15 by default, -p; src/tegua.h:241)
 constexpr int LM_STACK = 24;              // Hirschberg sub-problems in flight (depth <= log2 of the longer side + 1)
 constexpr int LM_RBITS = 15;              // row index bits of the location keys: target rows <= 32766, E < 2^17
@@ -722,11 +742,14 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
       2 * bv_words <= dirs_cap) {
     uint32_t* planeH = dirs;
     uint32_t* planeV = dirs + bv_words;
+    LRT_LAP(12);
     if (bv_nw == 1) lm_dirs_myers<1>(t, tlen, qy, qlen, planeH, planeV, lane);
     else if (bv_nw == 2) lm_dirs_myers<2>(t, tlen, qy, qlen, planeH, planeV, lane);
     else lm_dirs_myers<3>(t, tlen, qy, qlen, planeH, planeV, lane);
+    LRT_LAP(8);
     tl = lm_traceback_planes(planeH, planeV, bv_nw, bv_nl1, t, qy, rr, cc, tmp, lane);
   } else {
+    LRT_LAP(12);
     for (int q = 0; q < Q; ++q) {
       const int32_t* bin = (q > 0) ? ((q & 1) ? bndA : bndB) : nullptr;
       int32_t* bout = (q + 1 < Q) ? ((q & 1) ? bndB : bndA) : nullptr;
@@ -734,6 +757,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    LRT_LAP(8);
     GeoLR G{dirs, strip_words};
     tl = traceback_runs<true>(G, rr, cc, tmp, lane);
   }
@@ -747,6 +771,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
   for (int k = lane; k < tl; k += WAVE) ops[pos + k] = tmp[tl - 1 - k];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  LRT_LAP(9);
   return pos + tl;
 }
 
@@ -772,20 +797,189 @@ inline uint64_t lm_dirs_words(int tcap, int qcap) {
   return best + 64;
 }
 
-// edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment  (obtainAlignment,
-// edlib.cpp:1163-1389).  Returns the op count, ops[] in forward order; -1 on overflow.
+// Hirschberg split of a rectangle with query length ql (edlib.cpp:1328-1345): the optimum of left[i] + right[ql - i] and the
+// first query index that reaches it (ascending over 1 .. ql - 1, then the two boundary cases)
+__device__ __forceinline__ int lm_split_column(const int32_t* left, const int32_t* right, int ql, int lane) {
+  int best = 1 << 30;
+  for (int i = lane; i <= ql; i += WAVE) best = min(best, left[i] + right[ql - i]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o));
+  best = rfl(best);
+  int ul = -1;
+  for (int base = 1; base <= ql - 1 && ul < 0; base += WAVE) {
+    const int i = base + lane;
+    const bool hit = (i <= ql - 1) && (left[i] + right[ql - i] == best);
+    const unsigned long long bm = __ballot(hit);
+    if (bm) ul = base + __builtin_ctzll(bm);
+  }
+  if (ul < 0) ul = (left[0] + right[ql] == best) ? 0 : ql;
+  return rfl(ul);
+}
+
+// ---- Hirschberg levels breadth first: every last-row pass of a level in ONE wavefront (round 6) ----------------------------
+// The depth-first recursion below runs 2 + 4 + 8 + ... last-row passes, one after the other, each with one column per step
+// whatever its row count: a 475-row pass of the third level keeps 15 of the 64 lanes busy, and every level costs as much
+// as the first (profiles/r06/lrc_phases_start.txt: 44 % of a msaWfa junction, 41 % of a msaEdlib junction).  But the rectangles
+// of one level partition the target, so the rows of ALL their passes together are the rows of the first level's two: they fit
+// the lanes of one wavefront side by side.  lm_last_rows_packed runs them as SEGMENTS of lanes -- each with its own target
+// slice, direction, query slice and output row -- in one column loop whose length is the level's longest query slice, so
+// level k costs 1 / 2^k of the first instead of as much again.  The query's class indices are staged once in LDS (nibbles);
+// a lane reads the class of its own column there, so no letter travels through the lanes and a segment can start anywhere.
+// The rectangle list lives in LDS in left-to-right order; when every rectangle is in the traceback regime (or the list is
+// full) the depth-first code finishes each one in order, so the op string is edlib's byte for byte as before.
+constexpr int LM_BFS_RECTS = 32;      // rectangles of a level (a 4 kb x 4 kb alignment ends with 8)
+constexpr int LM_QCLS_CAP = 8192;     // query letters the class-index table holds (two per byte)
+struct __attribute__((aligned(16))) LmBfsLds {
+  int rect[2][LM_BFS_RECTS][4];       // (t0, tl, q0, ql), two generations
+  int roff[LM_BFS_RECTS];             // where the rectangle's two score rows start in the left / right row buffers; -1: not split at this level
+  unsigned seg[2 * LM_BFS_RECTS];     // segment 2r = left half of rectangle r, 2r + 1 = right half: first lane | lanes << 8 | pass << 16
+  uint8_t qcls[LM_QCLS_CAP / 2];
+};
+__device__ __forceinline__ LmBfsLds& lm_bfs_lds() {
+  __shared__ LmBfsLds B;
+  return B;
+}
+__device__ __forceinline__ bool lm_traceback_regime(int tl, int ql) {   // edlib.cpp:1185-1191
+  const long long blocks = (ql + 63) / 64;
+  return (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl < 1024 * 1024;
+}
+
+// the last-row passes of pass `pass` of the current level (segments assigned by lm_nw_path): for the left half of rectangle
+// r, Lrow[roff + i] = distance(t[t0 .. t0 + lw), q[q0 .. q0 + i)); for the right half, Rrow[roff + k] = distance of the
+// reversed strings (last k query letters against t[t0 + lw .. t0 + tl)) -- what lm_last_row_myers computes one at a time
+template <int NWORDS>
+__device__ __noinline__ void lm_last_rows_packed(const uint8_t* target_, int nrect, int cur, int pass, int32_t* Lrow_, int32_t* Rrow_,
+                                                 int lane) {
+  LmBfsLds& B = lm_bfs_lds();
+  uint32_t* E = lm_eq_lds();
+  const gptr_cu8 target = (gptr_cu8)target_;
+  int myseg = -1, off = 0, nl = 0;
+  for (int k = 0; k < 2 * nrect; ++k) {
+    const unsigned d = B.seg[k];
+    const int fl = (int)(d & 255u), n = (int)((d >> 8) & 255u);
+    if ((int)(d >> 16) == pass && lane >= fl && lane < fl + n) { myseg = k; off = lane - fl; nl = n; }
+  }
+  const bool mine = myseg >= 0;
+  const int r = mine ? (myseg >> 1) : 0;
+  const bool right = mine && (myseg & 1);
+  const int t0 = B.rect[cur][r][0], tl = B.rect[cur][r][1], q0 = B.rect[cur][r][2];
+  const int ql = mine ? B.rect[cur][r][3] : 0;
+  const int lw = tl / 2, rw = tl - lw;
+  const int tlen = mine ? (right ? rw : lw) : 0;
+  const int tbase = right ? t0 + tl - 1 : t0, tstep = right ? -1 : 1;
+  const int qbase = right ? q0 + ql - 1 : q0, qdir = right ? -1 : 1;
+  const gptr_i32 out = (gptr_i32)(right ? Rrow_ : Lrow_) + (mine ? B.roff[r] : 0);
+  const bool is_head = off == 0, is_tail = mine && off == nl - 1;
+  const int row0 = off * 32 * NWORDS;
+  uint32_t mk[NWORDS];   // rows of this lane at or beyond tlen (their vertical deltas are taken off the bottom score)
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+#pragma unroll
+    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
+    const int lo = row0 + w * 32;
+    const int nb = min(32, max(0, lo + 32 - tlen));
+    mk[w] = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? (~0u << (32 - nb)) : 0u);
+    for (int q = 0; q < 32; ++q) {
+      const int rr = lo + q;
+      if (rr < tlen) {
+        const int x = iupac_index((int)target[tbase + rr * tstep]);
+        uint32_t pm = (1u << x) | iupac_partners(x);
+        while (pm) {
+          const int y = __builtin_ctz(pm);
+          pm &= pm - 1;
+          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
+        }
+      }
+    }
+  }
+  int T = mine ? ql + off : 0;   // steps until this lane has seen its last column
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) T = max(T, __shfl_xor(T, o));
+  T = rfl(T);
+  uint32_t Pv[NWORDS], Mv[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) {
+    Pv[w] = 0xffffffffu;
+    Mv[w] = 0;
+  }
+  int score = row0 + 32 * NWORDS;
+  int hcarry = 1;
+  // class of this lane's column at step t (x WAVE: the slot offset in E); 15 = none outside the segment's columns
+  auto load_cls = [&](int t) -> int {
+    const int c = t - off;
+    const bool in = mine && (unsigned)c < (unsigned)ql;
+    const int a = in ? qbase + qdir * c : 0;
+    const int nib = ((int)B.qcls[a >> 1] >> ((a & 1) * 4)) & 15;
+    return (in ? nib : 15) * WAVE;
+  };
+  int clsN = load_cls(0), clsNN = load_cls(1);
+  uint32_t EqN[NWORDS];
+#pragma unroll
+  for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + clsN + lane];
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    uint32_t EqC[NWORDS];
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) EqC[w] = EqN[w];
+    clsN = clsNN;
+    clsNN = load_cls(t + 2);
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) EqN[w] = E[w * 16 * WAVE + clsN + lane];
+    int hin = dpp_from_prev(hcarry, 1);
+    hin = is_head ? 1 : hin;          // E[0][c] - E[0][c-1] = 1 above a segment's first row
+    const int c = t - off;
+    const bool valid = mine && (unsigned)c < (unsigned)ql;
+    uint32_t nP[NWORDS], nM[NWORDS];
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) {
+      uint32_t Eq = EqC[w];
+      const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470
+      const uint32_t Xv = Eq | Mv[w];
+      Eq |= hinNeg;
+      const uint32_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+      uint32_t Ph = Mv[w] | ~(Xh | Pv[w]);
+      uint32_t Mh = Pv[w] & Xh;
+      const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+      Ph <<= 1;
+      Mh <<= 1;
+      Mh |= hinNeg;
+      Ph |= (hin > 0) ? 1u : 0u;
+      nP[w] = Mh | ~(Xv | Ph);
+      nM[w] = Ph & Xv;
+      hin = hout;
+    }
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) {
+      Pv[w] = valid ? nP[w] : Pv[w];
+      Mv[w] = valid ? nM[w] : Mv[w];
+    }
+    hcarry = valid ? hin : hcarry;
+    score += valid ? hin : 0;
+    if (is_tail && valid) {   // E[tlen][c + 1] in the lane that owns row tlen
+      int sc = score;
+#pragma unroll
+      for (int w = 0; w < NWORDS; ++w) sc += __popc(Mv[w] & mk[w]) - __popc(Pv[w] & mk[w]);
+      out[c + 1] = sc;
+    }
+  }
+  if (mine && is_head) out[0] = tlen;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment of ONE rectangle, depth first (obtainAlignment,
+// edlib.cpp:1163-1389); ops appended at `pos`, returns the new position or -1 on overflow.
 // (`strip_words` = capacity of `dirs` in words, lm_dirs_words())
-__device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int mode, int32_t* bnd,
-                                          int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
-                                          uint8_t* ops, int ops_cap, int lane) {
+__device__ __forceinline__ int lm_nw_dfs(const uint8_t* target, const uint8_t* query, int rt0, int rtl, int rq0, int rql, int mode,
+                                         int32_t* bnd, int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                         uint8_t* ops, int ops_cap, int pos, int lane) {
   // explicit stack of rectangles (t0, tlen, q0, qlen), processed left to right.  In LDS: indexed by the stack pointer, a local
   // array would live in scratch memory (384 B per lane in every kernel that aligns long strings; one wavefront per workgroup
   // in all of them, and one path at a time)
   __shared__ int st[LM_STACK][4];
   int sp = 0;
-  st[sp][0] = 0; st[sp][1] = tn; st[sp][2] = 0; st[sp][3] = qn;
+  st[sp][0] = rt0; st[sp][1] = rtl; st[sp][2] = rq0; st[sp][3] = rql;
   ++sp;
-  int pos = 0;
   int32_t* bndA = bnd;
   int32_t* bndB = bnd + bnd_stride;
   int32_t* left = bnd + 2 * bnd_stride;
@@ -800,37 +994,118 @@ __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const u
       pos += tl + ql;
       continue;
     }
-    const long long blocks = (ql + 63) / 64;
-    const long long sz = (2ll * 8 + 4) * blocks * tl + 2ll * 4 * tl;
-    if (sz < 1024 * 1024) {
+    if (lm_traceback_regime(tl, ql)) {
       if ((uint64_t)(tl / LRS + 1) * lr_strip_words(ql) > strip_words) return -1;   // (direction area: sized by lm_dirs_words)
       pos = lm_plain_path(target + t0, tl, query + q0, ql, mode, bndA, bndB, dirs, strip_words, tmp, ops, pos, lane);
       continue;
     }
     // Hirschberg step
     const int lw = tl / 2, rw = tl - lw;
+    LRT_LAP(12);
     lm_last_row(target + t0, 1, lw, query + q0, 1, ql, mode, bndA, bndB, left, lane);                        // left[i]  : q[0..i) vs t[0..lw)
     lm_last_row(target + t0 + tl - 1, -1, rw, query + q0 + ql - 1, -1, ql, mode, bndA, bndB, right, lane);   // right[k] : last k letters of q vs t[lw..)
-    // optimum and the first query index that reaches it (ascending), then the two boundary cases
-    int best = 1 << 30;
-    for (int i = lane; i <= ql; i += WAVE) best = min(best, left[i] + right[ql - i]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o));
-    best = rfl(best);
-    int ul = -1;
-    for (int base = 1; base <= ql - 1 && ul < 0; base += WAVE) {
-      const int i = base + lane;
-      const bool hit = (i <= ql - 1) && (left[i] + right[ql - i] == best);
-      const unsigned long long bm = __ballot(hit);
-      if (bm) ul = base + __builtin_ctzll(bm);
-    }
-    if (ul < 0) ul = (left[0] + right[ql] == best) ? 0 : ql;
-    ul = rfl(ul);
+    LRT_LAP(7);
+    const int ul = lm_split_column(left, right, ql, lane);
     if (sp + 2 > LM_STACK) return -1;
     st[sp][0] = t0 + lw; st[sp][1] = rw; st[sp][2] = q0 + ul; st[sp][3] = ql - ul;   // lower right (second)
     ++sp;
     st[sp][0] = t0; st[sp][1] = lw; st[sp][2] = q0; st[sp][3] = ul;                  // upper left (first)
     ++sp;
+  }
+  return pos;
+}
+
+// edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment.  Returns the op count, ops[] in forward order;
+// -1 on overflow.  Hirschberg levels breadth first with packed last-row passes while the compare-free regime and the LDS
+// tables allow (see above), then depth first from every rectangle of the list.
+__device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const uint8_t* query, int qn, int mode, int32_t* bnd,
+                                          int bnd_stride, uint32_t* dirs, uint64_t strip_words, uint8_t* tmp,
+                                          uint8_t* ops, int ops_cap, int lane) {
+  LmBfsLds& B = lm_bfs_lds();
+  int cur = 0, nrect = 1;
+  if (lane == 0) { B.rect[0][0][0] = 0; B.rect[0][0][1] = tn; B.rect[0][0][2] = 0; B.rect[0][0][3] = qn; }
+  int32_t* left = bnd + 2 * bnd_stride;
+  int32_t* right = bnd + 3 * bnd_stride;
+  const bool packed = (mode & LM_EQ) && (mode & LM_EQFAST) && qn >= 1 && tn >= 2 && qn <= LM_QCLS_CAP && tn <= 2 * MYERS_ROWS &&
+                      qn + LM_BFS_RECTS < bnd_stride && !lm_traceback_regime(tn, qn);
+  if (packed) {
+    LRT_LAP(12);
+    for (int i = lane; i < (qn + 1) / 2; i += WAVE) {   // (compare-free regime: every letter is one of the 15 classes)
+      const int lo = iupac_index((int)query[2 * i]);
+      const int hi = (2 * i + 1 < qn) ? iupac_index((int)query[2 * i + 1]) : 15;
+      B.qcls[i] = (uint8_t)((lo & 15) | ((hi & 15) << 4));
+    }
+    __syncthreads();
+    for (;;) {
+      int t0 = 0, tl = 0, q0 = 0, ql = 0;
+      if (lane < nrect) { t0 = B.rect[cur][lane][0]; tl = B.rect[cur][lane][1]; q0 = B.rect[cur][lane][2]; ql = B.rect[cur][lane][3]; }
+      const bool split = lane < nrect && ql > 0 && tl >= 2 && !lm_traceback_regime(tl, ql);
+      const unsigned long long sm = __ballot(split);
+      const int nsplit = __popcll(sm);
+      if (nsplit == 0 || nrect + nsplit > LM_BFS_RECTS) break;
+      const int lw = tl / 2, rw = tl - lw;
+      int nw = 3;   // words per lane: the smallest that seats every segment of the level in one pass
+      {
+        int need1 = split ? (lw + 31) / 32 + (rw + 31) / 32 : 0, need2 = split ? (lw + 63) / 64 + (rw + 63) / 64 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { need1 += __shfl_xor(need1, o); need2 += __shfl_xor(need2, o); }
+        nw = (rfl(need1) <= WAVE) ? 1 : ((rfl(need2) <= WAVE) ? 2 : 3);
+      }
+      const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      if (lane < nrect) {
+        B.roff[lane] = split ? q0 + __popcll(sm & below) : -1;
+        B.seg[2 * lane] = split ? (unsigned)((lw + 32 * nw - 1) / (32 * nw)) : 0u;
+        B.seg[2 * lane + 1] = split ? (unsigned)((rw + 32 * nw - 1) / (32 * nw)) : 0u;
+      }
+      __syncthreads();
+      int npass = 0, used = 0;
+      for (int k = 0; k < 2 * nrect; ++k) {   // greedy seating, left to right (uniform)
+        const int n = rfl((int)B.seg[k]);
+        unsigned d = 0xffffffffu;
+        if (n > 0) {
+          if (used + n > WAVE) { ++npass; used = 0; }
+          d = (unsigned)used | ((unsigned)n << 8) | ((unsigned)npass << 16);
+          used += n;
+        }
+        if (lane == 0) B.seg[k] = d;
+      }
+      npass += 1;
+      __syncthreads();
+      for (int p = 0; p < npass; ++p) {
+        if (nw == 1) lm_last_rows_packed<1>(target, nrect, cur, p, left, right, lane);
+        else if (nw == 2) lm_last_rows_packed<2>(target, nrect, cur, p, left, right, lane);
+        else lm_last_rows_packed<3>(target, nrect, cur, p, left, right, lane);
+      }
+      LRT_LAP(7);
+      // next generation, in order: a rectangle that was not split stays, a split one becomes its two halves
+      int at = 0;
+      for (int r = 0; r < nrect; ++r) {
+        const int rt0 = rfl(B.rect[cur][r][0]), rtl = rfl(B.rect[cur][r][1]), rq0 = rfl(B.rect[cur][r][2]), rql = rfl(B.rect[cur][r][3]);
+        const int ro = rfl(B.roff[r]);
+        if (ro < 0) {
+          if (lane == 0) { B.rect[cur ^ 1][at][0] = rt0; B.rect[cur ^ 1][at][1] = rtl; B.rect[cur ^ 1][at][2] = rq0; B.rect[cur ^ 1][at][3] = rql; }
+          at += 1;
+        } else {
+          const int ul = lm_split_column(left + ro, right + ro, rql, lane);
+          const int rlw = rtl / 2;
+          if (lane == 0) {
+            B.rect[cur ^ 1][at][0] = rt0; B.rect[cur ^ 1][at][1] = rlw; B.rect[cur ^ 1][at][2] = rq0; B.rect[cur ^ 1][at][3] = ul;
+            B.rect[cur ^ 1][at + 1][0] = rt0 + rlw; B.rect[cur ^ 1][at + 1][1] = rtl - rlw; B.rect[cur ^ 1][at + 1][2] = rq0 + ul; B.rect[cur ^ 1][at + 1][3] = rql - ul;
+          }
+          at += 2;
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+      nrect = at;
+      LRT_LAP(12);
+    }
+  }
+  __syncthreads();
+  int pos = 0;
+  for (int r = 0; r < nrect && pos >= 0; ++r) {
+    const int rt0 = rfl(B.rect[cur][r][0]), rtl = rfl(B.rect[cur][r][1]), rq0 = rfl(B.rect[cur][r][2]), rql = rfl(B.rect[cur][r][3]);
+    pos = lm_nw_dfs(target, query, rt0, rtl, rq0, rql, mode, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, pos, lane);
   }
   return pos;
 }
@@ -887,7 +1162,9 @@ __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* 
                                        uint8_t* ops, int ops_cap, int lane) {
   LmRes o;
   int first, last;
+  LRT_LAP(12);
   lm_locate(T, 1, tn, Qy, 1, qn, (mode & (LM_EQ | LM_EQFAST)) | LM_HW, bnd, bnd + bnd_stride, lane, o.ed, first, last);
+  LRT_LAP(5);
   o.endLoc = first - 1;
   o.startLoc = 0;
   o.nops = 0;
@@ -898,6 +1175,7 @@ __device__ __forceinline__ LmRes lm_hw(const uint8_t* T, int tn, const uint8_t* 
   }
   int ed2, f2, l2;
   lm_locate(T + o.endLoc, -1, o.endLoc + 1, Qy + (qn - 1), -1, qn, mode & (LM_EQ | LM_EQFAST), bnd, bnd + bnd_stride, lane, ed2, f2, l2);
+  LRT_LAP(6);
   o.startLoc = o.endLoc - (l2 - 1);
   if (!path) return o;
   const int tl2 = o.endLoc - o.startLoc + 1;
@@ -931,6 +1209,10 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
   const int N = J.n_seq;
   if (J.svt == 4) return;   // insertions: msaWfa (lrwfa_kernel.hpp)
   int status = 0, cons_len = 0, rows = 0;
+#ifdef DH_LR_TIMING
+  const unsigned long long lrt_j0 = wall_clock64();
+  LRT_START();
+#endif
   uint8_t* alnA = ws;
   uint8_t* alnB = ws + A.off_alnB;
   uint8_t* astr = ws + A.off_astr;
@@ -1041,11 +1323,19 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LRT_LAP(4);
         const int rd = L.sel[step];
         const uint8_t* qy = blob + L.roff[rd];
         const int qn = L.rlen[rd];
         const int eqmode = LM_EQ | ((lm_in_classes(astr, 1, acols, lane) && lm_in_classes(qy, 1, qn, lane)) ? LM_EQFAST : 0);
+#ifdef DH_LR_TIMING
+        const unsigned long long lrt_p0 = wall_clock64();
+#endif
         const int nops = lm_nw_path(astr, acols, qy, qn, eqmode, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, acap + A.ncap, lane);
+#ifdef DH_LR_TIMING
+        LRT_ADD(13, wall_clock64() - lrt_p0);
+        LRT_LAP(12);
+#endif
         if (nops < 0 || nops > acap - 1) { status = DELLYHIP_E_LIMIT; break; }   // (the next target must fit the strips)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1067,6 +1357,7 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LRT_LAP(10);
         uint8_t* sw = cur; cur = nxt; nxt = sw;
         arows += 1;
         acols = nops;
@@ -1091,6 +1382,11 @@ __device__ void lrmsa_junction(const LrMsaArgs& A, int j, LrMsaLds& L, uint8_t* 
       }
     }
   }
+#ifdef DH_LR_TIMING
+  LRT_LAP(11);
+  LRT_ADD(14, 1);
+  LRT_ADD(15, wall_clock64() - lrt_j0);
+#endif
   if (lane == 0) {
     out->sr_support = rows;
     out->status = status;

@@ -270,6 +270,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
     }
 #ifdef DH_LR_TIMING
     tw0 = tw1 = tw2 = wall_clock64();
+    LRT_START();
 #endif
     if (!status) {
       // ---- pairwise scores: diagonal seeding, trimmed NW distance, per mille of the length (:551-574)
@@ -358,6 +359,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int bd = wfa_best_diagonal(rd, (int)lenI, (int)lenJ, tabI, tabJ, diag, lane);
         wfa_clear_table(sup, (int)lenI, tabI, lane);
         wfa_clear_table(rd, (int)lenJ, tabJ, lane);
+        LRT_LAP(1);
         uint32_t preI, postI, preJ, postJ, seqlen;
         if (bd >= 0) {
           seqlen = min(lenI - (uint32_t)bd, lenJ);
@@ -381,7 +383,14 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           // edlibAlign(seqI, seqJ, NW, PATH): query = seqI (columns), target = seqJ (rows)
           const bool rd_pure = ((pure_reads >> L.sel[step]) & 1ull) != 0;
           const int pmode = (sup_pure && rd_pure) ? (LM_EQ | LM_EQFAST) : 0;   // (identity among ACGT: same op string)
+#ifdef DH_LR_TIMING
+          const unsigned long long lrt_p0 = wall_clock64();
+#endif
           const int nops = lm_nw_path(sJ, (int)seqlen, sI, (int)seqlen, pmode, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+#ifdef DH_LR_TIMING
+          LRT_ADD(2, wall_clock64() - lrt_p0);
+          LRT_LAP(12);
+#endif
           if (nops < 0) { status = DELLYHIP_E_LIMIT; break; }
           sup_pure = sup_pure && rd_pure;
           // buildSuperstring (:90-133)
@@ -412,6 +421,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           sl = ob + tlen;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
+          LRT_LAP(3);
           uint8_t* sw = sup; sup = sup2; sup2 = sw;
         }
       }
@@ -476,11 +486,19 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LRT_LAP(4);
         const int rd = L.sel[step];
         const uint8_t* qy = blob + L.roff[rd];
         const int qn = L.rlen[rd];
         const int eqmode = LM_EQ | ((lm_in_classes(astr, 1, acols, lane) && lm_in_classes(qy, 1, qn, lane)) ? LM_EQFAST : 0);
+#ifdef DH_LR_TIMING
+        const unsigned long long lrt_p0 = wall_clock64();
+#endif
         const LmRes h = lm_hw(astr, acols, qy, qn, eqmode, true, true, bnd, bnd_stride, dirs, A.strip_words, tmp, ops, ops_cap, lane);
+#ifdef DH_LR_TIMING
+        LRT_ADD(13, wall_clock64() - lrt_p0);
+        LRT_LAP(12);
+#endif
         if (h.nops < 0) { status = DELLYHIP_E_LIMIT; break; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -517,6 +535,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LRT_LAP(10);
         uint8_t* sw = cur; cur = nxt; nxt = sw;
         arows += 1;
         acols = ncols;
@@ -568,10 +587,10 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
     }
   }
 #ifdef DH_LR_TIMING
-  if (lane == 0 && (j & 127) == 0) {
-    const unsigned long long tw4 = wall_clock64();
-    printf("lrwfa junction %d: pairwise %llu us, superstring %llu us, progressive+consensus+trim %llu us\n", j, (tw1 - tw0) / 100, (tw2 - tw1) / 100, (tw4 - tw2) / 100);
-  }
+  LRT_LAP(11);
+  LRT_ADD(14, 1);
+  LRT_ADD(15, wall_clock64() - tw0);
+  (void)tw1; (void)tw2;
 #endif
   if (lane == 0) {
     out->sr_support = rows;
