@@ -634,11 +634,17 @@ __device__ __noinline__ void lm_dirs_myers(const uint8_t* tp_, int tlen, const u
 // windowed run-length traceback over the two planes (see traceback_runs, split_kernel.hpp, for the row-word
 // flavour): lane x keeps column cc - x and the planes' words of the 32-row word its fetch row lies in.
 // ops (edlib codes 0 match, 1 insert, 2 delete, 3 mismatch) to tr[] in push order; rr / cc end at the border.
+// CLS: t / qy are class-index strings staged in LDS (lm_plain_path), not the letters in HBM -- the walk is a chain of dependent
+// loads (plane words of the next window, the letter under every step), and two of them per window plus one per run were
+// HBM / L2 round trips for a byte
+template <bool CLS>
 __device__ __noinline__ int lm_traceback_planes(const uint32_t* planeH, const uint32_t* planeV, int nw, int nl1, const uint8_t* t,
-                                                const uint8_t* qy, int& rr, int& cc, uint8_t* tr, int lane) {
+                                                const uint8_t* qy, int& rr_io, int& cc_io, uint8_t* tr, int lane) {
+  // (rr / cc as LOCALS: through the references they live in the caller's frame -- scratch memory -- and every byte store to tr[],
+  //  which may alias anything, made the compiler re-load them: two scratch round trips per run, ~2 500 cycles, round 6)
   int tl = 0;
-  rr = rfl(rr);
-  cc = rfl(cc);
+  int rr = rfl(rr_io);
+  int cc = rfl(cc_io);
   while (rr > 0 && cc > 0) {
     const int r = rr - lane, c = cc - lane;
     uint32_t wh = 0, wv = 0;
@@ -652,7 +658,7 @@ __device__ __noinline__ int lm_traceback_planes(const uint32_t* planeH, const ui
       rwf = z >> 5;
       wh = ld_scratch(planeH + wi);
       wv = ld_scratch(planeV + wi);
-      const int y = iupac_index((int)qy[c - 1]);
+      const int y = CLS ? (int)qy[c - 1] : iupac_index((int)qy[c - 1]);
       tmask = (1u << y) | iupac_partners(y);   // (the relation is symmetric)
     }
     int l = 0;   // columns consumed since the fetch: lane x stands for diagonal offset x - l
@@ -666,7 +672,7 @@ __device__ __noinline__ int lm_traceback_planes(const uint32_t* planeH, const ui
         const int q = (rx - 1) & 31;
         if ((wh >> q) & 1u) code = (uint32_t)ED_INSERT;
         else if ((wv >> q) & 1u) code = (uint32_t)ED_DELETE;
-        else code = ((tmask >> iupac_index((int)t[rx - 1])) & 1u) ? (uint32_t)ED_MATCH : (uint32_t)ED_MISMATCH;
+        else code = ((tmask >> (CLS ? (int)t[rx - 1] : iupac_index((int)t[rx - 1]))) & 1u) ? (uint32_t)ED_MATCH : (uint32_t)ED_MISMATCH;
       }
       const bool isd = (code == (uint32_t)ED_MATCH || code == (uint32_t)ED_MISMATCH);
       const unsigned long long dm = __ballot(isd) >> l;
@@ -694,6 +700,8 @@ __device__ __noinline__ int lm_traceback_planes(const uint32_t* planeH, const ui
       }
     }
   }
+  rr_io = rr;
+  cc_io = cc;
   return tl;
 }
 
@@ -719,6 +727,22 @@ __device__ __forceinline__ void lm_last_row(const uint8_t* tp, int tstep, int tl
   if (lane == 0) row_out[0] = tlen;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+}
+
+// the end of a traceback-regime path: border runs (target exhausted -> INSERTs, query exhausted -> DELETEs, edlib.cpp:1027-1091),
+// then the ops, walked back to front into tmp[0..tl), appended to `ops` in forward order at `pos`; returns the new position
+__device__ __forceinline__ int lm_plain_finish(int tl, int rr, int cc, uint8_t* tmp, uint8_t* ops, int pos, int lane) {
+  const int tail = (rr > 0) ? rr : cc;
+  const uint8_t op = (rr > 0) ? (uint8_t)ED_DELETE : (uint8_t)ED_INSERT;
+  for (int k = lane; k < tail; k += WAVE) tmp[tl + k] = op;
+  tl += tail;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int k = lane; k < tl; k += WAVE) ops[pos + k] = tmp[tl - 1 - k];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  LRT_LAP(9);
+  return pos + tl;
 }
 
 // plain (traceback-regime) NW path of t[0..tlen) vs q[0..qlen): direction strips + windowed
@@ -747,7 +771,18 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
     else if (bv_nw == 2) lm_dirs_myers<2>(t, tlen, qy, qlen, planeH, planeV, lane);
     else lm_dirs_myers<3>(t, tlen, qy, qlen, planeH, planeV, lane);
     LRT_LAP(8);
-    tl = lm_traceback_planes(planeH, planeV, bv_nw, bv_nl1, t, qy, rr, cc, tmp, lane);
+    if (tlen + qlen <= MYERS_NW * 16 * WAVE * 4) {
+      // the match masks are done with: their LDS holds the two strings as class indices for the walk
+      uint8_t* tcl = reinterpret_cast<uint8_t*>(lm_eq_lds());
+      uint8_t* qcl = tcl + tlen;
+      for (int k = lane; k < tlen; k += WAVE) tcl[k] = (uint8_t)iupac_index((int)t[k]);
+      for (int k = lane; k < qlen; k += WAVE) qcl[k] = (uint8_t)iupac_index((int)qy[k]);
+      __syncthreads();
+      tl = lm_traceback_planes<true>(planeH, planeV, bv_nw, bv_nl1, tcl, qcl, rr, cc, tmp, lane);
+      __syncthreads();
+    } else {
+      tl = lm_traceback_planes<false>(planeH, planeV, bv_nw, bv_nl1, t, qy, rr, cc, tmp, lane);
+    }
   } else {
     LRT_LAP(12);
     for (int q = 0; q < Q; ++q) {
@@ -761,18 +796,7 @@ __device__ __forceinline__ int lm_plain_path(const uint8_t* t, int tlen, const u
     GeoLR G{dirs, strip_words};
     tl = traceback_runs<true>(G, rr, cc, tmp, lane);
   }
-  // border runs: target exhausted -> INSERTs, query exhausted -> DELETEs (edlib.cpp:1027-1091)
-  const int tail = (rr > 0) ? rr : cc;
-  const uint8_t op = (rr > 0) ? (uint8_t)ED_DELETE : (uint8_t)ED_INSERT;
-  for (int k = lane; k < tail; k += WAVE) tmp[tl + k] = op;
-  tl += tail;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int k = lane; k < tl; k += WAVE) ops[pos + k] = tmp[tl - 1 - k];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  LRT_LAP(9);
-  return pos + tl;
+  return lm_plain_finish(tl, rr, cc, tmp, ops, pos, lane);
 }
 
 // words of direction codes the traceback-regime rectangles of lm_nw_path can need for targets <= tcap and queries <= qcap:
@@ -967,6 +991,99 @@ __device__ __noinline__ void lm_last_rows_packed(const uint8_t* target_, int nre
   __syncthreads();
 }
 
+// The traceback-regime rectangles a breadth-first run ends with are independent too: the bit-plane fills (lm_dirs_myers) of
+// consecutive ones run as segments of one wavefront, each into its own planes inside the direction area; the walks follow one
+// after the other.  One word per lane (targets <= 2048 rows each); segment k = rectangle k: B.seg[k] as above (pass = group),
+// B.roff[k] = word offset of its planeH (planeV follows at + lm_bv_words).  The query's classes come from B.qcls.
+__device__ __forceinline__ uint64_t lm_bv_words1(int tl, int ql) {   // words of ONE plane of a tl x ql rectangle, one word per lane (lm_plain_path)
+  const int nl1 = (tl - 1) / 32 + 2;
+  return (uint64_t)(((ql + nl1 - 2 + 15) >> 4) * 16) * nl1;
+}
+__device__ __noinline__ void lm_dirs_packed(const uint8_t* target_, int cur, int r0, int r1, int group, uint32_t* dirs_, int lane) {
+  LmBfsLds& B = lm_bfs_lds();
+  uint32_t* E = lm_eq_lds();
+  const gptr_cu8 target = (gptr_cu8)target_;
+  int myseg = -1, off = 0, nl = 0;
+  for (int k = r0; k < r1; ++k) {
+    const unsigned d = B.seg[k];
+    const int fl = (int)(d & 255u), n = (int)((d >> 8) & 255u);
+    if ((int)(d >> 16) == group && lane >= fl && lane < fl + n) { myseg = k; off = lane - fl; nl = n; }
+  }
+  const bool mine = myseg >= 0;
+  const int r = mine ? myseg : r0;
+  const int t0 = B.rect[cur][r][0], tlen = mine ? B.rect[cur][r][1] : 0, q0 = B.rect[cur][r][2];
+  const int ql = mine ? B.rect[cur][r][3] : 0;
+  const int nl1 = nl + 1;   // owner lanes + the (unused here) dummy slot of the single-rectangle layout
+  const gptr_u32 planeH = (gptr_u32)dirs_ + (mine ? B.roff[r] : 0);
+  const gptr_u32 planeV = planeH + (mine ? lm_bv_words1(tlen, ql) : 0);
+  const bool is_head = off == 0;
+  const int row0 = off * 32;
+#pragma unroll
+  for (int y = 0; y < 16; ++y) E[y * WAVE + lane] = 0;
+  for (int q = 0; q < 32; ++q) {
+    const int rr = row0 + q;
+    if (rr < tlen) {
+      const int x = iupac_index((int)target[t0 + rr]);
+      uint32_t pm = (1u << x) | iupac_partners(x);
+      while (pm) {
+        const int y = __builtin_ctz(pm);
+        pm &= pm - 1;
+        E[y * WAVE + lane] |= 1u << q;
+      }
+    }
+  }
+  int T = mine ? ql + off : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) T = max(T, __shfl_xor(T, o));
+  T = rfl(T);
+  uint32_t Pv = 0xffffffffu, Mv = 0;
+  int hcarry = 1;
+  auto load_cls = [&](int t) -> int {
+    const int c = t - off;
+    const bool in = mine && (unsigned)c < (unsigned)ql;
+    const int a = in ? q0 + c : 0;
+    const int nib = ((int)B.qcls[a >> 1] >> ((a & 1) * 4)) & 15;
+    return (in ? nib : 15) * WAVE;
+  };
+  int clsN = load_cls(0), clsNN = load_cls(1);
+  uint32_t EqN = E[clsN + lane];
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    uint32_t Eq = EqN;
+    clsN = clsNN;
+    clsNN = load_cls(t + 2);
+    EqN = E[clsN + lane];
+    int hin = dpp_from_prev(hcarry, 1);
+    hin = is_head ? 1 : hin;
+    const int c = t - off;
+    const bool valid = mine && (unsigned)c < (unsigned)ql;
+    const uint32_t hinNeg = (hin < 0) ? 1u : 0u;   // edlib.cpp:390-470
+    const uint32_t Xv = Eq | Mv;
+    Eq |= hinNeg;
+    const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    uint32_t Ph = Mv | ~(Xh | Pv);
+    uint32_t Mh = Pv & Xh;
+    const uint32_t PhOut = Ph;                      // horizontal +1 deltas of this column's rows
+    const int hout = (int)(Ph >> 31) - (int)(Mh >> 31);
+    Ph <<= 1;
+    Mh <<= 1;
+    Mh |= hinNeg;
+    Ph |= (hin > 0) ? 1u : 0u;
+    const uint32_t nP = Mh | ~(Xv | Ph);
+    const uint32_t nM = Ph & Xv;
+    if (valid) {   // cell (r, c + 1) of the rectangle: step s = c + off of the single-rectangle layout
+      const size_t wi = (size_t)t * nl1 + off;
+      planeH[wi] = PhOut;
+      planeV[wi] = nP;                              // vertical +1 deltas within this column
+    }
+    Pv = valid ? nP : Pv;
+    Mv = valid ? nM : Mv;
+    hcarry = valid ? hout : hcarry;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // edlibAlign(query, target, NW, PATH, extended-IUPAC equalities).alignment of ONE rectangle, depth first (obtainAlignment,
 // edlib.cpp:1163-1389); ops appended at `pos`, returns the new position or -1 on overflow.
 // (`strip_words` = capacity of `dirs` in words, lm_dirs_words())
@@ -1103,9 +1220,51 @@ __device__ __forceinline__ int lm_nw_path(const uint8_t* target, int tn, const u
   }
   __syncthreads();
   int pos = 0;
-  for (int r = 0; r < nrect && pos >= 0; ++r) {
-    const int rt0 = rfl(B.rect[cur][r][0]), rtl = rfl(B.rect[cur][r][1]), rq0 = rfl(B.rect[cur][r][2]), rql = rfl(B.rect[cur][r][3]);
-    pos = lm_nw_dfs(target, query, rt0, rtl, rq0, rql, mode, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, pos, lane);
+  int r = 0, group = 0;
+  while (r < nrect && pos >= 0) {
+    // consecutive traceback-regime rectangles whose plane fills fit one wavefront and the direction area together
+    int e = r, lanes = 0, need = 0;
+    uint64_t words = 0;
+    if (packed && nrect > 1) {
+      for (; e < nrect; ++e) {
+        const int tl = rfl(B.rect[cur][e][1]), ql = rfl(B.rect[cur][e][3]);
+        if (ql <= 0 || tl <= 0 || tl > WAVE * 32 || !lm_traceback_regime(tl, ql)) break;
+        const int n = (tl + 31) / 32;
+        const uint64_t w = 2 * lm_bv_words1(tl, ql);
+        if (lanes + n > WAVE || words + w > strip_words || words + w > 0x7fffffffull) break;
+        if (lane == 0) { B.seg[e] = (unsigned)lanes | ((unsigned)n << 8) | ((unsigned)group << 16); B.roff[e] = (int)words; }
+        lanes += n;
+        words += w;
+        need += tl + ql;
+      }
+    }
+    if (e - r >= 2) {
+      if (pos + need > ops_cap) return -1;
+      __syncthreads();
+      LRT_LAP(12);
+      lm_dirs_packed(target, cur, r, e, group, dirs, lane);
+      LRT_LAP(8);
+      for (int k = r; k < e; ++k) {
+        const int rt0 = rfl(B.rect[cur][k][0]), rtl = rfl(B.rect[cur][k][1]), rq0 = rfl(B.rect[cur][k][2]), rql = rfl(B.rect[cur][k][3]);
+        const uint32_t* planeH = dirs + rfl(B.roff[k]);
+        const uint32_t* planeV = planeH + lm_bv_words1(rtl, rql);
+        uint8_t* tcl = reinterpret_cast<uint8_t*>(lm_eq_lds());   // (the match masks are done with)
+        uint8_t* qcl = tcl + rtl;
+        for (int i = lane; i < rtl; i += WAVE) tcl[i] = (uint8_t)iupac_index((int)target[rt0 + i]);
+        for (int i = lane; i < rql; i += WAVE) qcl[i] = (uint8_t)iupac_index((int)query[rq0 + i]);
+        __syncthreads();
+        int rr = rtl, cc = rql;
+        const int tl = lm_traceback_planes<true>(planeH, planeV, 1, (rtl - 1) / 32 + 2, tcl, qcl, rr, cc, tmp, lane);
+        __syncthreads();
+        pos = lm_plain_finish(tl, rr, cc, tmp, ops, pos, lane);
+      }
+      group += 1;
+      r = e;
+    } else {
+      const int rt0 = rfl(B.rect[cur][r][0]), rtl = rfl(B.rect[cur][r][1]), rq0 = rfl(B.rect[cur][r][2]), rql = rfl(B.rect[cur][r][3]);
+      pos = lm_nw_dfs(target, query, rt0, rtl, rq0, rql, mode, bnd, bnd_stride, dirs, strip_words, tmp, ops, ops_cap, pos, lane);
+      r += 1;
+    }
   }
   return pos;
 }
