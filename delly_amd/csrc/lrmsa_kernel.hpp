@@ -252,6 +252,36 @@ __device__ __forceinline__ LmKeys lm_pass(const uint8_t* tp, int tstep, int tlen
   return lm_pass_t<DIRS, LOC, 0>(tp, tstep, tlen, qp, qstep, qlen, q, pad, mode, r0, bin, bout, dirs, lane, lastcol);
 }
 
+// Match masks of one lane-word for the compare-free passes: E[(w * 16 + y) * WAVE + lane] bit q = "row lo + q of the target
+// equals query class y" (its own letter or one of the partners).  Eight rows at a time: the eight letters are loaded before any
+// of them is used (the row-at-a-time loop of rounds 2-5 waited one HBM / L2 round trip per row: 64-96 in front of EVERY pass),
+// and the fifteen masks are built without a branch on the letter.
+__device__ __forceinline__ void lm_eq_word(uint32_t* E, int w, gptr_cu8 tp, int tstep, int lo, int tlen, int lane) {
+  uint32_t e[15];
+#pragma unroll
+  for (int y = 0; y < 15; ++y) e[y] = 0;
+#pragma unroll 1
+  for (int q0 = 0; q0 < 32; q0 += 8) {
+    int ch[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = lo + q0 + k;
+      ch[k] = (r < tlen) ? (int)tp[r * tstep] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = lo + q0 + k;
+      const int x = iupac_index(ch[k]);
+      const uint32_t pm = (r < tlen && x >= 0) ? ((1u << x) | iupac_partners(x)) : 0u;
+#pragma unroll
+      for (int y = 0; y < 15; ++y) e[y] |= ((pm >> y) & 1u) << (q0 + k);
+    }
+  }
+#pragma unroll
+  for (int y = 0; y < 15; ++y) E[(w * 16 + y) * WAVE + lane] = e[y];
+  E[(w * 16 + 15) * WAVE + lane] = 0;
+}
+
 // ---- bit-vector flavour of the last-row pass (Hirschberg halves of edlib's NW PATH, edlib.cpp:1163-1389) -------------
 // In the compare-free regime (every letter of both strings is one of the 15 classes) "equal" is a relation
 // between classes, so the pass is Myers' recurrence with one equality mask per QUERY class: mask[y] = rows whose
@@ -276,23 +306,10 @@ __device__ __noinline__ void lm_last_row_myers(const uint8_t* tp_, int tstep, in
   uint32_t mk[NWORDS];   // rows of this lane at or beyond tlen (their vertical deltas are taken off the bottom score)
 #pragma unroll
   for (int w = 0; w < NWORDS; ++w) {
-#pragma unroll
-    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
     const int lo = row0 + w * 32;
     const int nb = min(32, max(0, lo + 32 - tlen));
     mk[w] = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? (~0u << (32 - nb)) : 0u);
-    for (int q = 0; q < 32; ++q) {
-      const int r = lo + q;
-      if (r < tlen) {
-        const int x = iupac_index((int)tp[r * tstep]);
-        uint32_t pm = (1u << x) | iupac_partners(x);
-        while (pm) {
-          const int y = __builtin_ctz(pm);
-          pm &= pm - 1;
-          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
-        }
-      }
-    }
+    lm_eq_word(E, w, tp, tstep, lo, tlen, lane);
   }
   uint32_t Pv[NWORDS], Mv[NWORDS];
 #pragma unroll
@@ -387,21 +404,8 @@ __device__ __noinline__ LmKeys lm_locate_myers(const uint8_t* tp_, int tstep, in
   const int row0 = lane * 32 * NWORDS;
 #pragma unroll
   for (int w = 0; w < NWORDS; ++w) {
-#pragma unroll
-    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
     const int lo = row0 + w * 32;
-    for (int q = 0; q < 32; ++q) {
-      const int r = lo + q;
-      if (r < tlen) {
-        const int x = iupac_index((int)tp[r * tstep]);
-        uint32_t pm = (1u << x) | iupac_partners(x);
-        while (pm) {
-          const int y = __builtin_ctz(pm);
-          pm &= pm - 1;
-          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
-        }
-      }
-    }
+    lm_eq_word(E, w, tp, tstep, lo, tlen, lane);
   }
   uint32_t Pv[NWORDS], Mv[NWORDS];
 #pragma unroll
@@ -543,21 +547,8 @@ __device__ __noinline__ void lm_dirs_myers(const uint8_t* tp_, int tlen, const u
   const int row0 = lane * 32 * NWORDS;
 #pragma unroll
   for (int w = 0; w < NWORDS; ++w) {
-#pragma unroll
-    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
     const int lo = row0 + w * 32;
-    for (int q = 0; q < 32; ++q) {
-      const int r = lo + q;
-      if (r < tlen) {
-        const int x = iupac_index((int)tp[r]);
-        uint32_t pm = (1u << x) | iupac_partners(x);
-        while (pm) {
-          const int y = __builtin_ctz(pm);
-          pm &= pm - 1;
-          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
-        }
-      }
-    }
+    lm_eq_word(E, w, tp, 1, lo, tlen, lane);
   }
   uint32_t Pv[NWORDS], Mv[NWORDS];
 #pragma unroll
@@ -898,23 +889,10 @@ __device__ __noinline__ void lm_last_rows_packed(const uint8_t* target_, int nre
   uint32_t mk[NWORDS];   // rows of this lane at or beyond tlen (their vertical deltas are taken off the bottom score)
 #pragma unroll
   for (int w = 0; w < NWORDS; ++w) {
-#pragma unroll
-    for (int y = 0; y < 16; ++y) E[(w * 16 + y) * WAVE + lane] = 0;
     const int lo = row0 + w * 32;
     const int nb = min(32, max(0, lo + 32 - tlen));
     mk[w] = (nb >= 32) ? 0xffffffffu : ((nb > 0) ? (~0u << (32 - nb)) : 0u);
-    for (int q = 0; q < 32; ++q) {
-      const int rr = lo + q;
-      if (rr < tlen) {
-        const int x = iupac_index((int)target[tbase + rr * tstep]);
-        uint32_t pm = (1u << x) | iupac_partners(x);
-        while (pm) {
-          const int y = __builtin_ctz(pm);
-          pm &= pm - 1;
-          E[(w * 16 + y) * WAVE + lane] |= 1u << q;
-        }
-      }
-    }
+    lm_eq_word(E, w, target + tbase, tstep, lo, tlen, lane);
   }
   int T = mine ? ql + off : 0;   // steps until this lane has seen its last column
 #pragma unroll
@@ -1018,20 +996,7 @@ __device__ __noinline__ void lm_dirs_packed(const uint8_t* target_, int cur, int
   const gptr_u32 planeV = planeH + (mine ? lm_bv_words1(tlen, ql) : 0);
   const bool is_head = off == 0;
   const int row0 = off * 32;
-#pragma unroll
-  for (int y = 0; y < 16; ++y) E[y * WAVE + lane] = 0;
-  for (int q = 0; q < 32; ++q) {
-    const int rr = row0 + q;
-    if (rr < tlen) {
-      const int x = iupac_index((int)target[t0 + rr]);
-      uint32_t pm = (1u << x) | iupac_partners(x);
-      while (pm) {
-        const int y = __builtin_ctz(pm);
-        pm &= pm - 1;
-        E[y * WAVE + lane] |= 1u << q;
-      }
-    }
-  }
+  lm_eq_word(E, 0, target + t0, 1, row0, tlen, lane);
   int T = mine ? ql + off : 0;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) T = max(T, __shfl_xor(T, o));
