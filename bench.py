@@ -520,16 +520,16 @@ FLAT_ROWS = (("u_c2_40k_junctions", "u_c2_40k_alignments_per_s"), ("u_full_n20",
 # The driver's record of a run keeps the first DRIVER_CONFIG_KEYS scalar entries of `config`: these come first, in this order
 # (tests/test_bench_record.py parses a line the way the driver does and asserts they survive).
 DRIVER_CONFIG_KEYS = 24
-CONFIG_FIRST = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
-                "u_full_n20_10k_junctions_per_s", "u_full_n20_2k_junctions_per_s", "sr_stage_mixed_all_svt_junctions_per_s",
+CONFIG_FIRST = ("workload", "value_is", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
+                "host_inclusive_full_payload_alignments_per_s", "u_full_n20_10k_junctions_per_s", "u_full_n20_2k_junctions_per_s", "sr_stage_mixed_all_svt_junctions_per_s",
                 "ins_svt4_junctions_per_s", "lr_c4_align_consensus_junctions_per_s", "lr_c4_msaedlib_n15_junctions_per_s",
                 "lr_ins_msawfa_n15_junctions_per_s", "lr_stress_10kb_x_20kb_junctions_per_s", "lr_c4_align_consensus_8k_junctions_per_s",
                 "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
                 "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
-                "u_c2_40k_alignments_per_s", "u_full_n20_10k_msa_deferred_junctions", "u_full_n5_2k_junctions_per_s",
-                "value_min", "value_max", "u_full_n20_10k_host_inclusive_per_s", "refined_ok_min")
+                "u_c2_40k_alignments_per_s", "u_full_n5_2k_junctions_per_s",
+                "value_min", "value_max", "refined_ok_min")
 # N > 1 (the driver's SCALE runs): what the return paths cost comes first
-CONFIG_FIRST_MULTI = ("workload", "value_return_path", "gather_alignments_per_s", "gather_step_ms", "gather_ms_per_step", "gather_transport", "rccl_ranks",
+CONFIG_FIRST_MULTI = ("workload", "value_is", "value_return_path", "gather_alignments_per_s", "gather_step_ms", "gather_ms_per_step", "gather_transport", "rccl_ranks",
                       "shm_return_alignments_per_s", "shm_return_ms_per_step", "shm_return_gather_ms_per_step", "host_inclusive_alignments_per_s", "ms_per_step_min_rank", "ms_per_step_max_rank",
                       "ranks_launched", "ranks_that_ran_kernels", "oversubscribed_one_device", "gathered_records_on_rank0",
                       "gathered_blob_bytes_on_rank0", "shm_return_records_seen_by_rank0", "junctions_per_gpu", "refined_ok_min",
@@ -673,7 +673,10 @@ def main():
         # the download of step k - 1 (two small compaction kernels in front of it) runs while the persistent sparse kernel of
         # step k holds the chip: 12 of its 16 wavefronts per CU leave them room (as in the slots of dellyhip_stream)
         os.environ.setdefault("DELLYHIP_SPS_WAVES", "12")
-    ctx = refine.Context(device=local)
+    # N > 1: the results travel (to rank 0's host memory, inside every step) with the compact payload -- records + consensus bytes; the
+    # "REF,ALT" strings of the deletions are re-cut by the merging process from the record and its own copy of the chromosome
+    # (dellyhip_recut_alleles, tests/test_gpu_compact.py): ~0.35 instead of ~1 KB per junction over PCIe / xGMI
+    ctx = refine.Context(params=abi.params_sr(compact_alleles=multi), device=local)
     ctx.set_chromosomes(chroms)
     # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
     # streams the library verified to run side by side, so the tail of one step's launch runs under the head of the next
@@ -906,7 +909,30 @@ def main():
             for x in rbs:
                 x.free()
             rbs = []
-            hi = host_inclusive_rate(ctx, batches, 0)
+            # The caller-facing configuration (include/delly_dropin/split.h: refineBatch): compact payload -- the "REF,ALT" strings of
+            # small deletions (~700 of the ~1000 result bytes per junction) are plain substrings of the chromosome the caller holds and
+            # are re-cut there from the record (dellyhip_recut_alleles; tests/test_gpu_compact.py holds them to oracle/_ref), so they
+            # do not cross PCIe.  The full payload (round 5's figure) is timed beside it, and so is the host re-cut of one batch.
+            ctx_c = refine.Context(params=abi.params_sr(compact_alleles=True), device=local, share_with=ctx)
+            hi = host_inclusive_rate(ctx_c, batches, 0)
+            hi["payload"] = "compact: records + consensus bytes; REF,ALT re-cut on the host from the record (DELLYHIP_COMPACT_ALLELES)"
+            try:
+                if world == 1:
+                    full = host_inclusive_rate(ctx, batches, 0, seconds=0.5)
+                    hi["full_payload"] = {k: full[k] for k in ("value", "ms_per_batch", "bytes_down_per_batch", "batches")}
+                    gr, gb = ctx_c.refine(batches[0], want_alignment=False)
+                    best = None
+                    buf = None
+                    for _ in range(5):
+                        buf, _, sec = refine.recut_alleles_raw(ctx_c.params, batches[0].junctions, gr, gb, chroms, out=buf)
+                        best = sec if best is None else min(best, sec)
+                    hi["host_recut_ms_per_batch_one_thread"] = best * 1e3
+                    hi["host_recut_bytes_per_batch"] = int(buf.nbytes)
+                    hi["host_recut_note"] = ("dellyhip_recut_alleles_batch on ONE host thread over one batch's records: the VCF writer's job, off the refinement "
+                                             "stage's clock (src/split.h:606-624 fills sv.alleles for output only); not inside `value`")
+            except Exception as e:
+                hi["full_payload"] = {"error": repr(e)}
+            ctx_c.close()
             if world > 1:
                 hv = torch.tensor([hi["value"], hi["wall_s"]], dtype=torch.float64, device=dev)
                 allh = [torch.zeros_like(hv) for _ in range(world)]
@@ -933,8 +959,10 @@ def main():
                "launches_in_flight": 1 if (multi and first != "shm") else 2,
                "junctions_per_gpu": n, "resident_batches": len(batches), "refined_ok_min": min(n_ok), "parallelism": "junction-sharded x%d" % world,
                "ranks_launched": world, "ranks_that_ran_kernels": ranks_that_ran,
-               "value_is": "inputs resident in HBM, results left in HBM (bench contract)" if not multi else
-                           "inputs resident in HBM; the previous step's results reach rank 0's host memory inside every step (return path: config.return_path)",
+               "value_is": ("inputs resident in HBM, results left in HBM (the bench contract); host buffers in -> host buffers out is host_inclusive_alignments_per_s "
+                            "(compact payload) / host_inclusive_full_payload_alignments_per_s") if not multi else
+                           ("inputs resident in HBM; the previous step's results (compact payload) reach rank 0's host memory inside every step through the return path "
+                            "config.value_return_path (shm = per-rank PCIe writes into shared memory, no collective; the RCCL all-gatherv to rank 0 is gather_alignments_per_s)"),
                "kernels_ms_per_step_rank0": ms_split}
         if not multi:
             dts = region[None]["dts"]
@@ -975,6 +1003,11 @@ def main():
             cfg["host_inclusive_wall_s"] = hi["wall_s"]
             cfg["host_inclusive_batches"] = hi["batches"]
             cfg["host_inclusive_ms_per_batch"] = hi["ms_per_batch"]
+            cfg["host_inclusive_payload"] = "compact (REF,ALT re-cut on the host from the record); full payload: host_inclusive_full_payload_alignments_per_s"
+            if isinstance(hi.get("full_payload"), dict) and "value" in hi["full_payload"]:
+                cfg["host_inclusive_full_payload_alignments_per_s"] = hi["full_payload"]["value"]
+            if "host_recut_ms_per_batch_one_thread" in hi:
+                cfg["host_recut_ms_per_batch_one_thread"] = hi["host_recut_ms_per_batch_one_thread"]
         out = {
             "metric": "candidate split-read alignments/sec (DEL, 150bp reads, 1kb ref window)",
             "value": value,

@@ -32,9 +32,13 @@ class Params(C.Structure):
     ]
 
 
-def params_sr():
+REALIGN = 1           # dellyhip_params.reserved bit 0 (DELLYHIP_REALIGN)
+COMPACT_ALLELES = 4   # bit 2 (DELLYHIP_COMPACT_ALLELES): no "REF,ALT" bytes where they are plain substrings; allele_len = -(length)
+
+
+def params_sr(compact_alleles=False):
     """`delly sr` defaults: src/delly.h:221,240,393-398."""
-    return Params(5, -4, -10, -1, 2, 13, 1000, 100, 0.95, 0)
+    return Params(5, -4, -10, -1, 2, 13, 1000, 100, 0.95, COMPACT_ALLELES if compact_alleles else 0)
 
 
 def params_lr(realign=False):

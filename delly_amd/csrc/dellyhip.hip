@@ -2147,6 +2147,48 @@ int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   return 0;
 }
 
+// src/split.h:606-624 on the host, for records produced with DELLYHIP_COMPACT_ALLELES (see dellyhip.h)
+int64_t dellyhip_recut_alleles(const dellyhip_params* P, const dellyhip_junction* J, const dellyhip_result* R, const char* cons,
+                               const char* seq, int64_t chr_len, char* out, uint64_t cap) {
+  if (!P || !J || !R || !out) return fail(DELLYHIP_E_ARG, "null argument");
+  if (R->allele_len >= 0) return 0;
+  if (!cons || !seq) return fail(DELLYHIP_E_ARG, "null argument");
+  const int64_t total = -(int64_t)R->allele_len;
+  const int64_t nr = (int64_t)R->r_end - R->r_start, na = (int64_t)R->c_end - R->c_start;
+  if (!R->ok || (J->svt != 2 && J->svt != 4) || nr < 0 || na < 0 || nr + na + 1 != total || R->c_start < 1 || R->r_start < 1 || R->c_end - 1 > R->cons_len)
+    return fail(DELLYHIP_E_ARG, "dellyhip_recut_alleles: the record does not describe compact alleles");
+  if ((uint64_t)total > cap) return fail(DELLYHIP_E_ARG, "dellyhip_recut_alleles: out too small");
+  // window start = bp.svStartBeg (src/tags.h:151-172; alignConsensus src/split.h:650-655)
+  const int32_t boundary = (J->svt == 4) ? std::max((int32_t)(((size_t)R->cons_len - (size_t)(int64_t)J->ins_len) / 3), P->minimum_flank_size) : R->cons_len;
+  const int64_t beg = std::max(0, J->sv_start - boundary);
+  const int64_t r0 = beg + R->r_start - 1;
+  if (r0 < 0 || r0 + nr > chr_len) return fail(DELLYHIP_E_ARG, "dellyhip_recut_alleles: the reference allele leaves the chromosome");
+  for (int64_t i = 0; i < nr; ++i) {
+    const unsigned char ch = (unsigned char)seq[r0 + i];
+    out[i] = (char)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);   // boost::to_upper_copy of _getSVRef (src/split.h:116-119)
+  }
+  out[nr] = ',';
+  memcpy(out + nr + 1, cons + (R->c_start - 1), (size_t)na);
+  return total;
+}
+
+// the same over a batch: out_off[i] .. out_off[i + 1] = "REF,ALT" of record i (empty where it has no compact alleles)
+int64_t dellyhip_recut_alleles_batch(const dellyhip_params* P, int32_t n, const dellyhip_junction* J, const dellyhip_result* R, const char* blob,
+                                     const char* const* chr_seq, const int64_t* chr_len, int32_t n_chr, char* out, uint64_t cap, uint64_t* out_off) {
+  if (!P || n < 0 || (n && (!J || !R || !blob || !chr_seq || !chr_len || !out_off))) return fail(DELLYHIP_E_ARG, "null argument");
+  uint64_t at = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    out_off[i] = at;
+    if (R[i].allele_len >= 0) continue;
+    if (J[i].chr < 0 || J[i].chr >= n_chr) return fail(DELLYHIP_E_ARG, "dellyhip_recut_alleles_batch: chromosome index outside the table");
+    const int64_t got = dellyhip_recut_alleles(P, &J[i], &R[i], blob + R[i].cons_off, chr_seq[J[i].chr], chr_len[J[i].chr], out + at, cap - at);
+    if (got < 0) return got;
+    at += (uint64_t)got;
+  }
+  if (n) out_off[n] = at;
+  return (int64_t)at;
+}
+
 int dellyhip_batch_device_results(dellyhip_ctx* c, dellyhip_batch* b, void** dptr, uint64_t* bytes) {
   if (!c || !b || !dptr || !bytes) return fail(DELLYHIP_E_ARG, "null argument");
   *dptr = b->res.p;

@@ -646,7 +646,12 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
           int nr = rB - rA, na = vB - vA;
           uint8_t* al = ob + A.out_cons_cap;
-          if (nr + na + 1 <= A.out_allele_cap && clean_letters) {
+          if ((P.reserved & 4) && clean_letters && nr + na + 1 <= A.out_allele_cap) {
+            // compact payload (dellyhip_params.reserved bit 2): the two alleles are plain substrings -- REF = window[rStart-1 .. rEnd-1),
+            // ALT = consensus[cStart-1 .. cEnd-1) -- which the caller re-cuts from its own copy of the chromosome and the consensus
+            // (dellyhip_recut_alleles); the record carries the NEGATED length, no bytes are written or returned
+            allele_len = -(nr + na + 1);
+          } else if (nr + na + 1 <= A.out_allele_cap && clean_letters) {
             // REF = S.ref[rA .. rB), ALT = S.cons[vA .. vB)
             const int fr = nr & ~7, fa = na & ~7;
             for (int i = lane * 8; i < fr; i += WAVE * 8) st8u(al + i, sp_lds8a(S.ref + rA + i));
@@ -683,7 +688,7 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
         R->matches = ma; R->mismatches = mm;
         if (final_ok) {
           if (allele_len) {
-            R->allele_off = X.ob_off + A.out_cons_cap;
+            R->allele_off = (allele_len > 0) ? X.ob_off + A.out_cons_cap : 0;
             R->allele_len = allele_len;
           }
           if (status) R->status = status;

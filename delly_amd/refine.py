@@ -22,6 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdellyhip.so")
 
 EXPORTS = [
+    "dellyhip_recut_alleles", "dellyhip_recut_alleles_batch",
     "dellyhip_create", "dellyhip_destroy", "dellyhip_last_error", "dellyhip_default_params_sr",
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
@@ -46,6 +47,39 @@ class DellyHipError(RuntimeError):
 
 
 _lib = None
+
+
+def recut_alleles(params, junctions, results, blob, chroms):
+    """dellyhip_recut_alleles over a batch: the "REF,ALT" bytes of every record of a compact-payload run (allele_len < 0), cut on the
+    host from the chromosomes and the records' consensus bytes exactly as src/split.h:606-624 -> list of bytes (b"" where the record
+    has no compact alleles).  junctions: the batch AS SUBMITTED."""
+    buf, off, _ = recut_alleles_raw(params, junctions, results, blob, chroms)
+    raw = buf.tobytes()
+    return [raw[int(off[i]):int(off[i + 1])] for i in range(results.shape[0])]
+
+
+def recut_alleles_raw(params, junctions, results, blob, chroms, out=None):
+    """dellyhip_recut_alleles_batch -> (bytes as a uint8 array, offsets (n + 1), seconds inside the C function)"""
+    import time
+    lib = load_library()
+    lib.dellyhip_recut_alleles_batch.restype = C.c_int64
+    n = int(results.shape[0])
+    junctions = np.ascontiguousarray(junctions)
+    results = np.ascontiguousarray(results)
+    need = int(np.maximum(-results["allele_len"].astype(np.int64), 0).sum())
+    if out is None or out.nbytes < need:
+        out = np.empty(max(need, 1), dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    ptrs = (C.c_void_p * len(chroms))(*[c.ctypes.data for c in chroms])
+    lens = np.array([c.size for c in chroms], dtype=np.int64)
+    t0 = time.perf_counter()
+    got = lib.dellyhip_recut_alleles_batch(C.byref(params), n, C.c_void_p(junctions.ctypes.data), C.c_void_p(results.ctypes.data),
+                                           C.c_void_p(blob.ctypes.data), ptrs, C.c_void_p(lens.ctypes.data), len(chroms),
+                                           C.c_void_p(out.ctypes.data), C.c_uint64(out.nbytes), C.c_void_p(off.ctypes.data))
+    dt = time.perf_counter() - t0
+    if got != need:
+        raise DellyHipError(int(got) if got < 0 else abi.E_ARG, "dellyhip_recut_alleles_batch: " + (lib.dellyhip_last_error() or b"").decode())
+    return out[:need], off, dt
 
 
 def load_library():

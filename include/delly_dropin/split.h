@@ -53,6 +53,20 @@ inline void store_result(StructuralVariantRecord& sv, dellyhip_result const& r, 
   if (r.allele_len > 0) sv.alleles.assign(blob + r.allele_off, (std::size_t)r.allele_len);
 }
 
+/* the same for a record of the compact payload (DELLYHIP_COMPACT_ALLELES: allele_len < 0, no allele bytes came back): "REF,ALT"
+ * is cut from the caller's chromosome and the record's consensus exactly as src/split.h:606-624 does from the alignment --
+ * REF = toupper(seq[svStartBeg + rStart - 1 .. + rEnd - 1)), ALT = consensus[cStart - 1 .. cEnd - 1).  `j` is the junction as it
+ * was submitted (the record's coordinates before refinement place the window, src/tags.h:151-172). */
+inline void store_result(StructuralVariantRecord& sv, dellyhip_result const& r, const char* blob, dellyhip_params const& p,
+                         dellyhip_junction const& j, char const* seq, int64_t chr_len) {
+  store_result(sv, r, blob);
+  if (r.allele_len < 0) {
+    sv.alleles.resize((std::size_t)(-(int64_t)r.allele_len));
+    const int64_t got = dellyhip_recut_alleles(&p, &j, &r, blob + r.cons_off, seq, chr_len, &sv.alleles[0], sv.alleles.size());
+    if (got != -(int64_t)r.allele_len) throw dellyhip_dropin::Error((int)std::min<int64_t>(got, DELLYHIP_E_ARG), "refineBatch: compact alleles could not be re-cut");
+  }
+}
+
 inline dellyhip_junction junction_of(StructuralVariantRecord const& sv, int32_t tag, uint64_t seq_first, int32_t n_seq) {
   dellyhip_junction j;
   std::memset(&j, 0, sizeof j);
@@ -132,7 +146,11 @@ inline int refineBatch(TConfig const& c, bam_hdr_t const* hdr, char const* seq, 
   namespace dd = dellyhip_dropin;
   if (refined) refined->assign(svidsToProcess.size(), 0);
   if (svidsToProcess.empty()) return 0;
-  dd::Session& S = dd::session(dd::make_params(c, false));
+  // compact payload: the exact alleles of small deletions are ~70 % of the result bytes and plain substrings of `seq`, which this
+  // caller holds -- they are re-cut here instead of crossing PCIe (store_result below)
+  dellyhip_params params = dd::make_params(c, false);
+  params.reserved |= DELLYHIP_COMPACT_ALLELES;
+  dd::Session& S = dd::session(params);
   std::vector<dellyhip_junction> J;
   J.reserve(svidsToProcess.size());
   std::string blob;
@@ -167,7 +185,7 @@ inline int refineBatch(TConfig const& c, bam_hdr_t const* hdr, char const* seq, 
       sv.srAlignQuality = 0;
       continue;
     }
-    dellyhip_detail::store_result(sv, r, out.data());
+    dellyhip_detail::store_result(sv, r, out.data(), S.params, J[k], seq, (int64_t)hdr->target_len[sv.chr]);
     sv.srSupport = (int32_t)seqStore[svidsToProcess[k]].size();
     if (refined) (*refined)[k] = 1;
     ++n_ok;

@@ -53,7 +53,12 @@ typedef struct dellyhip_params {
   int32_t min_cons_window;    /* c.minConsWindow    100 sr / 1000 lr */
   float flank_quality;        /* c.flankQuality    0.95 sr / 0.9 lr */
   int32_t reserved;          /* bit 0: the `realign` argument of alignConsensus (src/split.h:644-646,
-                              * orientation test :564-572; long-read call sites pass true) */
+                              * orientation test :564-572; long-read call sites pass true).
+                              * bit 2 (DELLYHIP_COMPACT_ALLELES): compact result payload -- where the exact "REF,ALT" alleles of
+                              * src/split.h:606-624 are plain substrings of the reference window and the consensus (every junction
+                              * the sparse longNeedle kernels finish: letters A, C, G, T, N only), their bytes are NOT produced;
+                              * the record carries allele_len = -(length) and dellyhip_recut_alleles() rebuilds them on the host
+                              * from c_start / c_end / r_start / r_end.  ~70 % of a deletion's result bytes (bit 1 is internal) */
 } dellyhip_params;
 
 /* One SV candidate ("junction").  Mirrors the fields of
@@ -108,6 +113,9 @@ typedef struct dellyhip_result {
   int32_t reserved;
 } dellyhip_result;
 
+#define DELLYHIP_REALIGN 1
+#define DELLYHIP_COMPACT_ALLELES 4
+
 typedef struct dellyhip_ctx dellyhip_ctx;
 
 /* ---- context ----------------------------------------------------------- */
@@ -120,6 +128,21 @@ const char* dellyhip_last_error(void);
 /* out[0..3] = DELLYHIP_VERSION, sizeof(dellyhip_params), sizeof(dellyhip_junction),
  * sizeof(dellyhip_result): lets a binding verify its struct layout without a GPU. */
 void dellyhip_abi_info(int32_t out[4]);
+/* The alleles of a record produced with DELLYHIP_COMPACT_ALLELES (allele_len < 0), exactly as src/split.h:606-624 builds them:
+ * "REF,ALT" with REF = toupper(chr_seq[window start + r_start - 1 .. + r_end - 1)) and ALT = consensus[c_start - 1 .. c_end - 1),
+ * the window start being svStartBeg of _initBreakpoint (src/tags.h:151-172) for the junction AS SUBMITTED (`junction`: sv_start,
+ * svt, ins_len before refinement).  consensus / cons_len: the record's consensus bytes (out_blob + cons_off, result->cons_len).
+ * chr_seq: the caller's copy of chromosome junction->chr (the `seq` of src/shortpe.h:88).  Pure host code, no device, re-entrant.
+ * Returns the number of bytes written to out (= -result->allele_len), 0 when the record has no compact alleles, or
+ * DELLYHIP_E_ARG (cap too small, inconsistent record). */
+int64_t dellyhip_recut_alleles(const dellyhip_params* params, const dellyhip_junction* junction, const dellyhip_result* result,
+                               const char* consensus, const char* chr_seq, int64_t chr_len, char* out, uint64_t cap);
+/* The same over a batch of n records (junctions[i] as submitted, results[i] / blob as returned): the alleles go to out back to
+ * back, out_off[i] .. out_off[i + 1] (n + 1 entries) being record i's (empty where it has none to re-cut); chr_seq / chr_len: the
+ * caller's chromosome table.  Returns the bytes written or a negative error. */
+int64_t dellyhip_recut_alleles_batch(const dellyhip_params* params, int32_t n, const dellyhip_junction* junctions, const dellyhip_result* results,
+                                     const char* blob, const char* const* chr_seq, const int64_t* chr_len, int32_t n_chr, char* out,
+                                     uint64_t cap, uint64_t* out_off);
 /* Default parameters of `delly sr` (src/delly.h:393-398) and `delly lr`
  * (src/tegua.h:237-241). */
 void dellyhip_default_params_sr(dellyhip_params* p);

@@ -9,13 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-MUST_SURVIVE = ("workload", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
+MUST_SURVIVE = ("workload", "value_is", "host_inclusive_full_payload_alignments_per_s", "one_launch_at_a_time_alignments_per_s", "one_launch_at_a_time_kernel_ms", "host_inclusive_alignments_per_s",
                 "u_full_n20_10k_junctions_per_s", "u_full_n20_2k_junctions_per_s", "ins_svt4_junctions_per_s",
                 "lr_c4_align_consensus_junctions_per_s", "lr_c4_msaedlib_n15_junctions_per_s", "lr_ins_msawfa_n15_junctions_per_s",
                 "sr_stage_mixed_all_svt_junctions_per_s", "lr_stress_10kb_x_20kb_junctions_per_s",
                 "substitutions_2pct_alignments_per_s", "substitutions_5pct_alignments_per_s",
                 "lr_c4_align_consensus_8k_junctions_per_s", "lr_c4_msaedlib_n15_3k_junctions_per_s", "lr_ins_msawfa_n15_2k_junctions_per_s",
-                "u_full_n20_10k_msa_deferred_junctions", "u_full_n20_10k_host_inclusive_per_s")
+                "u_c2_40k_alignments_per_s")
 
 
 def _line_like_bench():
@@ -25,7 +25,8 @@ def _line_like_bench():
            "value_is": "...", "kernels_ms_per_step_rank0": 0.3, "timed_regions": 25, "value_is_region": "...", "value_min": 1.0, "value_max": 2.0,
            "value_median": 1.5, "timed_seconds_total": 0.1, "one_launch_at_a_time_alignments_per_s": 3.0e7, "one_launch_at_a_time_ms_per_step": 0.3,
            "one_launch_at_a_time_kernel_ms": 0.26, "host_inclusive_alignments_per_s": 4.0e7, "host_inclusive_wall_s": 1.0,
-           "host_inclusive_batches": 4000, "host_inclusive_ms_per_batch": 0.25}
+           "host_inclusive_batches": 4000, "host_inclusive_ms_per_batch": 0.25, "host_inclusive_payload": "...",
+           "host_inclusive_full_payload_alignments_per_s": 3.7e7, "host_recut_ms_per_batch_one_thread": 1.0}
     for _, key in bench.FLAT_ROWS:
         cfg[key] = 1.0
     cfg["u_full_n20_10k_msa_deferred_junctions"] = 0
@@ -43,7 +44,7 @@ def test_the_rows_the_verdicts_track_survive_the_drivers_cut():
     assert len(kept) == bench.DRIVER_CONFIG_KEYS
     missing = [k for k in MUST_SURVIVE if k[:40] not in kept]
     assert not missing, missing
-    assert sum(isinstance(v, str) for v in kept.values()) == 1  # the workload string; every other slot is a number
+    assert sum(isinstance(v, str) for v in kept.values()) == 2  # the workload and which-figure-is-which; every other slot is a number
 
 
 def test_first_keys_fit_the_cut_and_stay_distinct():
@@ -81,4 +82,4 @@ def test_an_n_gt_1_line_starts_with_what_the_return_paths_cost():
               "shm_return_ms_per_step", "ranks_launched", "ranks_that_ran_kernels", "oversubscribed_one_device", "gathered_records_on_rank0",
               "shm_return_records_seen_by_rank0", "host_inclusive_alignments_per_s"):
         assert k[:40] in kept, k
-    assert list(kept)[0] == "workload" and list(kept)[1] == "value_return_path"
+    assert list(kept)[0] == "workload" and list(kept)[1] == "value_is" and list(kept)[2] == "value_return_path"
