@@ -229,7 +229,7 @@ def one_genome(synth, batches):
     return chroms, out
 
 
-def host_inclusive_rate(ctx, batches, with_msa, seconds=HOST_INCLUSIVE_SECONDS, depth=STREAM_DEPTH, min_batches=3):
+def host_inclusive_rate(ctx, batches, with_msa, seconds=HOST_INCLUSIVE_SECONDS, depth=STREAM_DEPTH, min_batches=3, pinned_input=False):
     """host buffers in, host buffers out.  The batches (host arrays) cycle through a dellyhip_stream with `depth`
     slots -- depth - 1 in flight while the consumer still holds the block of the last collect -- for >= `seconds` of wall
     time; the clock covers validation, routing, staging copies, H2D, kernels, device-side compaction, D2H and the waits."""
@@ -237,9 +237,18 @@ def host_inclusive_rate(ctx, batches, with_msa, seconds=HOST_INCLUSIVE_SECONDS, 
     from delly_amd import abi, refine
     st = refine.Stream(ctx, depth=depth, with_msa=with_msa)
     args = []
+    registered = []
+    if pinned_input:
+        # the caller keeps its sequence bytes in pinned memory and leaves them alone until the batch is collected
+        # (dellyhip_stream_zero_copy): the copy engine reads them in place, no staging copy in submit
+        st.zero_copy(True)
     for b in batches:
         junc = np.ascontiguousarray(b.junctions)
         blob = np.ascontiguousarray(b.seq_blob, dtype=np.uint8)
+        if pinned_input:
+            blob = blob.copy()
+            ctx.host_register(blob.ctypes.data, blob.nbytes)
+            registered.append(blob)
         off = np.ascontiguousarray(b.seq_off, dtype=np.uint64)
         args.append((junc.shape[0], junc.ctypes.data_as(C.c_void_p), blob.ctypes.data_as(C.c_char_p),
                      off.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1), (junc, blob, off)))
@@ -282,12 +291,48 @@ def host_inclusive_rate(ctx, batches, with_msa, seconds=HOST_INCLUSIVE_SECONDS, 
     total = state["k"]
     stats = st.stats()
     st.close()
+    for blob in registered:
+        ctx.host_unregister(blob.ctypes.data)
     up = sum(a[5][0].nbytes + a[5][1].nbytes + a[5][2].nbytes for a in args) / len(args)
     return {"value": nj / dt, "unit": "junctions/s", "batches": total, "junctions_per_batch": nj / max(total, 1), "wall_s": dt,
             "ms_per_batch": dt / max(total, 1) * 1e3, "depth": depth,
             "host_ms_per_batch": {k: (v / max(total, 1) * 1e3 if k.endswith("_s") else v) for k, v in stats.items()},
             "bytes_up_per_batch": int(up), "bytes_down_per_batch": int(nb / max(total, 1) + nj / max(total, 1) * abi.result_dtype().itemsize),
             "note": "dellyhip_stream: host buffers in -> host buffers out (validation, routing, pinned staging, H2D, kernels, compaction, D2H); chromosome resident"}
+
+
+def host_inclusive_rate_threads(ctx, batches, with_msa, threads, seconds=HOST_INCLUSIVE_SECONDS, depth=4, pinned_input=True):
+    """The same loop from `threads` caller threads at once, each with a dellyhip_stream of its own on `ctx` (the reference's callers are
+    the workers of a thread pool, src/shortpe.h:80,175-201: c.maxThreads = 4 by default): a submit's host work -- validation, window
+    lengths, routing, staging the records -- is ~0.13 ms per 10 000 junctions on one thread, more than the kernels take.  ctypes
+    releases the GIL inside the calls."""
+    import threading
+    out = [None] * threads
+    err = []
+    start = threading.Barrier(threads)
+
+    def run(k):
+        try:
+            start.wait()
+            out[k] = host_inclusive_rate(ctx, batches[k % len(batches):] + batches[:k % len(batches)], with_msa, seconds=seconds, depth=depth,
+                                         pinned_input=pinned_input)
+        except Exception as e:   # pragma: no cover
+            err.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    wall = time.perf_counter() - t0
+    if err or any(o is None for o in out):
+        return {"error": "; ".join(err) or "a caller thread returned nothing"}
+    nj = sum(o["value"] * o["wall_s"] for o in out)
+    return {"value": sum(o["value"] for o in out), "unit": "junctions/s", "threads": threads, "depth_per_thread": depth,
+            "per_thread": [o["value"] for o in out], "ms_per_batch_per_thread": [o["ms_per_batch"] for o in out],
+            "junctions": nj, "wall_s_incl_warmup": wall,
+            "note": "sum of the threads' own rates (each over its own >= %.1f s timed region, all regions concurrent)" % seconds}
 
 
 def deficit_sweep(ctx, synth, device, with_cpu, steps=5):
@@ -833,9 +878,18 @@ def main():
             mode[0] = pth
             for x in rbs:
                 x.kernel_ms()
-            d, gs = timed_region(max(args.warmup, 1))
-            mx, per = max_over_ranks(d)
-            region[pth] = {"dt": mx, "per_rank": per, "gather_s": gs, "records": gathered_n[0], "blob_bytes": gathered_n[1]}
+            # the median of a few K-step regions, as at N = 1 (each one: K steps between barrier + synchronize on both sides, max over ranks).
+            # A single region of this path has been seen at 0.27 and at 3.1 ms per step on the same build, in processes minutes apart
+            # (profiles/r06/README.md: not reproduced by freeing memory, by the order of the rows or by where stdout / stderr go).
+            regs = []
+            for rep in range(max(1, min(args.repeats, 5))):
+                d, gs = timed_region(max(args.warmup, 1) if rep == 0 else 1)
+                mx, per = max_over_ranks(d)
+                regs.append((mx, per, gs))
+            regs.sort(key=lambda r: r[0])
+            mx, per, gs = regs[(len(regs) - 1) // 2]
+            region[pth] = {"dt": mx, "per_rank": per, "gather_s": gs, "records": gathered_n[0], "blob_bytes": gathered_n[1],
+                           "regions_ms_per_step": [r[0] / args.steps * 1e3 for r in regs]}
             if pth == "shm":
                 if world > 1:
                     dist.barrier()   # every rank has committed its last download
@@ -914,12 +968,17 @@ def main():
             # are re-cut there from the record (dellyhip_recut_alleles; tests/test_gpu_compact.py holds them to oracle/_ref), so they
             # do not cross PCIe.  The full payload (round 5's figure) is timed beside it, and so is the host re-cut of one batch.
             ctx_c = refine.Context(params=abi.params_sr(compact_alleles=True), device=local, share_with=ctx)
-            hi = host_inclusive_rate(ctx_c, batches, 0)
+            hi = host_inclusive_rate(ctx_c, batches, 0, pinned_input=True)
+            hi["input"] = "sequence bytes in pinned host memory, read in place (dellyhip_stream_zero_copy); records and offsets staged"
             hi["payload"] = "compact: records + consensus bytes; REF,ALT re-cut on the host from the record (DELLYHIP_COMPACT_ALLELES)"
             try:
                 if world == 1:
                     full = host_inclusive_rate(ctx, batches, 0, seconds=0.5)
                     hi["full_payload"] = {k: full[k] for k in ("value", "ms_per_batch", "bytes_down_per_batch", "batches")}
+                    hi["full_payload"]["input"] = "pageable host buffers, staged by submit (round 5's configuration)"
+                    mid = host_inclusive_rate(ctx_c, batches, 0, seconds=0.5)
+                    hi["compact_payload_pageable_input"] = {k: mid[k] for k in ("value", "ms_per_batch", "bytes_down_per_batch", "batches")}
+                    hi["two_caller_threads"] = host_inclusive_rate_threads(ctx_c, batches, 0, 2, seconds=0.7)
                     gr, gb = ctx_c.refine(batches[0], want_alignment=False)
                     best = None
                     buf = None
@@ -990,6 +1049,7 @@ def main():
                 cfg["gathered_records_on_rank0"] = r["records"]
                 cfg["gathered_blob_bytes_on_rank0"] = r["blob_bytes"]
                 cfg["gather_path"] = path_text["rccl"]
+                cfg["gather_regions_ms_per_step"] = r.get("regions_ms_per_step")
             if "shm" in region:    # the pipelined per-rank return into shared memory
                 r = region["shm"]
                 cfg["shm_return_alignments_per_s"] = total_units / r["dt"]
@@ -998,6 +1058,8 @@ def main():
                 cfg["shm_return_records_seen_by_rank0"] = r["records"]
                 cfg["shm_return_blob_bytes_seen_by_rank0"] = r["blob_bytes"]
                 cfg["shm_return_path"] = path_text["shm"]
+                cfg["shm_return_regions_ms_per_step"] = r.get("regions_ms_per_step")
+                cfg["value_is_region"] = "median of %d timed K-step regions (max over ranks each)" % len(r.get("regions_ms_per_step") or [0])
         if isinstance(hi, dict) and "value" in hi:
             cfg["host_inclusive_alignments_per_s"] = hi["value"]       # SURVEY.md 8d's definition: host buffers in -> host buffers out
             cfg["host_inclusive_wall_s"] = hi["wall_s"]
@@ -1006,6 +1068,8 @@ def main():
             cfg["host_inclusive_payload"] = "compact (REF,ALT re-cut on the host from the record); full payload: host_inclusive_full_payload_alignments_per_s"
             if isinstance(hi.get("full_payload"), dict) and "value" in hi["full_payload"]:
                 cfg["host_inclusive_full_payload_alignments_per_s"] = hi["full_payload"]["value"]
+            if isinstance(hi.get("two_caller_threads"), dict) and "value" in hi["two_caller_threads"]:
+                cfg["host_inclusive_two_caller_threads_per_s"] = hi["two_caller_threads"]["value"]
             if "host_recut_ms_per_batch_one_thread" in hi:
                 cfg["host_recut_ms_per_batch_one_thread"] = hi["host_recut_ms_per_batch_one_thread"]
         out = {

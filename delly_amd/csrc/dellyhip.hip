@@ -1155,56 +1155,83 @@ __global__ void small_inv_fix_kernel(dellyhip_result* res, const SmallInv* list,
 }
 
 // ---- device-side compaction of the fixed-stride out blob (dellyhip_batch_fetch) ----------
-// off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total
-__global__ __launch_bounds__(1024) void blob_offsets_kernel(const dellyhip_result* res, int n, uint64_t* off) {
-  // One block of 1024 threads; per round thread t owns the C records [base + t * C, + C): their lengths are loaded into registers
-  // with EVERY load of the round in flight at once (the index is clamped, not branched on: round 5 -- a loop over a run-time chunk
-  // took one memory latency per record and pass, 39 us for 10 000 records), then one scan over the wavefront (shuffles), one over
-  // the 16 wavefront totals, and the offsets from the registers.  Rounds of 16 384 records carry the running total.
-  constexpr int C = 16;
-  __shared__ uint64_t wsum[16];
+// off[i] = bytes of junctions < i (consensus + "REF,ALT" + two alignment rows), off[n] = total.
+// Two launches of small workgroups (round 6).  Rounds 3-5 ran ONE workgroup of 1 024 threads: it needs a compute unit with all
+// sixteen wavefront slots free, and in the pipelined path it is queued while the persistent sparse kernel of the next batch holds
+// every slot of the chip -- rocprofv3 showed 131 us on average (18 us alone, up to 442 us) for 31 us of work, and the slots of a
+// dellyhip_stream ran their sparse kernels at 12 of 16 wavefronts per CU just to leave it room.  Workgroups of 256 threads
+// (four wavefronts) slip in as wavefronts retire.
+//   blob_offsets_local_kernel: workgroup g scans the lengths of records [g * BO_SPAN, + BO_SPAN) -> off[i] relative to its
+//                              first record, tot[g] = its bytes
+//   blob_offsets_fix_kernel:   off[i] += sum of tot[< g]; off[n] = total
+constexpr int BO_SPAN = 1024;   // records per workgroup (256 threads x 4)
+__host__ __device__ inline size_t blob_off_words(size_t n) { return n + 1 + (n + BO_SPAN - 1) / BO_SPAN + 1; }   // off[0 .. n], then tot[]
+__global__ __launch_bounds__(256) void blob_offsets_local_kernel(const dellyhip_result* res, int n, uint64_t* off) {
+  constexpr int C = BO_SPAN / 256;
+  __shared__ uint64_t wsum[4];
+  uint64_t* tot = off + n + 1;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  if (n <= 0) {
-    if (t == 0) off[0] = 0;
+  const int lo = (int)blockIdx.x * BO_SPAN + t * C;
+  uint64_t len[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) {   // (the index is clamped, not branched on: every load of the thread in flight at once)
+    const int r = min(lo + i, n - 1);
+    const int l0 = res[r].cons_len, l1 = res[r].allele_len, l2 = res[r].aln_len;
+    const uint64_t v = (uint64_t)max(l0, 0) + (uint64_t)max(l1, 0) + 2ull * (uint64_t)max(l2, 0);
+    len[i] = (lo + i < n) ? v : 0ull;
+  }
+  uint64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < C; ++i) sum += len[i];
+  uint64_t inc = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint64_t at = inc - sum, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t v = wsum[k];
+    at += k < w ? v : 0ull;
+    total += v;
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    if (lo + i < n) off[lo + i] = at;
+    at += len[i];
+  }
+  if (t == 0) tot[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void blob_offsets_fix_kernel(int n, uint64_t* off) {
+  __shared__ uint64_t part[4];
+  const uint64_t* tot = off + n + 1;
+  const int t = threadIdx.x, g = (int)blockIdx.x, ng = (n + BO_SPAN - 1) / BO_SPAN;
+  const bool last = g == ng;            // one extra workgroup writes the total
+  uint64_t s = 0;
+  for (int k = t; k < (last ? ng : g); k += 256) s += tot[k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if ((t & 63) == 0) part[t >> 6] = s;
+  __syncthreads();
+  const uint64_t base = part[0] + part[1] + part[2] + part[3];
+  if (last) {
+    if (t == 0) off[n] = base;
     return;
   }
-  uint64_t carry = 0;
-  for (int base = 0; base < n; base += 1024 * C) {
-    const int lo = base + t * C;
-    uint64_t len[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-      const int r = min(lo + i, n - 1);
-      const int l0 = res[r].cons_len, l1 = res[r].allele_len, l2 = res[r].aln_len;
-      const uint64_t v = (uint64_t)max(l0, 0) + (uint64_t)max(l1, 0) + 2ull * (uint64_t)max(l2, 0);
-      len[i] = (lo + i < n) ? v : 0ull;
-    }
-    uint64_t sum = 0;
-#pragma unroll
-    for (int i = 0; i < C; ++i) sum += len[i];
-    uint64_t inc = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint64_t v = __shfl_up(inc, d);
-      if (lane >= d) inc += v;
-    }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint64_t at = carry + inc - sum, total = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint64_t v = wsum[k];
-      at += k < w ? v : 0ull;
-      total += v;
-    }
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-      if (lo + i < n) off[lo + i] = at;
-      at += len[i];
-    }
-    carry += total;
-    __syncthreads();   // (wsum is rewritten by the next round)
+  if (base)
+    for (int i = g * BO_SPAN + t; i < min(n, (g + 1) * BO_SPAN); i += 256) off[i] += base;
+}
+// off must hold blob_off_words(n) words
+static inline void launch_blob_offsets(hipStream_t s, const dellyhip_result* res, int n, uint64_t* off) {
+  if (n <= 0) {
+    (void)hipMemsetAsync(off, 0, sizeof(uint64_t), s);
+    return;
   }
-  if (t == 0) off[n] = carry;
+  const int ng = (n + BO_SPAN - 1) / BO_SPAN;
+  hipLaunchKernelGGL(blob_offsets_local_kernel, dim3(ng), dim3(256), 0, s, res, n, off);
+  hipLaunchKernelGGL(blob_offsets_fix_kernel, dim3(ng + 1), dim3(256), 0, s, n, off);
 }
 // one wavefront per junction: its three pieces, back to back, at out + off[i]
 __global__ void blob_gather_kernel(const dellyhip_result* res, const uint8_t* blob, const uint64_t* off, uint8_t* out, int n, uint64_t cap) {
@@ -1389,6 +1416,7 @@ struct UploadOpts {
   bool lazy = false;                   // stream slot: host routing of what split_sparse_kernel leaves behind is deferred
   hipStream_t up = nullptr;            // the staged inputs travel on this stream (else the context's); up_done is recorded
   hipEvent_t up_done = nullptr;        // behind the copy and the context's stream waits for it
+  bool zero_copy_blob = false;         // a PINNED seq_blob is read by the copy engine in place instead of being staged (dellyhip_stream_zero_copy)
 };
 
 // per-batch host state back to "freshly constructed", device allocations kept
@@ -1746,7 +1774,18 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
     if ((rc = arena->begin(cap))) return bail(rc);
   }
   if ((rc = push(b->junc, junc, (size_t)n, 0, "H2D junctions"))) return bail(rc);
-  if ((rc = push(b->seq_blob, reinterpret_cast<const uint8_t*>(seq_blob), (size_t)blob_bytes, 64, "H2D sequences"))) return bail(rc);   // (+64: the bit-vector kernels fetch pattern bytes 32 at a time)
+  // The sequence bytes are three quarters of what a batch uploads and the largest part of the host's staging time (one memcpy into
+  // the pinned arena).  A caller that keeps them in pinned memory (dellyhip_host_register / hipHostMalloc) and has said so
+  // (dellyhip_stream_zero_copy) is spared the copy: the bytes get their place at the END of the arena's device block and travel
+  // from the caller's buffer by a copy of their own (below, behind the arena's).
+  bool blob_in_place = false;
+  if (arena && opts->zero_copy_blob && blob_bytes >= 4096) {
+    void *d0 = nullptr, *d1 = nullptr;
+    blob_in_place = hipHostGetDevicePointer(&d0, const_cast<char*>(seq_blob), 0) == hipSuccess &&
+                    hipHostGetDevicePointer(&d1, const_cast<char*>(seq_blob) + blob_bytes - 1, 0) == hipSuccess;
+    if (!blob_in_place) (void)hipGetLastError();   // (pageable memory: staged as usual)
+  }
+  if (!blob_in_place && (rc = push(b->seq_blob, reinterpret_cast<const uint8_t*>(seq_blob), (size_t)blob_bytes, 64, "H2D sequences"))) return bail(rc);   // (+64: the bit-vector kernels fetch pattern bytes 32 at a time)
   if ((rc = push(b->seq_off, seq_off, (size_t)n_seq + 1, 0, "H2D offsets"))) return bail(rc);
   const bool cons_len_staged = arena && !with_msa;   // (given consensus: the lengths travel with the other inputs)
   if (recycle) {
@@ -1910,7 +1949,14 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
   }
   if (arena && arena->used) {
     hipStream_t up = (opts->up && opts->up_done) ? opts->up : c->stream;
-    e = hipMemcpyAsync(arena->d.p, arena->h.p, arena->used, hipMemcpyHostToDevice, up);
+    const size_t staged = arena->used;
+    if (blob_in_place) {   // (reserved last: the arena's own copy ends in front of it)
+      uint8_t* dev = nullptr;
+      if (!arena->put<uint8_t>(nullptr, (size_t)blob_bytes, 64, &dev)) return bail(fail(DELLYHIP_E_RUNTIME, "staging arena overflow"));
+      b->seq_blob.borrow(dev, (size_t)blob_bytes + 64);
+    }
+    e = hipMemcpyAsync(arena->d.p, arena->h.p, staged, hipMemcpyHostToDevice, up);
+    if (e == hipSuccess && blob_in_place) e = hipMemcpyAsync(b->seq_blob.p, seq_blob, (size_t)blob_bytes, hipMemcpyHostToDevice, up);
     if (e == hipSuccess && up != c->stream) {
       e = hipEventRecord(opts->up_done, up);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, opts->up_done, 0);
@@ -2279,8 +2325,8 @@ static int compact_batch(dellyhip_ctx* c, dellyhip_batch* b, std::vector<uint64_
   off.assign((size_t)b->n + 1, 0);
   if (b->n == 0) return 0;
   if (b->fetch_pending && b->fetch_ev) HIPCHK(hipEventSynchronize(b->fetch_ev));   // (it uses the same offset / compaction buffers)
-  if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
-  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, b->res.p, b->n, b->blob_off.p);
+  if ((rc = b->blob_off.reserve(blob_off_words((size_t)b->n)))) return rc;
+  launch_blob_offsets(c->stream, b->res.p, b->n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(off.data(), b->blob_off.p, off.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -2359,7 +2405,7 @@ int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_resu
   HIPCHK(hipHostGetDevicePointer(&d_status, b->fetch_status, 0));
   const uint64_t cap = d_blob ? out_blob_cap : 0;
   int rc;
-  if ((rc = b->blob_off.reserve((size_t)b->n + 1))) return rc;
+  if ((rc = b->blob_off.reserve(blob_off_words((size_t)b->n)))) return rc;
   // (the used bytes are not known here: room for the smaller of everything the batch can hold and what the caller can take)
   // the kernels' cap is what was RESERVED here, not the caller's: a record with lengths beyond its out_stride share would
   // otherwise pass `off[n] <= cap` and overrun blob_compact.  (+16: the compacted bytes start at the destination's alignment mod 16.)
@@ -2376,7 +2422,7 @@ int dellyhip_batch_fetch_begin(dellyhip_ctx* c, dellyhip_batch* b, dellyhip_resu
   hipStream_t s = env_on("DELLYHIP_FETCH_SAME_STREAM") ? run_s : device_download_stream(c->device);
   if (!s) s = run_s;
   if (s != run_s && b->pending && b->last) HIPCHK(hipStreamWaitEvent(s, b->last, 0));
-  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, b->n, b->blob_off.p);
+  launch_blob_offsets(s, b->res.p, b->n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_kernel, dim3(std::min(b->n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p, b->blob_off.p,
                      compact, b->n, kcap);
@@ -2607,18 +2653,28 @@ int dellyhip_comm_gather_bytes(dellyhip_ctx* c, dellyhip_comm* m, int32_t root, 
 }
 
 // the exchange itself: afterwards the root holds every rank's records (rank order) and compact blobs in HBM
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static int gather_device(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b, int32_t root, std::vector<uint64_t>& all,
                          std::vector<uint64_t>& first_n, std::vector<uint64_t>& first_b, const void** d_rec, const void** d_blob) {
   std::vector<uint64_t> off;
   uint64_t used = 0;
+  static const bool trace = getenv("DELLYHIP_TRACE_GATHER") != nullptr;   // (debugging aid: where a gather's host time goes)
+  const double tg0 = trace ? now_s() : 0;
   int local_rc = dellyhip_batch_sync(c, b);
+  const double tg1 = trace ? now_s() : 0;
   if (!local_rc) local_rc = compact_batch(c, b, off, &used);
+  if (trace) fprintf(stderr, "gather: wait for the batch %.3f ms, compaction %.3f ms\n", (tg1 - tg0) * 1e3, (now_s() - tg1) * 1e3);
   if (!local_rc && getenv("DELLYHIP_TEST_FAIL_GATHER_RANK") && atoi(getenv("DELLYHIP_TEST_FAIL_GATHER_RANK")) == m->rank)
     local_rc = fail(DELLYHIP_E_RUNTIME, "dellyhip_gather_results: failure injected by DELLYHIP_TEST_FAIL_GATHER_RANK");   // (tests of the abort protocol)
   const std::string local_err = local_rc ? g_err : std::string();
   const int W = m->world;
   const bool is_root = m->rank == root;
+  const double tg2 = trace ? now_s() : 0;
   if (int rc = exchange_sizes(m, c->stream, (uint64_t)b->n, used, local_rc, local_err, all)) return rc;
+  if (trace) fprintf(stderr, "gather: size exchange %.3f ms\n", (now_s() - tg2) * 1e3);
   uint64_t tot_n = 0, tot_b = 0;
   first_n.assign(W + 1, 0);
   first_b.assign(W + 1, 0);
@@ -2723,13 +2779,18 @@ int dellyhip_gather_results(dellyhip_ctx* c, dellyhip_comm* m, dellyhip_batch* b
   if (counts)
     for (int r = 0; r < W; ++r) counts[r] = (int32_t)all[2 * r];
   if (tot_n) {
+    const bool trace = getenv("DELLYHIP_TRACE_GATHER") != nullptr;
+    const double t0 = trace ? now_s() : 0;
     HIPCHK(hipMemcpyAsync(results, dr, tot_n * sizeof(dellyhip_result), hipMemcpyDeviceToHost, c->stream));
     if (tot_b) HIPCHK(hipMemcpyAsync(out_blob, db, tot_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (trace) fprintf(stderr, "gather: download of %llu + %llu bytes %.3f ms\n", (unsigned long long)(tot_n * sizeof(dellyhip_result)), (unsigned long long)tot_b, (now_s() - t0) * 1e3);
     // blob offsets: each rank's pieces lie back to back in its compact blob in junction order
     std::vector<uint64_t> cnt(W), byt(W);
     for (int r = 0; r < W; ++r) { cnt[r] = first_n[r + 1] - first_n[r]; byt[r] = first_b[r + 1] - first_b[r]; }
+    const double t1 = trace ? now_s() : 0;
     if (dellyhip_rebase_gathered(results, tot_n, W, cnt.data(), byt.data())) return DELLYHIP_E_RUNTIME;
+    if (trace) fprintf(stderr, "gather: rebase on the host %.3f ms\n", (now_s() - t1) * 1e3);
   }
   return 0;
 }
@@ -2800,6 +2861,7 @@ static DeviceStreams& device_streams(int device) {
 struct dellyhip_stream {
   dellyhip_ctx* parent = nullptr;
   int with_msa = 0, want_alignment = 0;
+  bool zero_copy = false;   // dellyhip_stream_zero_copy: pinned sequence bytes are read in place
   std::vector<StreamSlot> slots;
   uint64_t n_submit = 0, n_collect = 0;
   // The copies run on two streams of their own, created with priorities other than the compute streams': the runtime keeps
@@ -2828,9 +2890,6 @@ struct dellyhip_stream {
   double t_created = 0;
   uint64_t log_junctions = 0, log_up = 0, log_down = 0;
 };
-static inline double now_s() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 namespace {
 
@@ -2842,12 +2901,12 @@ int slot_compact_and_download(dellyhip_stream* st, StreamSlot& S, bool all_blob)
   dellyhip_batch* b = S.b;
   const int n = b->n;
   int rc;
-  if ((rc = b->blob_off.reserve_grow((size_t)n + 1)) || (rc = b->blob_compact.reserve_grow(std::max<uint64_t>((uint64_t)n * b->out_stride, 1))) ||
+  if ((rc = b->blob_off.reserve_grow(blob_off_words((size_t)n))) || (rc = b->blob_compact.reserve_grow(std::max<uint64_t>((uint64_t)n * b->out_stride, 1))) ||
       (rc = S.d_rec.reserve_grow(64 + (size_t)std::max(n, 1) * sizeof(dellyhip_result))))
     return rc;
   hipStream_t s = c->stream;
   const bool split = st->s_down && S.comp_done && !all_blob;   // (the slow path stays on the slot's own stream)
-  hipLaunchKernelGGL(blob_offsets_kernel, dim3(1), dim3(1024), 0, s, b->res.p, n, b->blob_off.p);
+  launch_blob_offsets(s, b->res.p, n, b->blob_off.p);
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(blob_gather_records_kernel, dim3(std::min(n, c->n_cu * 16)), dim3(dh::WAVE), 0, s, b->res.p, b->out_blob.p,
                      b->blob_off.p, b->blob_compact.p, reinterpret_cast<dellyhip_result*>(S.d_rec.p + 64), n,
@@ -3043,7 +3102,10 @@ int dellyhip_stream_create(dellyhip_ctx* c, int32_t depth, int32_t with_msa, int
     // 12 of the 16 wavefront slots of a CU for a slot's persistent sparse kernel: the next slot's kernel (the other compute
     // stream), the compaction kernels and the memsets find room at once instead of in the kernel's tail -- 32.4 against
     // 29.6 M junctions/s at depth 6 (tools/stream_matrix.sh); DELLYHIP_SPS_WAVES overrides
-    S.ctx->sps_waves = (depth >= 2 && !getenv("DELLYHIP_SPS_WAVES")) ? std::min(c->sps_waves, 12) : c->sps_waves;
+    // Round 6: with the compact payload (DELLYHIP_COMPACT_ALLELES: 2.9 instead of 9.9 MB down per 10 000 junctions) the room is
+    // not needed -- 47.1 against 43.8 M junctions/s with all 16 -- and the cap applies to the full payload only (39.6 / 39.7).
+    const bool roomy = depth >= 2 && !getenv("DELLYHIP_SPS_WAVES") && !(c->params.reserved & DELLYHIP_COMPACT_ALLELES);
+    S.ctx->sps_waves = roomy ? std::min(c->sps_waves, 12) : c->sps_waves;
     S.ctx->lr_waves = c->lr_waves; S.ctx->lr_teams = c->lr_teams; S.ctx->lr_team_serial = c->lr_team_serial; S.ctx->sparse_cost = c->sparse_cost; S.ctx->msa_tmax = c->msa_tmax;
     S.ctx->msa_waves = c->msa_waves; S.ctx->msa_only = c->msa_only; S.ctx->msa_team = c->msa_team; S.ctx->msa_pair = c->msa_pair; S.ctx->sr_wide = c->sr_wide;
   }
@@ -3084,6 +3146,12 @@ static int slot_bail(StreamSlot& S, int rc) {
   return rc;
 }
 
+int dellyhip_stream_zero_copy(dellyhip_stream* st, int32_t on) {
+  if (!st) return fail(DELLYHIP_E_ARG, "null argument");
+  st->zero_copy = on != 0;
+  return 0;
+}
+
 int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_junction* junc, const char* seq_blob, const uint64_t* seq_off,
                            uint64_t n_seq, uint64_t tag) {
   if (!st) return fail(DELLYHIP_E_ARG, "null argument");
@@ -3097,6 +3165,7 @@ int dellyhip_stream_submit(dellyhip_stream* st, int32_t n, const dellyhip_juncti
   o.lazy = true;
   o.up = st->s_up;
   o.up_done = S.up_done;
+  o.zero_copy_blob = st->zero_copy;
   dellyhip_batch* b = nullptr;
   const double t0 = now_s();
   int rc = slot_pump(st, nullptr);
@@ -3182,7 +3251,7 @@ static int stream_collect_impl(dellyhip_stream* st, const dellyhip_result** resu
       // rare: junctions beyond the sparse kernel's shapes or level budget -> dense kernels now, then compact again
       if ((rc = finish_lazy(S))) return rc;
       HIPCHK(hipStreamSynchronize(c->stream));
-      blob_offsets_kernel<<<dim3(1), dim3(1024), 0, c->stream>>>(b->res.p, b->n, b->blob_off.p);
+      launch_blob_offsets(c->stream, b->res.p, b->n, b->blob_off.p);
       HIPCHK(hipMemcpyAsync(&H->used, b->blob_off.p + b->n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       if (H->used > S.blob_cap) {

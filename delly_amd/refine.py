@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdellyhip.so")
 
 EXPORTS = [
-    "dellyhip_recut_alleles", "dellyhip_recut_alleles_batch",
+    "dellyhip_recut_alleles", "dellyhip_recut_alleles_batch", "dellyhip_stream_zero_copy",
     "dellyhip_create", "dellyhip_destroy", "dellyhip_last_error", "dellyhip_default_params_sr",
     "dellyhip_default_params_lr", "dellyhip_set_chromosome", "dellyhip_refine_batch",
     "dellyhip_align_consensus_batch", "dellyhip_batch_upload", "dellyhip_batch_run", "dellyhip_batch_sync",
@@ -459,6 +459,10 @@ class Stream:
         off = np.ascontiguousarray(batch.seq_off, dtype=np.uint64)
         self.ctx._check(self.ctx.lib.dellyhip_stream_submit(self._s, int(junc.shape[0]), _p(junc, C.c_void_p), _p(blob),
                                                             _p(off, C.POINTER(C.c_uint64)), C.c_uint64(off.size - 1), C.c_uint64(tag)))
+
+    def zero_copy(self, on=True):
+        """dellyhip_stream_zero_copy: pinned sequence bytes are read in place (the caller leaves them alone until the batch is collected)"""
+        self.ctx._check(self.ctx.lib.dellyhip_stream_zero_copy(self._s, 1 if on else 0))
 
     def submit_raw(self, n, junc_ptr, blob_ptr, off_ptr, n_seq, tag=0):
         """pre-marshalled arguments (benchmark loops: no numpy work between the calls)"""

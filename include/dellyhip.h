@@ -238,6 +238,11 @@ int dellyhip_stream_submit(dellyhip_stream* stream, int32_t n_junctions, const d
                            const char* seq_blob, const uint64_t* seq_off, uint64_t n_seq, uint64_t tag);
 int dellyhip_stream_collect(dellyhip_stream* stream, const dellyhip_result** results, const char** blob,
                             uint64_t* blob_len, int32_t* n_junctions, uint64_t* tag);
+/* on != 0: a seq_blob passed to dellyhip_stream_submit that lies in PINNED host memory (dellyhip_host_register, hipHostMalloc) is
+ * read by the copy engine in place instead of being copied into the stream's staging arena first -- the sequence bytes are three
+ * quarters of a batch's upload and the staging copy was the largest part of a submit's host time.  The caller must then leave
+ * those bytes unchanged until the batch has been collected.  Pageable memory is staged as before (no error).  Default: off. */
+int dellyhip_stream_zero_copy(dellyhip_stream* stream, int32_t on);
 /* Errors: a submit that fails leaves the stream as it was before the call (anything it had enqueued has been waited for,
  * the slot is free).  A collect that fails DROPS the batch it was waiting for -- the stream's pending count goes down by
  * one, the slot is free again and the following collects return the following batches; the synchronous entry points

@@ -95,3 +95,30 @@ def test_stream_with_the_compact_payload(gpu_ctx, reference):
         assert gb.nbytes < 0.45 * rb.nbytes or rb.nbytes == 0
     finally:
         ctx.close()
+
+
+def test_stream_reads_pinned_sequence_bytes_in_place(gpu_ctx, reference):
+    """dellyhip_stream_zero_copy: a pinned seq_blob is not staged; same records.  A pageable blob on the same stream is staged as before."""
+    bs = [synth.make_batch(3000, mode="c2", seed=s) for s in (41, 42, 43)]
+    import bench
+    chroms, batches = bench.one_genome(synth, bs)
+    gpu_ctx.set_chromosomes(chroms)
+    st = refine.Stream(gpu_ctx, depth=3)
+    st.zero_copy(True)
+    keep = []
+    for k, b in enumerate(batches):
+        blob = np.ascontiguousarray(b.seq_blob, dtype=np.uint8).copy()
+        if k != 1:                                  # batch 1 stays pageable
+            gpu_ctx.host_register(blob.ctypes.data, blob.nbytes)
+        keep.append(blob)
+        b2 = synth.Batch(b.chroms, b.junctions, blob, b.seq_off, b.with_msa, b.truth)
+        st.submit(b2, tag=k)
+    for k, b in enumerate(batches):
+        gr, gb, tag = st.collect()
+        assert tag == k
+        rr, rb = reference.refine_batch(b, want_alignment=False, n_threads=THREADS)
+        compare(gr, gb, rr, rb, fields=CORE, blobs=("cons", "allele"), label="zero-copy stream batch %d" % k)
+    st.close()
+    for k, blob in enumerate(keep):
+        if k != 1:
+            gpu_ctx.host_unregister(blob.ctypes.data)
