@@ -657,7 +657,7 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
     const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
     const int grid = (b->lri_count + rounds - 1) / rounds;
     dh::LrInsArgs li = b->lri;
-    li.realign = ((c->params.reserved & 1) && b->with_msa != 2) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions
+    li.realign = ((c->params.reserved & 1) && b->with_msa != 2 && !b->ref_blob.p) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions (direct pairs: splitAlign alone)
     hipLaunchKernelGGL(dh::lr_ins_kernel, dim3(grid), dim3(dh::WAVE), 0, c->lr_aux, ai, li);
     hipError_t e1 = hipGetLastError();
     if (e1 == hipSuccess) e1 = hipEventRecord(b->lri_join, c->lr_aux);
@@ -711,13 +711,13 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
     hipLaunchKernelGGL(dh::ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a);
     HIPCHK(hipGetLastError());
   }
-  if (b->lr_count > 0 && !direct) {
+  if (b->lr_count > 0) {   // (direct: dellyhip_long_needle beyond the short-read shapes)
     a.work_list = b->work.p + b->lr_first;
     a.n_work = b->lr_count;
     a.work_counter = c->counters.p + 28;
     const int grid = std::min(b->lr_count, b->lr_blocks);
     dh::LrArgs lr = b->lr;
-    lr.realign = (c->params.reserved & 1) ? 1 : 0;
+    lr.realign = ((c->params.reserved & 1) && !b->ref_blob.p) ? 1 : 0;   // (direct pairs: longNeedle alone, no orientation test)
     lr.lr_grid = grid;
     hipStream_t aux = nullptr;
     if (b->lr_teams > 0 && lr.team_state && ensure_lr_aux(c, b) == 0) aux = (s == c->lr_aux) ? c->stream : c->lr_aux;
@@ -752,13 +752,13 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
       b->lr_aux_used = true;
     }
   }
-  if (b->lri_count > 0 && !direct && !lri_side) {
+  if (b->lri_count > 0 && !lri_side) {   // (direct: dellyhip_split_align beyond the short-read shapes)
     a.work_list = b->work.p + b->lri_first;
     a.n_work = b->lri_count;
     const int rounds = (b->lri_count + b->lri_blocks - 1) / b->lri_blocks;
     const int grid = (b->lri_count + rounds - 1) / rounds;
     dh::LrInsArgs li = b->lri;
-    li.realign = ((c->params.reserved & 1) && b->with_msa != 2) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions
+    li.realign = ((c->params.reserved & 1) && b->with_msa != 2 && !b->ref_blob.p) ? 1 : 0;   // src/assemble.h:859: the long-read loop passes realign = false for insertions (direct pairs: splitAlign alone)
     hipLaunchKernelGGL(dh::lr_ins_kernel, dim3(grid), dim3(dh::WAVE), 0, s, a, li);
     HIPCHK(hipGetLastError());
   }
@@ -990,13 +990,13 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL,
     const dellyhip_junction& J = b->h_junc[i];
     if (J.svt == 4) {  // splitAlign path: own kernels, one junction per wavefront
       if (mode == BINS_LEFTOVER) continue;
-      if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
-          b->lri_blocks > 0)
+      if (!b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX && b->h_win_len[i] <= dh::LR_NMAX &&
+          b->lri_blocks > 0)   // (direct batches carry window lengths only beyond the short-read shapes: direct_pair)
         lriv.push_back(i);
       else ins.push_back(i);
       continue;
     }
-    if (!direct && !b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
+    if (!b->h_win_len.empty() && is_lr_shape(P, J, m, b->h_win_len[i]) && m <= dh::LR_MMAX &&
         b->h_win_len[i] <= dh::LR_NMAX && b->lr_blocks > 0) {  // strip kernel (else: E_LIMIT in the short-read kernels)
       if (mode != BINS_LEFTOVER) lrv.push_back(i);
       continue;
@@ -3490,12 +3490,22 @@ int dellyhip_msa_wfa(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, con
 static int direct_pair(dellyhip_ctx* c, int svt, const char* s1, int32_t m, const char* s2, int32_t n, char* align_rows,
                        int32_t aln_cap, int32_t* aln_len, int32_t* found, const char* what) {
   if (!c || !s1 || !s2 || !aln_len || !found || m < 0 || n < 0) return fail(DELLYHIP_E_ARG, "bad argument");
-  if (m > dh::MMAX || n > dh::NMAX) return fail(DELLYHIP_E_LIMIT, what);
+  // beyond the short-read kernels' shapes: the long-read kernels in their direct mode (round 6; the reference has no limit,
+  // src/needle.h:45-47, src/split.h:480-482)
+  const bool big = m > dh::MMAX || n > dh::NMAX;
+  if (big && (m > dh::LR_MMAX || n > dh::LR_NMAX)) return fail(DELLYHIP_E_LIMIT, what);
   HIPCHK(hipSetDevice(c->device));
   dellyhip_batch* b = new dellyhip_batch();
   b->n = 1;
   b->want_alignment = 1;
   b->out_stride = (dh::OUT_CONS_CAP + dh::OUT_ALLELE_CAP + dh::OUT_ALN_CAP + 15) & ~15ull;
+  if (big) {   // output slot of the long-read shapes (as batch_upload_impl sizes it)
+    b->out_cons_cap = std::max<int>(dh::OUT_CONS_CAP, (m + 16) & ~15);
+    b->out_allele_cap = std::max<int>(dh::OUT_ALLELE_CAP, (m + n + 8 + 15) & ~15);
+    b->out_aln_cap = std::max<int>(dh::OUT_ALN_CAP, 2 * ((m + n + 8 + 15) & ~15));
+    b->out_stride = ((uint64_t)b->out_cons_cap + b->out_allele_cap + b->out_aln_cap + 15) & ~15ull;
+    b->h_win_len.assign(1, n);
+  }
   dellyhip_junction J{};
   J.svt = svt;
   J.n_seq = 1;
@@ -3517,6 +3527,8 @@ static int direct_pair(dellyhip_ctx* c, int svt, const char* s1, int32_t m, cons
   (void)hipMemcpy(b->ref_len.p, &n, 4, hipMemcpyHostToDevice);
   (void)hipMemsetAsync(b->res.p, 0, sizeof(dellyhip_result), c->stream);
   (void)hipStreamSynchronize(c->stream);
+  if (big && svt == 4 && (rc = setup_lri_workspace(c, b, m, n, 1))) return bail(rc);
+  if (big && svt != 4 && (rc = setup_lr_workspace(c, b, m, n, 1))) return bail(rc);
   if ((rc = build_bins(b, c->params))) return bail(rc);
   rc = dellyhip_batch_run(c, b, nullptr);
   dellyhip_result R;
@@ -3586,7 +3598,19 @@ int dellyhip_edlib_align(dellyhip_ctx* c, const char* query, int32_t qn, const c
     out[3] = -2;
     return 0;
   }
-  if (tn > dh::MMAX || qn > dh::NMAX) return fail(DELLYHIP_E_LIMIT, "edlibAlign operand exceeds the insertion-kernel limits");
+  if (tn > dh::MMAX || qn > dh::NMAX) {
+    // beyond the insertion kernel's shapes: the strip machinery of dellyhip_edlib_align_full (any shape it takes; round 6 --
+    // the reference's edlibAlign has no limit).  out[] as above: distance, locations, first end, first start (-2: none)
+    std::vector<int32_t> ends((size_t)tn + 2), starts((size_t)tn + 2);
+    int32_t ed = -1, nloc = 0;
+    rc = dellyhip_edlib_align_full(c, query, qn, target, tn, -1, mode, task, 0, &ed, &nloc, ends.data(), starts.data(), (int32_t)ends.size(), ops, ops_cap, ops_len);
+    if (rc) return rc;
+    out[0] = ed;
+    out[1] = nloc;
+    out[2] = nloc > 0 ? ends[0] : -1;
+    out[3] = (task >= 1 && nloc > 0) ? starts[0] : -2;
+    return 0;
+  }
   if ((rc = ensure_scratch(c))) return rc;
   DevBuf<uint8_t> dq, dt, dops;
   DevBuf<int32_t> dout;

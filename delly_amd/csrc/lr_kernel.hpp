@@ -682,7 +682,7 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
   X.svS = J.sv_start;
   X.svE = J.sv_end;
   X.sBeg = X.sEnd = X.eBeg = X.eEnd = 0;
-  X.direct = false;
+  X.direct = (A.ref_base != nullptr);   // dellyhip_long_needle beyond the short-read shapes: s2 given, longNeedle only (round 6)
   X.consLeft = X.refLeft = X.refRight = X.consRight = 0;
   StrPtr S{ws, ws + R.off_rcons, ws + R.off_ref, ws + R.off_rref};
   int32_t* bnd0 = reinterpret_cast<int32_t*>(ws + R.off_bnd0);
@@ -707,10 +707,17 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     }
   }
   if (go && J.svt == 4) { status = DELLYHIP_E_LIMIT; go = false; }   // long-read splitAlign: edlib's Hirschberg regime
-  if (go && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
+  if (go && !X.direct && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
   Seg seg[3];
   int nseg = 0, n = 0;
-  if (go) {
+  if (go && X.direct) {
+    n = A.ref_len[j];
+    if (n < 0 || n > LR_NMAX || n > R.ncap) { status = DELLYHIP_E_LIMIT; go = false; n = 0; }
+    else {
+      const uint8_t* rg = A.ref_base + A.ref_off[j];
+      for (int i = lane; i < n; i += WAVE) S.ref[i] = rg[i];
+    }
+  } else if (go) {
     int sBeg, sEnd, eBeg, eEnd;
     if (!window_segments<false>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
@@ -901,7 +908,8 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
 #ifdef DH_LR_TIMING
     const unsigned long long tq3 = wall_clock64();
 #endif
-    split_detect(A, X, S, L, X.go, spLtot, spPosC, lane);
+    if (X.go && X.direct && lane == 0) X.out->ok = 1;   // longNeedle() returned true, rows written by masks_finish
+    split_detect(A, X, S, L, X.go && !X.direct, spLtot, spPosC, lane);
 #ifdef DH_LR_TIMING
     if (lane == 0) {   // phase times in units of 10 us (wall clock 100 MHz): orientation | sparse | masks | detect
       const unsigned long long tq4 = wall_clock64();
@@ -1074,7 +1082,8 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
 #ifdef DH_LR_TIMING
   td3 = wall_clock64();
 #endif
-  split_detect(A, X, S, L, go, Ltot, posC, lane);
+  if (go && X.direct && lane == 0) X.out->ok = 1;   // longNeedle() returned true
+  split_detect(A, X, S, L, go && !X.direct, Ltot, posC, lane);
   if (!TEAM && defer_slot >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __threadfence();

@@ -72,7 +72,7 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
   X.svS = J.sv_start;
   X.svE = J.sv_end;
   X.sBeg = X.sEnd = X.eBeg = X.eEnd = 0;
-  X.direct = false;
+  X.direct = (A.ref_base != nullptr);   // dellyhip_split_align beyond the short-read shapes: svRefStr given, splitAlign only (round 6)
   X.consLeft = X.refLeft = X.refRight = X.consRight = 0;
   StrPtr S{ws, ws + R.off_rcons, ws + R.off_ref, ws + R.off_rref};
   int32_t* bnd = reinterpret_cast<int32_t*>(ws + R.off_bnd);
@@ -99,10 +99,17 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
       if (A.cons_base != A.out_blob) X.ob[i] = ch;   // (MSA modes: the consensus already lives in the slot)
     }
   }
-  if (go && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
+  if (go && !X.direct && !(P.reserved & 2) && m < 2 * P.minimum_flank_size + J.ins_len) go = false;     // split.h:647
   Seg seg[3];
   int nseg = 0, n = 0;
-  if (go) {
+  if (go && X.direct) {
+    n = A.ref_len[j];
+    if (n > LR_NMAX || n > R.ncap || n < 3) { status = DELLYHIP_E_LIMIT; go = false; n = 0; }
+    else {
+      const uint8_t* rg = A.ref_base + A.ref_off[j];
+      for (int i = lane; i < n; i += WAVE) S.ref[i] = rg[i];
+    }
+  } else if (go) {
     int sBeg, sEnd, eBeg, eEnd;
     (void)window_segments<true>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd);
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
@@ -284,7 +291,8 @@ __device__ void process_lr_ins(const SplitArgs& A, const LrInsArgs& R, int j, Po
     }
   }
   X.go = go;
-  split_detect(A, X, S, L, go, Ltot, Ltot, lane);
+  if (go && X.direct && lane == 0) X.out->ok = 1;   // splitAlign() returned true, rows written by masks_finish
+  split_detect(A, X, S, L, go && !X.direct, Ltot, Ltot, lane);
 }
 
 __global__ __launch_bounds__(WAVE) void lr_ins_kernel(SplitArgs A, LrInsArgs R) {

@@ -135,3 +135,46 @@ def test_edit_distance_nw_pairs_beyond_6144_vs_reference(gpu_ctx, reference):
     want = reference.edit_distance_nw_batch(jobs, blob)
     assert (got == want).all(), (got, want)
     assert (got > 0).all()
+
+
+def _split_pair(rng, m, n, err=0.01, kind="del"):
+    """a consensus of m letters spanning a deletion (or carrying an insertion) against a window of n letters"""
+    ref = synth.ACGT[rng.integers(0, 4, n)]
+    if kind == "del":
+        a = int(rng.integers(50, max(51, n // 2 - m // 2)))
+        b = int(rng.integers(n // 2 + m // 2, max(n // 2 + m // 2 + 1, n - m // 2 - 50)))
+        cons = np.concatenate([ref[a:a + m // 2], ref[b:b + (m - m // 2)]]).copy()
+    else:
+        ins = max(30, m // 4)
+        a = int(rng.integers(10, max(11, n - (m - ins) - 10)))
+        half = (m - ins) // 2
+        cons = np.concatenate([ref[a:a + half], synth.ACGT[rng.integers(0, 4, ins)], ref[a + half:a + (m - ins)]]).copy()
+    for k in rng.integers(0, cons.size, max(1, int(err * cons.size))):
+        cons[k] = synth.ACGT[rng.integers(0, 4)]
+    return cons.tobytes(), ref.tobytes()
+
+
+def test_single_item_long_needle_at_any_shape_vs_reference(gpu_ctx, lr_reference):
+    """dellyhip_long_needle beyond 319 x 2 048 runs the long-read kernels in their direct mode (the reference has no
+    limit, src/needle.h:45-47) -- incl. the 2 kb x 7 kb shape of the long-read loop and an unrelated pair (longNeedle returns false)"""
+    rng = np.random.default_rng(5)
+    for it, (m, n) in enumerate([(2000, 7000), (400, 1500), (300, 2500), (1500, 1800), (3000, 9000)]):
+        cons, ref = _split_pair(rng, m, n)
+        if it == 3:
+            cons = synth.ACGT[rng.integers(0, 4, m)].tobytes()
+        f1, a0, a1 = gpu_ctx.long_needle(cons, ref)
+        f2, b0, b1, _ = lr_reference.long_needle(cons, ref)
+        assert f1 == f2, (m, n)
+        assert a0 == b0 and a1 == b1, (m, n)
+
+
+def test_single_item_split_align_at_any_shape_vs_reference(gpu_ctx, lr_reference):
+    """dellyhip_split_align beyond the short-read shapes (src/split.h:480-482 has no limit): lr_ins_kernel's direct mode"""
+    rng = np.random.default_rng(6)
+    for m, n in [(1800, 2400), (900, 3000), (2500, 2600)]:
+        cons, ref = _split_pair(rng, m, n, kind="ins")
+        f1, a0, a1 = gpu_ctx.split_align(cons, ref)
+        f2, b0, b1 = lr_reference.split_align(cons, ref)[:3]
+        assert f1 == bool(f2), (m, n)
+        if f1:
+            assert a0 == b0 and a1 == b1, (m, n)

@@ -47,10 +47,29 @@ def test_edlib_align_tasks_and_edges_vs_port(gpu_ctx, port):
                     assert got == want, (len(q), len(t), mode, task, got[:4], want[:4])
 
 
-def test_edlib_align_limits(gpu_ctx):
-    from delly_amd.refine import DellyHipError
-    with pytest.raises(DellyHipError):
-        gpu_ctx.edlib_align(b"ACGT", b"A" * 400, 2, 2)   # target beyond the 319-row kernel limit
+def test_edlib_align_beyond_the_insertion_kernel_shapes_vs_reference(gpu_ctx, reference):
+    """dellyhip_edlib_align(HW / SHW / PATH ...) beyond 319 x 2 048 goes through the strip machinery of
+    dellyhip_edlib_align_full instead of failing (the reference's edlibAlign has no limit)"""
+    rng = np.random.default_rng(8)
+    cases = [(b"ACGT", b"A" * 400)]
+    for tn, qn in ((400, 120), (1500, 900), (5000, 1500), (900, 2600)):
+        t = bytes(rng.choice(list(b"ACGT"), tn).astype(np.uint8))
+        a = int(rng.integers(0, max(1, tn - min(qn, tn))))
+        q = bytearray((t[a:a + qn] + bytes(rng.choice(list(b"ACGT"), max(0, qn - (tn - a))).astype(np.uint8)))[:qn])
+        for k in range(len(q)):
+            if rng.random() < 0.05:
+                q[k] = rng.choice(list(b"ACGT"))
+        cases.append((bytes(q), t))
+    for q, t in cases:
+        for mode in (0, 1, 2):
+            for task in (0, 2):
+                want = reference.edlib_align(q, t, mode, task)
+                got = gpu_ctx.edlib_align(q, t, mode, task)
+                assert want is not None
+                if task == 0:
+                    assert got[:3] == want[:3], (len(q), len(t), mode, task, got[:4], want[:4])
+                else:
+                    assert got == want, (len(q), len(t), mode, task, got[:4], want[:4])
 
 
 def test_nw_distance_bitvector_long_strings(gpu_ctx, port):
