@@ -52,3 +52,17 @@ def compare_probes(a, ab, b, bb, label=""):
                 n = int(a[w + "_len" + bp][k])
                 oa, ob = int(a[w + "_off" + bp][k]), int(b[w + "_off" + bp][k])
                 assert bytes(ab[oa:oa + n]) == bytes(bb[ob:ob + n]), (label, int(k), w, bp)
+
+
+def compare_compact(res, blob, ref_res, ref_blob, batch, label=""):
+    """records of a compact-payload run (dellyhip_params.reserved bit 2: allele_len = -(length), no "REF,ALT" bytes) against the
+    reference: every CORE field but the allele bookkeeping, the consensus bytes, and the alleles RE-CUT on the host from the record
+    (dellyhip_recut_alleles) against the reference's own"""
+    from delly_amd import abi, refine
+    import numpy as np
+    compare(res, blob, ref_res, ref_blob, fields=[f for f in CORE if f != "allele_len"], blobs=("cons",), label=label)
+    assert (np.abs(res["allele_len"]) == ref_res["allele_len"]).all(), label
+    recut = refine.recut_alleles(abi.params_sr(compact_alleles=True), batch.junctions, np.ascontiguousarray(res), np.ascontiguousarray(blob), batch.chroms)
+    for i in range(res.shape[0]):
+        got = recut[i] if res["allele_len"][i] < 0 else pyoracle.blob_field(res[i], blob, "allele")
+        assert got == pyoracle.blob_field(ref_res[i], ref_blob, "allele"), "%s junction %d: re-cut alleles differ" % (label, i)
