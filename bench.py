@@ -721,7 +721,7 @@ def main():
     # N > 1: the results travel (to rank 0's host memory, inside every step) with the compact payload -- records + consensus bytes; the
     # "REF,ALT" strings of the deletions are re-cut by the merging process from the record and its own copy of the chromosome
     # (dellyhip_recut_alleles, tests/test_gpu_compact.py): ~0.35 instead of ~1 KB per junction over PCIe / xGMI
-    ctx = refine.Context(params=abi.params_sr(compact_alleles=multi), device=local)
+    ctx = refine.Context(params=abi.params_sr(compact_alleles=multi or bool(os.environ.get("BENCH_COMPACT"))), device=local)
     ctx.set_chromosomes(chroms)
     # N = 1: consecutive steps alternate between TWO contexts (two scratch areas, one resident genome) on the two compute
     # streams the library verified to run side by side, so the tail of one step's launch runs under the head of the next

@@ -282,6 +282,7 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int myers_band = 1;        // banded bit-vector distances, several pairs per wavefront (myers_band.hpp; env DELLYHIP_MYERS_BAND=0: the full passes)
   int lrc_waves = 2;         // resident wavefronts per SIMD of the long-read consensus kernels (lrmsa_kernel / lrwfa_kernel: one junction per wavefront,
                              // 145 / 171 VGPRs = 3 / 2 per SIMD by registers; env DELLYHIP_LRC_WAVES; round 5 launched one per SIMD)
   int lr_waves = 8;          // resident wavefronts of the strip kernel per CU when the sparse passes are on (env DELLYHIP_LR_WAVES)
@@ -386,6 +387,7 @@ struct dellyhip_batch {
   DevBuf<uint8_t> lm_ws;
   dh::LrMsaArgs lm{};
   int lm_items = 0, lm_blocks = 0;
+  int lm_maxlen = 1;         // longest read of a long-read consensus batch
   // dellyhip_batch_fetch: device-side compaction
   DevBuf<uint64_t> blob_off;
   DevBuf<uint8_t> blob_compact;
@@ -1518,6 +1520,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LR_WAVES")) c->lr_waves = std::max(1, std::min(8, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_MYERS_BAND")) c->myers_band = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LRC_WAVES")) c->lrc_waves = std::max(1, std::min(4, atoi(t)));
   if (const char* t = getenv("DELLYHIP_LR_TEAMS")) c->lr_teams = std::max(0, std::min(256, atoi(t)));
   if (const char* t = getenv("DELLYHIP_LR_TEAMS_SERIAL")) c->lr_team_serial = atoi(t) ? 1 : 0;
@@ -1844,6 +1847,7 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
         long_pairs |= nlong >= 2;
       }
       b->lm_hbuf_half = long_pairs ? (((uint64_t)maxlen + 16 + 255) & ~255ull) : 0;
+      b->lm_maxlen = maxlen;
       b->lm_items = pf[n];
       if ((rc = push(b->lm_pair_first, pf.data(), (size_t)n + 1, 0, "H2D pair list")) ||
           (rc = b->lm_edit.reserve(std::max<size_t>((size_t)n * dh::LM_NR * dh::LM_NR, 1))))
@@ -2002,8 +2006,20 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
     if (b->lm_items > 0) {
       dh::PairArgs pa{b->junc.p, b->seq_blob.p, b->seq_off.p, b->lm_pair_first.p, b->n, b->lm_items, dh::LM_NR, b->lm_edit.p,
-                      b->lm_hbuf.p, b->lm_hbuf_half};
-      hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(b->lm_pair_grid), dim3(dh::WAVE), 0, s, pa);
+                      b->lm_hbuf.p, b->lm_hbuf_half, 0, 0, 0};
+      if (c->myers_band) {   // banded passes, several pairs per wavefront (myers_band.hpp): sized from the batch's longest read
+        pa.band_g = dh::mb_group(b->lm_maxlen);
+        pa.band_k = dh::mb_band(b->lm_maxlen);
+        pa.band_wl = dh::mb_lanes(pa.band_k);
+      }
+      int pgrid = b->lm_pair_grid;
+      if (pa.band_g >= 2) {   // groups of band_g pairs per wavefront and step: no more workgroups than stay resident (15 per CU by LDS), whole rounds
+        const int groups = (b->lm_items + pa.band_g - 1) / pa.band_g;
+        pgrid = std::max(1, std::min(groups, c->n_cu * 12));
+        const int rounds = (groups + pgrid - 1) / pgrid;
+        pgrid = (groups + rounds - 1) / rounds;
+      }
+      hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(pgrid), dim3(dh::WAVE), 0, s, pa);
       HIPCHK(hipGetLastError());
     }
     dh::LrMsaArgs M = b->lm;
@@ -2460,7 +2476,10 @@ extern "C" int dellyhip_debug_lrt(uint64_t* out, int n) {
   unsigned long long h[32];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dh::dh_lrt), sizeof h) != hipSuccess) return -1;
   for (int i = 0; i < n && i < 32; ++i) out[i] = h[i];
+  unsigned long long pr[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(pr, HIP_SYMBOL(dh::dh_lrt_pairs), sizeof pr) == hipSuccess && n > 21) { out[20] = pr[0]; out[21] = pr[1]; }
   memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(dh::dh_lrt_pairs), h, sizeof pr);
   return hipMemcpyToSymbol(HIP_SYMBOL(dh::dh_lrt), h, sizeof h) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -3405,7 +3424,7 @@ int dellyhip_msa_edlib(dellyhip_ctx* c, int32_t n_reads, const char* seq_blob, c
   HIPCHK(hipMemsetAsync(dres.p, 0, sizeof(dellyhip_result), c->stream));   // (on the launch stream: see batch_upload_impl)
   HIPCHK(hipMemsetAsync(dedit.p, 0, dh::LM_NR * dh::LM_NR * sizeof(int32_t), c->stream));
   if (pf[1] > 0) {
-    dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p, dhb.p, hhalf};
+    dh::PairArgs pa{dj.p, dblob.p, doff.p, dpf.p, 1, pf[1], dh::LM_NR, dedit.p, dhb.p, hhalf, 0, 0, 0};
     hipLaunchKernelGGL(dh::myers_pairs_kernel, dim3(pf[1]), dim3(dh::WAVE), 0, c->stream, pa);
     HIPCHK(hipGetLastError());
   }

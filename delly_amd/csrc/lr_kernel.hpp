@@ -768,6 +768,9 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
     // (bit-vector distance, myers_kernel.hpp; pattern = the shorter string, the distance is symmetric; beyond the rows
     //  of one pass the pattern is cut into strips whose boundary deltas park in the boundary-row arrays)
     int dF, dR;
+#ifdef DH_LR_TIMING
+    const unsigned long long tmy0 = wall_clock64();
+#endif
     if (min(m, n) <= MYERS_ROWS) {
       if (m <= n) {
         // both orientations in one pass over the window (two patterns in lock-step)
@@ -796,6 +799,9 @@ __device__ __forceinline__ void process_lr(const SplitArgs& A, const LrArgs& R, 
         dR = rfl(myers_nw_big(S.ref, n, S.rcons, m, hb0, hb1, lane));
       }
     }
+#ifdef DH_LR_TIMING
+    if (lane == 0 && (j & 255) == 0) printf("lr junction %d: m %d n %d, orientation passes %llu us (since the junction's start %llu us)\n", j, m, n, (wall_clock64() - tmy0) / 100, (wall_clock64() - tq0) / 100);
+#endif
     // the NW distance of the consensus to its window = the reference letters it skips (|n - m|) + its errors
     err_est = max(0, min(dF, dR) - abs(n - m));
     if (dR < dF) {   // consensus = revc

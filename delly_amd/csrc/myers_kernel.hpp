@@ -527,7 +527,11 @@ __device__ __forceinline__ bool myers_nw_auto_x2(MyersLds<MYERS_NW>& L, const ui
 // step.  L2: a second mask area for pattern B.  Returns false when a pattern holds bytes outside ACGTN (caller falls back).
 template <int NWORDS>
 __device__ __noinline__ bool myers_nw_fast2(MyersLds<NWORDS>& L, uint32_t* eqB, const uint8_t* patA, const uint8_t* patB, int pn,
-                                            const uint8_t* text, int tn, int lane, int& dA, int& dB) {
+                                            const uint8_t* text_, int tn, int lane, int& dA, int& dB) {
+  // (the text lives in the wavefront's HBM workspace for every caller: through a global-space pointer its chunk loads are
+  //  global_load, not flat_load -- a flat load counts against the LDS counter too, and the mask reads of the next sixteen steps
+  //  waited for the chunk's HBM round trip; same remedy as in myers_nw_fast, round 6)
+  const gptr_cu8 text = (gptr_cu8)text_;
   const int row0 = lane * 32 * NWORDS;
   bool foreign = false;
 #pragma unroll
@@ -675,6 +679,14 @@ __global__ __launch_bounds__(WAVE) void myers_single_kernel(const uint8_t* q, in
   if (lane == 0) out[0] = d;
 }
 
+}  // namespace dh
+#include "myers_band.hpp"
+namespace dh {
+#ifdef DH_LR_TIMING
+__device__ unsigned long long dh_lrt_pairs[4];   // profiling builds: [0] pairs through the banded passes, [1] of them not certified (full pass)
+#endif
+
+
 // ---- all pairs of a junction's reads: msaEdlib's distance matrix (src/assemble.h:386-395) ----
 struct PairArgs {
   const dellyhip_junction* junc;
@@ -687,10 +699,12 @@ struct PairArgs {
   int32_t* edit;               // edit[j*nrmax*nrmax + a*nrmax + b]
   int8_t* hbuf;                // per block: 2 x hbuf_half bytes for the strip passes of pairs with both reads > MYERS_ROWS
   uint64_t hbuf_half;          // (0: no such pair in the batch)
+  int32_t band_g, band_k, band_wl;   // banded passes (myers_band.hpp): pairs per wavefront (0: off), band, lanes per pair -- from the batch's longest read
 };
 
 __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
-  __shared__ MyersLds<MYERS_NW> L;
+  MyersBandLds& LB = myers_band_lds();
+  MyersLds<MYERS_NW>& L = LB.full();
   const int lane = threadIdx.x;
   myers_lut_init(L.lut, lane);
   DH_SYNC();
@@ -742,6 +756,46 @@ __global__ __launch_bounds__(WAVE) void myers_pairs_kernel(PairArgs A) {
     else d = myers_nw_auto(L, A.seq_blob + ob, lb, A.seq_blob + oa, la, lane);
     store(I, d);
   };
+  // banded passes, band_g items per wavefront and step (myers_band.hpp); what the band does not certify falls back below
+  if (A.band_g >= 2) {
+    __shared__ Item its[MB_G];
+    const int G = A.band_g;
+    const int ngroups = (A.n_items + G - 1) / G;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int first = grp * G, cnt = min(G, A.n_items - first);
+      MbLds& M = LB.band();
+      for (int q = 0; q < cnt; ++q) {
+        const Item I = describe(first + q);
+        if (lane == 0) {
+          its[q] = I;
+          const bool ab = I.la <= I.lb;   // pattern = the shorter read (the distance is symmetric)
+          M.item[q].pat = A.seq_blob + (ab ? I.oa : I.ob);
+          M.item[q].txt = A.seq_blob + (ab ? I.ob : I.oa);
+          M.item[q].pn = min(I.la, I.lb);
+          M.item[q].tn = max(I.la, I.lb);
+        }
+      }
+      DH_SYNC();
+      myers_band_multi(cnt, A.band_k, A.band_wl, lane);
+      int res[MB_G];
+#pragma unroll
+      for (int q = 0; q < MB_G; ++q) res[q] = (q < cnt) ? M.res[q] : 0;
+      DH_SYNC();
+#pragma unroll
+      for (int q = 0; q < MB_G; ++q) {
+        if (q < cnt) {
+          const Item I = its[q];
+#ifdef DH_LR_TIMING
+          if (lane == 0) { atomicAdd(&dh_lrt_pairs[0], 1ull); if (res[q] < 0) atomicAdd(&dh_lrt_pairs[1], 1ull); }
+#endif
+          if (rfl(res[q]) >= 0) store(I, rfl(res[q]));
+          else single(I);     // (rewrites the tables' bytes: the results are in registers)
+        }
+      }
+      DH_SYNC();
+    }
+    return;
+  }
   // items 2k and 2k + 1 side by side in the two halves of the wavefront when both shorter reads fit 3072 rows
   const int n_pairs_of_items = (A.n_items + 1) >> 1;
   for (int k = blockIdx.x; k < n_pairs_of_items; k += gridDim.x) {

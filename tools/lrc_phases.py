@@ -42,5 +42,7 @@ for row in rows:
     print("%s x %d: step %.1f ms; %d junctions through the consensus kernel, %.2f ms per junction wavefront" % (mode, n, dt * 1e3, nj, out[15] / nj / 1e5))
     for k in sorted(SLOTS):
         print("   %5.2f ms  %4.1f %%  %s" % (out[k] / nj / 1e5, 100.0 * out[k] / max(1, out[15]), SLOTS[k]))
+    if out[20]:
+        print("   banded pair distances: %d pairs, %d not certified by the band (full pass)" % (out[20], out[21]))
     rb.free()
     ctx.close()
