@@ -2049,6 +2049,12 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
         dh::WfaPairArgs WP = b->wfa_pairs;
         WP.junc = b->junc.p; WP.seq_blob = b->seq_blob.p; WP.seq_off = b->seq_off.p;
         HIPCHK(hipMemsetAsync(WP.next, 0, sizeof(uint32_t), s));
+        WP.band_g = WP.band_k = WP.band_wl = 0;
+        if (c->myers_band) {   // banded distances, several pairs per wavefront and pass (myers_band.hpp): sized from the batch's longest read
+          WP.band_g = dh::mb_group(b->lm_maxlen);
+          WP.band_k = dh::mb_band(b->lm_maxlen);
+          WP.band_wl = dh::mb_lanes(WP.band_k);
+        }
         hipLaunchKernelGGL(dh::wfa_pairs_kernel, dim3(b->wfa_pair_grid), dim3(dh::WAVE), 0, s, WP);
         HIPCHK(hipGetLastError());
         W.edit_all = b->wfa_edit.p;

@@ -53,19 +53,31 @@ __device__ __forceinline__ uint32_t wfa_char_to_int(uint8_t c) {   // charToInt,
   return (idx < 32u) ? (uint32_t)((0xc000002e50ull >> (2u * idx)) & 3ull) : 0u;
 }
 __device__ __forceinline__ uint32_t wfa_hash(const uint8_t* s, int p) {
+  // the seven letters in ONE eight-byte load (seven byte loads per position were seven round trips in flight per lane; the blob and
+  // the workspace strings are padded, the eighth byte is ignored)
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef u32x2 __attribute__((aligned(1))) u32x2_u;
+  const u32x2 v = *reinterpret_cast<const u32x2_u*>(s + p);
   uint32_t h = 0;
 #pragma unroll
-  for (int t = 0; t < WFA_KMER; ++t) h = h * 4u + wfa_char_to_int(s[p + t]);
+  for (int t = 0; t < WFA_KMER; ++t) h = h * 4u + wfa_char_to_int((uint8_t)((v[t >> 2] >> ((t & 3) * 8)) & 0xff));
   return h;
 }
 
 // fillKmerTable (len >= 7): tab[h] = 1-based start of the only occurrence, WFA_DUP when repeated, 0 when absent.
 // The table must be all zero on entry; wfa_clear_table undoes exactly what this call touched.
+// (four positions per lane in flight: the compare-and-swap returns the old entry, a round trip per position when done one by one)
 __device__ __forceinline__ void wfa_fill_table(const uint8_t* s, int len, uint32_t* tab, int lane) {
-  for (int p = lane; p <= len - WFA_KMER; p += WAVE) {
-    const uint32_t h = wfa_hash(s, p);
-    const uint32_t old = atomicCAS(&tab[h], 0u, (uint32_t)(p + 1));
-    if (old != 0u) atomicMax(&tab[h], WFA_DUP);
+  const int last = len - WFA_KMER;
+  for (int p0 = lane; p0 <= last; p0 += 4 * WAVE) {
+    uint32_t h[4], old[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h[u] = (p0 + u * WAVE <= last) ? wfa_hash(s, p0 + u * WAVE) : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) old[u] = (p0 + u * WAVE <= last) ? atomicCAS(&tab[h[u]], 0u, (uint32_t)(p0 + u * WAVE + 1)) : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u * WAVE <= last && old[u] != 0u) atomicMax(&tab[h[u]], WFA_DUP);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -84,10 +96,19 @@ __device__ __forceinline__ int wfa_best_diagonal(const uint8_t* sJ, int lenI, in
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // every k-mer that is unique in both reads votes once for its diagonal
-  for (int p = lane; p <= lenJ - WFA_KMER; p += WAVE) {
-    const uint32_t h = wfa_hash(sJ, p);
-    const uint32_t hj = tabJ[h], hi = tabI[h];
-    if (hj == (uint32_t)(p + 1) && hi != 0u && hi != WFA_DUP) atomicAdd(&diag[lenJ + (int)hi - (int)hj], 1u);
+  for (int p0 = lane; p0 <= lenJ - WFA_KMER; p0 += 4 * WAVE) {   // (four positions per lane in flight)
+    uint32_t hj[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = p0 + u * WAVE <= lenJ - WFA_KMER;
+      const uint32_t h = in ? wfa_hash(sJ, p0 + u * WAVE) : 0u;
+      hj[u] = in ? tabJ[h] : 0u;
+      hi[u] = in ? tabI[h] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u * WAVE <= lenJ - WFA_KMER && hj[u] == (uint32_t)(p0 + u * WAVE + 1) && hi[u] != 0u && hi[u] != WFA_DUP)
+        atomicAdd(&diag[lenJ + (int)hi[u] - (int)hj[u]], 1u);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -128,10 +149,12 @@ struct WfaPairArgs {
   uint8_t* ws;                 // per block: k-mer tables of both reads (all zero between items), diagonal votes, strip buffers
   uint64_t ws_stride, off_tabJ, off_diag, off_hb, hb_half;
   uint32_t* next;              // work counter
+  int32_t band_g, band_k, band_wl;   // banded distances (myers_band.hpp): pairs per wavefront and pass (0: off), band, lanes per pair
 };
 
 __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
-  __shared__ MyersLds<MYERS_NW> L;
+  MyersBandLds& LB = myers_band_lds();
+  MyersLds<MYERS_NW>& L = LB.full();
   const int lane = threadIdx.x;
   myers_lut_init(L.lut, lane);
   __syncthreads();
@@ -146,26 +169,33 @@ __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
     if (lane == 0) v = (int)atomicAdd(A.next, 1u);
     return __builtin_amdgcn_readfirstlane(v);
   };
-  for (int item = fetch(); item < n_items; item = fetch()) {
+  // one item: (junction, read pair) -> diagonal seeding -> the trimmed strings whose NW distance is wanted
+  struct Seeded { int j, a, b; const uint8_t* sI; const uint8_t* sJ; uint32_t lI, lJ; bool skip; };
+  auto seed = [&](int item) -> Seeded {
+    Seeded S;
     int lo = 0, hi = A.n_junc;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (A.pair_first[mid] <= item) lo = mid;
       else hi = mid;
     }
-    const int j = lo;
-    const dellyhip_junction J = A.junc[j];
+    S.j = lo;
+    const dellyhip_junction J = A.junc[S.j];
     const int N = J.n_seq;
-    int rem = item - A.pair_first[j], a = 0;
+    int rem = item - A.pair_first[S.j], a = 0;
     while (rem >= N - 1 - a) {
       rem -= N - 1 - a;
       ++a;
     }
-    const int b = a + 1 + rem;
-    const uint64_t oa = A.seq_off[J.seq_first + a], ob = A.seq_off[J.seq_first + b];
-    const int lenI = (int)(A.seq_off[J.seq_first + a + 1] - oa), lenJ = (int)(A.seq_off[J.seq_first + b + 1] - ob);
+    S.a = a;
+    S.b = a + 1 + rem;
+    const uint64_t oa = A.seq_off[J.seq_first + S.a], ob = A.seq_off[J.seq_first + S.b];
+    const int lenI = (int)(A.seq_off[J.seq_first + S.a + 1] - oa), lenJ = (int)(A.seq_off[J.seq_first + S.b + 1] - ob);
+    S.sI = S.sJ = nullptr;
+    S.lI = S.lJ = 0;
     // (a junction with a read outside these limits is flagged by lrwfa_junction and never looks at its scores)
-    if (lenI > A.ncap || lenI > A.acap - 2 || lenI < WFA_KMER + 1 || lenJ > A.ncap || lenJ > A.acap - 2 || lenJ < WFA_KMER + 1) continue;
+    S.skip = lenI > A.ncap || lenI > A.acap - 2 || lenI < WFA_KMER + 1 || lenJ > A.ncap || lenJ > A.acap - 2 || lenJ < WFA_KMER + 1;
+    if (S.skip) return S;
     const uint8_t* sI = A.seq_blob + oa;
     const uint8_t* sJ = A.seq_blob + ob;
     wfa_fill_table(sI, lenI, tabI, lane);
@@ -176,20 +206,73 @@ __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
     uint32_t oI, oJ, seqlen;
     if (bd >= 0) { seqlen = min((uint32_t)lenI - (uint32_t)bd, (uint32_t)lenJ); oI = (uint32_t)bd; oJ = 0; }
     else { seqlen = min((uint32_t)lenJ + (uint32_t)bd, (uint32_t)lenI); oI = 0; oJ = (uint32_t)(-bd); }
-    const uint32_t lI = min(seqlen, (uint32_t)lenI - oI), lJ = min(seqlen, (uint32_t)lenJ - oJ);   // substr clamps
-    int d;
-    if (lI == 0 || lJ == 0) d = (int)max(lI, lJ);
-    else if (lI > (uint32_t)MYERS_ROWS && lJ > (uint32_t)MYERS_ROWS) {
-      d = (A.hb_half && (uint64_t)max(lI, lJ) + 16 <= A.hb_half)
-              ? rfl(myers_nw_big(sI + oI, (int)lI, sJ + oJ, (int)lJ, hb, hb + A.hb_half, lane)) : -1;
-    } else if (lI <= lJ) d = rfl(myers_nw_auto(L, sI + oI, (int)lI, sJ + oJ, (int)lJ, lane));   // (pattern = the shorter string: the distance is symmetric)
-    else d = rfl(myers_nw_auto(L, sJ + oJ, (int)lJ, sI + oI, (int)lI, lane));
-    const int score = (d < 0) ? -1 : (d * 1000) / (int)max(lI, lJ);
+    S.lI = min(seqlen, (uint32_t)lenI - oI);   // substr clamps
+    S.lJ = min(seqlen, (uint32_t)lenJ - oJ);
+    S.sI = sI + oI;
+    S.sJ = sJ + oJ;
+    return S;
+  };
+  auto full_distance = [&](const Seeded& S) -> int {
+    const uint32_t lI = S.lI, lJ = S.lJ;
+    if (lI == 0 || lJ == 0) return (int)max(lI, lJ);
+    if (lI > (uint32_t)MYERS_ROWS && lJ > (uint32_t)MYERS_ROWS)
+      return (A.hb_half && (uint64_t)max(lI, lJ) + 16 <= A.hb_half) ? rfl(myers_nw_big(S.sI, (int)lI, S.sJ, (int)lJ, hb, hb + A.hb_half, lane)) : -1;
+    if (lI <= lJ) return rfl(myers_nw_auto(L, S.sI, (int)lI, S.sJ, (int)lJ, lane));   // (pattern = the shorter string: the distance is symmetric)
+    return rfl(myers_nw_auto(L, S.sJ, (int)lJ, S.sI, (int)lI, lane));
+  };
+  auto finish = [&](const Seeded& S, int d) {
+    const int score = (d < 0) ? -1 : (d * 1000) / (int)max(S.lI, S.lJ);
     if (lane == 0) {
-      int32_t* E = A.edit + (size_t)j * LM_NR * LM_NR;
-      E[a * LM_NR + b] = score;
-      E[b * LM_NR + a] = score;
+      int32_t* E = A.edit + (size_t)S.j * LM_NR * LM_NR;
+      E[S.a * LM_NR + S.b] = score;
+      E[S.b * LM_NR + S.a] = score;
     }
+  };
+  if (A.band_g >= 2) {
+    // band_g items at a time: their seedings one after the other (the k-mer tables are the wavefront's), then ONE banded pass
+    // over all their trimmed strings (myers_band.hpp); what the band does not certify gets the full pass
+    __shared__ Seeded sd[MB_G];
+    const int G = A.band_g;
+    auto fetch_group = [&]() -> int {
+      int v = 0;
+      if (lane == 0) v = (int)atomicAdd(A.next, (uint32_t)G);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int first = fetch_group(); first < n_items; first = fetch_group()) {
+      const int cnt = min(G, n_items - first);
+      MbLds& M = LB.band();
+      for (int q = 0; q < cnt; ++q) {
+        const Seeded S = seed(first + q);
+        if (lane == 0) {
+          sd[q] = S;
+          const bool ij = S.lI <= S.lJ;
+          M.item[q].pat = ij ? S.sI : S.sJ;
+          M.item[q].txt = ij ? S.sJ : S.sI;
+          M.item[q].pn = S.skip ? 0 : (int)min(S.lI, S.lJ);     // (0 rows: not a banded item)
+          M.item[q].tn = S.skip ? 0 : (int)max(S.lI, S.lJ);
+        }
+      }
+      __syncthreads();
+      myers_band_multi(cnt, A.band_k, A.band_wl, lane);
+      int res[MB_G];
+#pragma unroll
+      for (int q = 0; q < MB_G; ++q) res[q] = (q < cnt) ? M.res[q] : 0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MB_G; ++q) {
+        if (q < cnt) {
+          const Seeded S = sd[q];
+          if (!S.skip) finish(S, (rfl(res[q]) >= 0) ? rfl(res[q]) : full_distance(S));   // (the full pass rewrites the tables' bytes: the results are in registers)
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  for (int item = fetch(); item < n_items; item = fetch()) {
+    const Seeded S = seed(item);
+    if (S.skip) continue;
+    finish(S, full_distance(S));
   }
 }
 
