@@ -427,13 +427,13 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         res, _ = rb.fetch()
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
                      "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum()), "steps": row_steps}
-        if b.with_msa == 1:   # short-read msa(): how many junctions left the score-table kernel
+        if b.with_msa == 1:   # short-read msa(): how many junctions left the score-table kernel (CHANGELOG.md 4)
             try:
                 ms = rb.msa_stats()
                 out[name].update({"msa_deferred_junctions": ms[0], "msa_second_instance_junctions": ms[1], "msa_wavefronts_per_junction": ms[2]})
             except Exception:
                 pass
-        if lr:   # the dense strips of junctions the sparse passes give up on run on teams of wavefronts
+        if lr:   # the dense strips of junctions the sparse passes give up on run on teams of wavefronts (CHANGELOG.md 3.7)
             try:
                 ts = rb.lr_team_stats()
                 out[name]["lr_teams"], out[name]["lr_team_junctions"] = ts[0], ts[1]
@@ -771,7 +771,7 @@ def main():
         # every rank downloads the results of the previous step -- compacted on the device, inside the step, while the kernels of
         # the current step run -- into a POSIX shared-memory segment it owns and has pinned (dellyhip_host_register); rank 0, which
         # would run mergeSort / write the VCF, maps every rank's segment and reads the records in place.  Every rank uses its OWN
-        # PCIe link and no collective carries results (the gather funnels all of them through rank 0's link).
+        # PCIe link and no collective carries results (CHANGELOG.md 5: the gather funnels all of them through rank 0's link).
         from delly_amd import shmreturn
         tag = "%s_%d" % (os.environ.get("MASTER_PORT", "0"), world)
         cap_n, cap_b = n + 64, n * 1400 + (1 << 20)

@@ -581,7 +581,7 @@ int ensure_lr_aux(dellyhip_ctx* c, dellyhip_batch* b) {
   if (!b->lr_join) HIPCHK(hipEventCreateWithFlags(&b->lr_join, hipEventDisableTiming));
   if (c->lr_aux) return 0;
   // ONE auxiliary stream per device and process, found by the first context that needs one: the slots of a dellyhip_stream are
-  // contexts of their own, and every stream a process creates competes for the few hardware queues
+  // contexts of their own, and every stream a process creates competes for the few hardware queues (CHANGELOG.md 1b)
   static std::mutex aux_mu;
   static std::map<int, hipStream_t> aux_of_device;
   std::lock_guard<std::mutex> aux_guard(aux_mu);

@@ -60,7 +60,7 @@ struct LrArgs {
 #ifndef DH_LR_TEAM_W
 #define DH_LR_TEAM_W 4
 #endif
-constexpr int LR_TEAM_W = DH_LR_TEAM_W;   // wavefronts of a team (2 / 6 / 8 measured: DESIGN.md 3.7)
+constexpr int LR_TEAM_W = DH_LR_TEAM_W;   // wavefronts of a team (2 / 6 / 8 measured: CHANGELOG.md 3.7)
 enum { LRT_COUNT = 0, LRT_TAKEN = 1, LRT_SPARE = 2, LRT_ERROR = 3, LRT_LIST = 4 };
 #ifdef DH_LR_TEAM_DEBUG
 constexpr int LRT_DBG_INTS = 8 * 4096 + 8;   // time-line marks behind the list (8 ints per team) + lr_kernel's start

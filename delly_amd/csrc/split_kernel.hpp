@@ -11,7 +11,7 @@
 //
 // DP domain: V'[s][c] = score[s][c] + s.  With match +1 / mismatch -1 / gap -1
 // this turns the vertical move into a plain copy, the diagonal into +2 / +0 and
-// makes column 0 identically 0 ("split kernel").
+// makes column 0 identically 0 (see CHANGELOG.md 3.1, "DP formulation").
 //
 // Pass structure per junction
 //   R-pass : reverse-complement DP (rev of needle.h:74-81).  Emits, per cell, a

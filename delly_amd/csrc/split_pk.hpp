@@ -14,7 +14,7 @@
 // Junction B may have a shorter reference (nB <= nA): in the R-pass its columns beyond nB are
 // all-zero one-hot codes (they match nothing and only extend the code stack), in the M-pass it
 // starts nA-nB columns late; in the V' domain a never-matching column reproduces column 0, so
-// B's state is untouched until its first real column (derivation in DESIGN.md 3.4).
+// B's state is untouched until its first real column (derivation in CHANGELOG.md 3.4).
 #pragma once
 #include "split_main.hpp"
 

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
 // split_sparse_kernel stops at a 254 bp consensus (rows in a byte) and 1 280 window letters.  A consensus of 20 reads over an
 // insertion-free junction is 200-320 bp, mixed SV types have windows up to 4 |consensus|: in BASELINE's "all SV types" batch one
 // junction in seven fell to the packed dense kernels, and a HANDFUL of junctions there costs the step the ~1 ms a dense
-// wavefront takes (a latency chain: DESIGN.md 0).  This kernel runs the general form of the sparse longNeedle -- int16 rows,
+// wavefront takes (a latency chain: CHANGELOG.md 0).  This kernel runs the general form of the sparse longNeedle -- int16 rows,
 // tiles of 960 diagonals with a halo, tables in the wavefront's HBM workspace: what the strip kernel of lr_kernel.hpp runs,
 // with the four strings in LDS -- on every shape the dense kernels take (consensus <= 319, window <= 2 048), one junction
 // per wavefront, and what it does not resolve within 32 levels still goes to the dense kernels.

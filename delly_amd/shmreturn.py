@@ -2,7 +2,7 @@
 bytes over its OWN PCIe link into a POSIX shared-memory segment; the process that merges the junctions and writes the VCF
 (`mergeSort` + `vcfOutput`, src/delly.h:232-302, rank 0 here) maps every rank's segment and reads them in place.
 
-Why ("the root funnel"): at ~1 KB of results per junction and tens of millions of junctions per second and
+Why (CHANGELOG.md 5, "the root funnel"): at ~1 KB of results per junction and tens of millions of junctions per second and
 GPU, a gather to one rank pushes every rank's bytes through that rank's single PCIe link; the links of the other GPUs idle.
 
 Segment layout (little endian):

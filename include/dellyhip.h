@@ -177,7 +177,7 @@ int dellyhip_host_unregister(dellyhip_ctx* ctx, void* p);
  * while the process lives, so the footprint is the high-water mark of what was alive at once (parked blocks are capped
  * at half of the device's memory -- DELLYHIP_POOL_LIMIT_MB overrides -- beyond which the oldest go back to the runtime).  (hipMalloc / hipFree
  * synchronise the device, and allocations made after earlier ones were freed were measured to download at a fraction
- * of the PCIe rate: DESIGN.md 1b.)  dellyhip_trim_memory waits for the device, returns every parked block of ctx's
+ * of the PCIe rate: CHANGELOG.md 1b.)  dellyhip_trim_memory waits for the device, returns every parked block of ctx's
  * device to the runtime and reports the bytes released. */
 uint64_t dellyhip_trim_memory(dellyhip_ctx* ctx);
 
@@ -315,7 +315,7 @@ int dellyhip_batch_dp_kernel_ms(dellyhip_ctx* ctx, dellyhip_batch* b, double* ms
  * kernel is off or the run had no short-read junctions.  The sparse kernel's cost grows with a junction's deficit, the dense kernels' does
  * not (like the reference, src/needle.h:64-115): this is the number that says which regime a batch ran in. */
 int dellyhip_batch_sparse_left(dellyhip_ctx* ctx, dellyhip_batch* b, int32_t* left);
-/* Long-read batches: the dense strip fallback of the strip kernel runs on teams of wavefronts beside it.
+/* Long-read batches: the dense strip fallback of the strip kernel runs on teams of wavefronts beside it (CHANGELOG.md 3.7).
  * out[0] = teams launched for this batch (0: none -- DELLYHIP_LR_TEAMS=0, or no long-read junction), out[1] = junctions of
  * the last run the teams swept, out[2] = claims the teams made on the list (>= out[0]: every team ends with one that finds nothing), out[3] = 1 if a team gave up waiting
  * (the junction it was on carries status DELLYHIP_E_RUNTIME; since round 5 dellyhip_batch_sync -- and with it fetch, the stream

@@ -137,7 +137,7 @@ def _refine_with_teams(b, teams, monkeypatch, serial=False):
 
 
 def test_dense_strips_on_teams_vs_reference(monkeypatch, reference):
-    """lr_dense_team_kernel: junctions whose consensus does not align go to teams of four wavefronts that sweep
+    """lr_dense_team_kernel (CHANGELOG.md 3.7): junctions whose consensus does not align go to teams of four wavefronts that sweep
     the strips of the dense longNeedle pipelined.  Same records as the reference, and the teams really took them."""
     b = _unalignable(synth.make_batch(12, mode="lr", sub_rate=0.01, first=300), every=2)
     gr, gb, stats = _refine_with_teams(b, 64, monkeypatch)

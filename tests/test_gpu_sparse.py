@@ -1,4 +1,4 @@
-"""-m gpu: the sparse longNeedle kernels against the dense kernels they stand in front of and against
+"""-m gpu: the sparse longNeedle kernels (CHANGELOG.md 3.0 / 3.7) against the dense kernels they stand in front of and against
 the oracle: same records and bytes whether a junction is finished by split_sparse_kernel, left to the packed dense
 kernels (letters outside ACGTN, lower case, deficits beyond the level budget, windows beyond the tile) or forced
 through the dense path (DELLYHIP_SR_SPARSE=0 / DELLYHIP_SPARSE=0), with and without alignment rows (the two mask

@@ -1,6 +1,6 @@
 """The collective steps of dellyhip_gather_results on the shared-memory transport, WITHOUT a GPU: two (three) real
 processes load libdellyhip.so, meet in a hostlink communicator (dellyhip_comm_create_hostlink, ctx = NULL) and run the
-size exchange and the root-ready exchange -- the abort protocol of DESIGN.md 5: a rank that reports a failure (count = ~0
+size exchange and the root-ready exchange -- the abort protocol of CHANGELOG.md 5: a rank that reports a failure (count = ~0
 on the wire) must make EVERY rank leave with an error before anybody posts a payload, and nobody may hang."""
 import multiprocessing as mp
 import os

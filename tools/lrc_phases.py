@@ -1,4 +1,4 @@
-"""Where the long-read consensus kernels spend a junction's time: a -DDH_LR_TIMING build of the library
+"""Where the long-read consensus kernels spend a junction's time (CHANGELOG.md 3.8 / 3.9): a -DDH_LR_TIMING build of the library
 (tools/bin/libdellyhip_lrt.so, built on the CPU box: `python tools/lrc_phases.py --build`) sums per-phase wall-clock ticks over a
 launch (lrmsa_kernel.hpp: dh_lrt).  On the GPU box: DELLYHIP_LIB=tools/bin/libdellyhip_lrt.so python tools/lrc_phases.py [rows]"""
 import ctypes as C

@@ -60,7 +60,7 @@ micro)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/lds_rate.hip -o /tmp/lds_rate.bin 2>/dev/null && /tmp/lds_rate.bin > $O/lds_rate.txt 2>&1
   ;;
 stream)
-  # the pipelined host-buffer path by depth
+  # the pipelined host-buffer path by depth (CHANGELOG.md 1b)
   python tools/bench_stream.py > $O/bench_stream_u_c2.json 2> $O/bench_stream.err
   bash tools/stream_matrix.sh > $O/stream_matrix.txt 2>&1
   ;;
