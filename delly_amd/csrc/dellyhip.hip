@@ -282,6 +282,7 @@ struct dellyhip_ctx {
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
+  int wfa_lds_seed = 1;      // msaWfa's diagonal seeding in its own kernel with the k-mer table in LDS (wfa_seed_kernel; env DELLYHIP_WFA_LDS_SEED=0: inside wfa_pairs_kernel, tables in HBM)
   int myers_band = 1;        // banded bit-vector distances, several pairs per wavefront (myers_band.hpp; env DELLYHIP_MYERS_BAND=0: the full passes)
   int lrc_waves = 2;         // resident wavefronts per SIMD of the long-read consensus kernels (lrmsa_kernel / lrwfa_kernel: one junction per wavefront,
                              // 145 / 171 VGPRs = 3 / 2 per SIMD by registers; env DELLYHIP_LRC_WAVES; round 5 launched one per SIMD)
@@ -370,7 +371,8 @@ struct dellyhip_batch {
   DevBuf<int32_t> wfa_list;
   DevBuf<uint8_t> wfa_ws;
   // the pairwise stage of msaWfa as its own kernel (wfa_pairs_kernel): one (junction, read pair) per wavefront
-  DevBuf<int32_t> wfa_pair_first, wfa_edit;
+  DevBuf<int32_t> wfa_pair_first, wfa_edit, wfa_seeds;
+  int wfa_max_rows = 0;
   DevBuf<uint8_t> wfa_pair_ws;
   DevBuf<uint32_t> wfa_next;
   dh::WfaPairArgs wfa_pairs{};
@@ -1520,6 +1522,7 @@ static int create_ctx(const dellyhip_params* params, int device, dellyhip_ctx** 
   if (const char* t = getenv("DELLYHIP_SPARSE")) c->use_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_SR_SPARSE")) c->sr_sparse = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LR_WAVES")) c->lr_waves = std::max(1, std::min(8, atoi(t)));
+  if (const char* t = getenv("DELLYHIP_WFA_LDS_SEED")) c->wfa_lds_seed = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_MYERS_BAND")) c->myers_band = atoi(t) != 0;
   if (const char* t = getenv("DELLYHIP_LRC_WAVES")) c->lrc_waves = std::max(1, std::min(4, atoi(t)));
   if (const char* t = getenv("DELLYHIP_LR_TEAMS")) c->lr_teams = std::max(0, std::min(256, atoi(t)));
@@ -1645,7 +1648,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->lr_aux_used && c && c->lr_aux) (void)hipStreamSynchronize(c->lr_aux);
   b->junc.release(); b->seq_blob.release(); b->seq_off.release(); b->cons_off.release();
   b->cons_len.release(); b->res.release(); b->out_blob.release(); b->work.release();
-  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->msa_order.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
+  b->ref_blob.release(); b->ref_off.release(); b->ref_len.release(); b->msa_ws.release(); b->msa_big_ws.release(); b->lm_hbuf.release(); b->lr_ws.release(); b->blob_off.release(); b->blob_compact.release(); b->lm_edit.release(); b->lm_pair_first.release(); b->lm_ws.release(); b->lri_ws.release(); b->wfa_list.release(); b->wfa_ws.release(); b->early_list.release(); b->msa_order.release(); b->wfa_pair_first.release(); b->wfa_edit.release(); b->wfa_seeds.release(); b->wfa_pair_ws.release(); b->wfa_next.release(); b->small_inv.release(); b->lr_team_state.release();
   if (b->own_pin_len) PinPool::get().give(b->own_pin_len, b->own_pin_bytes);
   b->own_pin_len = nullptr;
   if (b->fetch_status) PinPool::get().give(b->fetch_status, b->fetch_status_bytes);
@@ -1901,6 +1904,11 @@ static int batch_upload_impl(dellyhip_ctx* c, int32_t n, const dellyhip_junction
           if (e != hipSuccess) return bail(fail(DELLYHIP_E_RUNTIME, "memset wfa pair workspace", e));
           WP.pair_first = b->wfa_pair_first.p;
           WP.edit = b->wfa_edit.p;
+          // the diagonal seeding with its tables in LDS (wfa_seed_kernel): four ints per pair for the distance kernel
+          b->wfa_max_rows = 0;
+          for (int i = 0; i < n; ++i)
+            if (junc[i].svt == 4 && junc[i].n_seq >= 2 && junc[i].n_seq <= dh::LM_NR) b->wfa_max_rows = std::max(b->wfa_max_rows, junc[i].n_seq - 1);
+          if (c->wfa_lds_seed && (rc = b->wfa_seeds.reserve((size_t)4 * b->wfa_items))) return bail(rc);
           WP.ws = b->wfa_pair_ws.p;
           WP.next = b->wfa_next.p;
           WP.n_junc = n;
@@ -2049,6 +2057,15 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
         dh::WfaPairArgs WP = b->wfa_pairs;
         WP.junc = b->junc.p; WP.seq_blob = b->seq_blob.p; WP.seq_off = b->seq_off.p;
         HIPCHK(hipMemsetAsync(WP.next, 0, sizeof(uint32_t), s));
+        WP.seeds = nullptr;
+        if (c->wfa_lds_seed && b->wfa_seeds.p && b->wfa_max_rows > 0) {
+          HIPCHK(hipMemsetAsync(WP.next, 0, sizeof(uint32_t), s));
+          dh::WfaSeedArgs SA{b->junc.p, b->seq_blob.p, b->seq_off.p, WP.pair_first, b->wfa_list.p, b->wfa_count, b->wfa_max_rows, WP.ncap, WP.acap, b->wfa_seeds.p, WP.next};
+          hipLaunchKernelGGL(dh::wfa_seed_kernel, dim3(std::max(1, std::min(b->wfa_count * b->wfa_max_rows, c->n_cu * 2))), dim3(dh::WAVE), 0, s, SA);
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipMemsetAsync(WP.next, 0, sizeof(uint32_t), s));
+          WP.seeds = b->wfa_seeds.p;
+        }
         WP.band_g = WP.band_k = WP.band_wl = 0;
         if (c->myers_band) {   // banded distances, several pairs per wavefront and pass (myers_band.hpp): sized from the batch's longest read
           WP.band_g = dh::mb_group(b->lm_maxlen);

@@ -150,7 +150,162 @@ struct WfaPairArgs {
   uint64_t ws_stride, off_tabJ, off_diag, off_hb, hb_half;
   uint32_t* next;              // work counter
   int32_t band_g, band_k, band_wl;   // banded distances (myers_band.hpp): pairs per wavefront and pass (0: off), band, lanes per pair
+  const int32_t* seeds;        // per item (oI, oJ, lI, lJ) from wfa_seed_kernel (nullptr: seed here); oI = WFS_UNSEEDED: seed here
 };
+constexpr int WFS_UNSEEDED = -2;
+
+// ---- the diagonal seeding of msaWfa's pairwise stage with its tables in LDS (round 6) ----------------------------------------
+// wfa_pairs_kernel's own seeding keeps two 64 Ki-entry tables per wavefront in HBM and fills / probes / clears them with random
+// four-byte accesses: 29 ms per 512 junctions, bound by HBM's random-access rate (2 GB of tables for 4 096 wavefronts).  But a
+// 7-mer hash is below 4^7 = 16 384, and positions fit 16 bits: ONE table of 16 384 words holds read I's entry in the low half
+// and read J's in the high half (0 absent, 0xFFFF repeated, else the 1-based start), 64 KB of LDS; the diagonal histogram
+// (votes <= read length) is 16-bit counters, two per word.  One wavefront takes a ROW of a junction's pair matrix -- read a
+// against every b > a -- so read a's entries are written once per row, not once per pair.  Results: the trimmed strings of
+// every pair, (oI, oJ, lI, lJ), for the distance kernel.  Reads whose histogram does not fit are left to the old path.
+constexpr int WFS_TAB = 16384;              // 4^DELLY_KMER
+constexpr int WFS_DIAG = 8192;              // histogram entries (lenI + lenJ + 64 must fit; 64 + 16 KB of LDS: two wavefronts per CU)
+struct WfaSeedArgs {
+  const dellyhip_junction* junc;
+  const uint8_t* seq_blob;
+  const uint64_t* seq_off;
+  const int32_t* pair_first;   // as WfaPairArgs
+  const int32_t* list;         // the insertion junctions
+  int32_t n_list, max_rows;    // rows per junction at most (longest read list - 1)
+  int32_t ncap, acap;
+  int32_t* seeds;              // 4 ints per item
+  uint32_t* next;              // work counter
+};
+
+// f(h, p) for every 7-mer start p of s[0 .. len) with len <= 4096 + 6: lane L takes the 64 consecutive starts [64 L, 64 L + 64) -- its
+// 80 bytes arrive in five 16-byte loads that are all in flight together (a load per position was a round trip per loop iteration),
+// and the hash rolls from one start to the next (two bits in, two bits out) instead of being rebuilt from seven letters
+template <typename F>
+__device__ __forceinline__ void wfs_for_each_kmer(const uint8_t* s_, int len, int lane, F f) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+  const gptr_cu8 s = (gptr_cu8)s_;
+  const int p0 = lane * 64;
+  const int last = len - WFA_KMER;
+  if (p0 > last) return;
+  u32x4 v[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) v[q] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_u*>(s + p0 + 16 * q);   // (padded strings)
+  auto code = [&](int q) -> uint32_t { return wfa_char_to_int((uint8_t)((v[q >> 4][(q >> 2) & 3] >> ((q & 3) * 8)) & 0xff)); };
+  uint32_t h = 0;
+#pragma unroll
+  for (int t = 0; t < WFA_KMER - 1; ++t) h = h * 4u + code(t);
+#pragma unroll
+  for (int q = 0; q < 64; ++q) {
+    h = (h * 4u + code(q + WFA_KMER - 1)) & (uint32_t)(WFS_TAB - 1);
+    if (p0 + q <= last) f(h, p0 + q);
+  }
+}
+
+__global__ __launch_bounds__(WAVE) void wfa_seed_kernel(WfaSeedArgs A) {
+  __shared__ uint32_t tab[WFS_TAB];
+  __shared__ uint32_t diag[WFS_DIAG / 2];
+  const int lane = threadIdx.x;
+  for (int q = lane; q < WFS_TAB; q += WAVE) tab[q] = 0;
+  __syncthreads();
+  const int n_rows = __builtin_amdgcn_readfirstlane(A.n_list * A.max_rows);
+  auto fetch = [&]() -> int {
+    int v = 0;
+    if (lane == 0) v = (int)atomicAdd(A.next, 1u);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  auto cnt = [&](int idx) -> uint32_t { return (diag[idx >> 1] >> (16 * (idx & 1))) & 0xffffu; };
+  for (int row = fetch(); row < n_rows; row = fetch()) {
+    // rows in a-major order: the long rows (a = 0: every other read of the junction) are handed out first
+    const int a = row / A.n_list, j = A.list[row - a * A.n_list];
+    const dellyhip_junction J = A.junc[j];
+    const int N = J.n_seq;
+    if (N < 2 || N > LM_NR || a > N - 2) continue;
+    const uint64_t oa = A.seq_off[J.seq_first + a];
+    const int lenI = (int)(A.seq_off[J.seq_first + a + 1] - oa);
+    const uint8_t* sI = A.seq_blob + oa;
+    const bool okI = !(lenI > A.ncap || lenI > A.acap - 2 || lenI < WFA_KMER + 1);
+    int32_t* out = A.seeds + 4 * ((size_t)A.pair_first[j] + (size_t)a * (N - 1) - (size_t)a * (a - 1) / 2);   // the row's first item
+    const bool rowfits = lenI <= 4096;
+    if (okI && rowfits) {   // fillKmerTable, low halves (the high halves are zero between pairs)
+      wfs_for_each_kmer(sI, lenI, lane, [&](uint32_t h, int p) {
+        const uint32_t old = atomicCAS(&tab[h], 0u, (uint32_t)(p + 1));
+        if (old != 0u) atomicOr(&tab[h], 0xffffu);
+      });
+    }
+    __syncthreads();
+    for (int b = a + 1; b < N; ++b, out += 4) {
+      const uint64_t ob = A.seq_off[J.seq_first + b];
+      const int lenJ = (int)(A.seq_off[J.seq_first + b + 1] - ob);
+      const uint8_t* sJ = A.seq_blob + ob;
+      const bool okJ = !(lenJ > A.ncap || lenJ > A.acap - 2 || lenJ < WFA_KMER + 1);
+      if (!okI || !okJ) {   // (wfa_pairs_kernel skips the pair on the same test)
+        if (lane == 0) { out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; }
+        continue;
+      }
+      const int dn = lenI + lenJ;
+      if (dn + 64 > WFS_DIAG || !rowfits || lenJ > 4096) {   // the histogram / a lane's stretch does not fit: seeded by wfa_pairs_kernel
+        if (lane == 0) out[0] = WFS_UNSEEDED;
+        continue;
+      }
+      wfs_for_each_kmer(sJ, lenJ, lane, [&](uint32_t h, int p) {   // read J's entries, high halves
+        const uint32_t old = atomicOr(&tab[h], (uint32_t)(p + 1) << 16);
+        if ((old >> 16) != 0u) atomicOr(&tab[h], 0xffff0000u);
+      });
+      for (int d = lane; d < (dn + 64 + 1) / 2; d += WAVE) diag[d] = 0u;
+      __syncthreads();
+      // bestDiagonal (assemble.h:522-545): every k-mer that is unique in both reads votes once for its diagonal
+      wfs_for_each_kmer(sJ, lenJ, lane, [&](uint32_t h, int p) {
+        const uint32_t w = tab[h];
+        const uint32_t hj = w >> 16, hi = w & 0xffffu;
+        if (hj == (uint32_t)(p + 1) && hi != 0u && hi != 0xffffu) {
+          const int idx = lenJ + (int)hi - (int)hj;
+          atomicAdd(&diag[idx >> 1], 1u << (16 * (idx & 1)));
+        }
+      });
+      __syncthreads();
+      // window of 20 diagonals (:533-544): the first maximum wins (see wfa_best_diagonal)
+      const int window = 20;
+      unsigned long long best = 0;   // (W + 1) << 20 | (0xfffff - d)
+      {   // every lane slides the window over a contiguous stretch of diagonals: two reads per diagonal instead of twenty
+        const int nd = dn - (window - 1);                       // windows end at d = window - 1 .. dn - 1
+        const int per = (max(nd, 0) + WAVE - 1) / WAVE;
+        const int d0 = window - 1 + lane * per, d1 = min(dn, d0 + per);
+        if (d0 < d1) {
+          uint32_t W = 0;
+#pragma unroll
+          for (int x = 0; x < window; ++x) W += cnt(d0 - x);
+          for (int d = d0;; ) {
+            const unsigned long long key = ((unsigned long long)(W + 1u) << 20) | (unsigned long long)(0xfffff - d);
+            best = key > best ? key : best;
+            if (++d >= d1) break;
+            W += cnt(d) - cnt(d - window);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const int lo = __shfl_xor((int)(best & 0xffffffffull), o), hi = __shfl_xor((int)(best >> 32), o);
+        const unsigned long long w = ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+        best = w > best ? w : best;
+      }
+      int bestDiag = window / 2;   // also the answer when there are fewer than 20 diagonals
+      if (best != 0ull) {
+        const int dstar = 0xfffff - (int)(best & 0xfffffull);
+        bestDiag = (dstar == window - 1) ? window / 2 : dstar - window / 2;
+      }
+      const int bd = rfl(bestDiag) - lenJ;
+      wfs_for_each_kmer(sJ, lenJ, lane, [&](uint32_t h, int) { atomicAnd(&tab[h], 0xffffu); });   // read J leaves the table
+      uint32_t oI, oJ, seqlen;
+      if (bd >= 0) { seqlen = min((uint32_t)lenI - (uint32_t)bd, (uint32_t)lenJ); oI = (uint32_t)bd; oJ = 0; }
+      else { seqlen = min((uint32_t)lenJ + (uint32_t)bd, (uint32_t)lenI); oI = 0; oJ = (uint32_t)(-bd); }
+      const uint32_t lI = min(seqlen, (uint32_t)lenI - oI), lJ = min(seqlen, (uint32_t)lenJ - oJ);   // substr clamps
+      if (lane == 0) { out[0] = (int32_t)oI; out[1] = (int32_t)oJ; out[2] = (int32_t)lI; out[3] = (int32_t)lJ; }
+      __syncthreads();
+    }
+    if (okI && rowfits) wfs_for_each_kmer(sI, lenI, lane, [&](uint32_t h, int) { tab[h] = 0u; });
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
   MyersBandLds& LB = myers_band_lds();
@@ -198,6 +353,17 @@ __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
     if (S.skip) return S;
     const uint8_t* sI = A.seq_blob + oa;
     const uint8_t* sJ = A.seq_blob + ob;
+    if (A.seeds) {   // wfa_seed_kernel has done the diagonal seeding with its tables in LDS
+      const int32_t* sd4 = A.seeds + 4 * (size_t)item;
+      const int s0 = rfl(sd4[0]);
+      if (s0 != WFS_UNSEEDED) {
+        S.lI = (uint32_t)rfl(sd4[2]);
+        S.lJ = (uint32_t)rfl(sd4[3]);
+        S.sI = sI + s0;
+        S.sJ = sJ + rfl(sd4[1]);
+        return S;
+      }
+    }
     wfa_fill_table(sI, lenI, tabI, lane);
     wfa_fill_table(sJ, lenJ, tabJ, lane);
     const int bd = wfa_best_diagonal(sJ, lenI, lenJ, tabI, tabJ, diag, lane);
