@@ -774,6 +774,12 @@ int run_split_dense(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool dire
 // the host can route a junction to the short-read or the long-read kernel and size workspaces
 int host_window_len(const dellyhip_params& P, const dellyhip_junction& J, int m, const std::vector<int64_t>& chr_len) {
   auto clampz = [](long v) { return (int)std::max<long>(0, v); };
+  // alignConsensus returns false before it builds a window when the consensus is shorter than both flanks + the insertion
+  // (src/split.h:647).  For an insertion with |consensus| < insLen the window formula below wraps (size_t arithmetic, :651) to the
+  // whole chromosome: such a junction -- consensus beyond the short-read kernels, "window" beyond the long-read ones -- used to be
+  // routed to the short-read insertion kernel and came back as E_LIMIT where the reference says false (found by
+  // tests/test_gpu_band.py, round 6; rounds 2-5 had it).  No window: the long-read insertion kernel takes it and exits early.
+  if (J.svt == 4 && m > dh::MMAX && m < 2 * P.minimum_flank_size + J.ins_len) return 0;
   const int svS = J.sv_start, svE = J.sv_end;
   const int len1 = (int)(uint32_t)chr_len[J.chr], len2 = (int)(uint32_t)chr_len[J.chr2];
   if (J.svt == 4) {

@@ -442,6 +442,11 @@ __global__ __launch_bounds__(WAVE) void wfa_pairs_kernel(WfaPairArgs A) {
   }
 }
 
+#ifdef DH_LR_TIMING
+#define LRW_LIMIT(site) ((lane == 0 ? printf("lrwfa junction %d: limit at line %d\n", j, site) : 0), DELLYHIP_E_LIMIT)
+#else
+#define LRW_LIMIT(site) DELLYHIP_E_LIMIT
+#endif
 // msaWfa for one junction
 __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* ws, int lane) {
   const dellyhip_junction J = A.junc[j];
@@ -473,7 +478,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
   const int ops_cap = 2 * max(acap, A.ncap) + 32;
   const uint8_t* blob = A.seq_blob;
   if (N >= 1) {
-    if (N > LM_NR) status = DELLYHIP_E_LIMIT;
+    if (N > LM_NR) status = LRW_LIMIT(476);
     if (!status) {
       for (int r = lane; r < N; r += WAVE) {
         const uint64_t a = A.seq_off[J.seq_first + r], b = A.seq_off[J.seq_first + r + 1];
@@ -482,7 +487,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       }
       __syncthreads();
       for (int r = 0; r < N; ++r)
-        if (L.rlen[r] > A.ncap || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = DELLYHIP_E_LIMIT;
+        if (L.rlen[r] > A.ncap || L.rlen[r] > acap - 2 || L.rlen[r] < WFA_KMER + 1) status = LRW_LIMIT(485);
     }
     // reads made of A, C, G, T only (the usual case): their plain-equality alignments may use the compare-free
     // bit-vector passes (lm_pure_acgt); the superstring is pure while every read merged into it is
@@ -500,7 +505,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int s0 = J.sv_start, s1 = min(seqlen, J.sv_start + A.p.min_cons_window);
         pn = max(0, p1 - p0);
         sn = max(0, s1 - s0);
-        if (pn > WFA_PCAP || sn > WFA_PCAP) status = DELLYHIP_E_LIMIT;
+        if (pn > WFA_PCAP || sn > WFA_PCAP) status = LRW_LIMIT(503);
         else {
           for (int k = lane; k < pn; k += WAVE) pre[k] = upc(seq[p0 + k]);
           for (int k = lane; k < sn; k += WAVE) suf[k] = upc(seq[s0 + k]);
@@ -508,7 +513,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
       } else {
         pn = A.prefix_len;
         sn = A.suffix_len;
-        if (pn > WFA_PCAP || sn > WFA_PCAP) status = DELLYHIP_E_LIMIT;
+        if (pn > WFA_PCAP || sn > WFA_PCAP) status = LRW_LIMIT(511);
         else {
           for (int k = lane; k < pn; k += WAVE) pre[k] = A.prefix[k];
           for (int k = lane; k < sn; k += WAVE) suf[k] = A.suffix[k];
@@ -628,7 +633,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         } else {
           const uint8_t* sI = (bd >= 0) ? sup + bd : sup;
           const uint8_t* sJ = (bd >= 0) ? rd : rd + (-bd);
-          if ((int)seqlen > acap - 2 || seqlen == 0) { status = DELLYHIP_E_LIMIT; break; }
+          if ((int)seqlen > acap - 2 || seqlen == 0) { status = LRW_LIMIT(631); break; }
           // edlibAlign(seqI, seqJ, NW, PATH): query = seqI (columns), target = seqJ (rows)
           const bool rd_pure = ((pure_reads >> L.sel[step]) & 1ull) != 0;
           const int pmode = (sup_pure && rd_pure) ? (LM_EQ | LM_EQFAST) : 0;   // (identity among ACGT: same op string)
@@ -640,7 +645,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           LRT_ADD(2, wall_clock64() - lrt_p0);
           LRT_LAP(12);
 #endif
-          if (nops < 0) { status = DELLYHIP_E_LIMIT; break; }
+          if (nops < 0) { status = LRW_LIMIT(643); break; }
           sup_pure = sup_pure && rd_pure;
           // buildSuperstring (:90-133)
           const bool f0 = preI > preJ;
@@ -665,7 +670,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           }
           const bool tailI = postI > postJ;
           const int tlen = tailI ? (int)postI : (int)postJ;
-          if (ob + tlen > acap - 2) { status = DELLYHIP_E_LIMIT; break; }
+          if (ob + tlen > acap - 2) { status = LRW_LIMIT(668); break; }
           for (int k = lane; k < tlen; k += WAVE) sup2[ob + k] = tailI ? sup[ib + k] : rd[jb + k];
           sl = ob + tlen;
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -748,7 +753,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         LRT_ADD(13, wall_clock64() - lrt_p0);
         LRT_LAP(12);
 #endif
-        if (h.nops < 0) { status = DELLYHIP_E_LIMIT; break; }
+        if (h.nops < 0) { status = LRW_LIMIT(751); break; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // convertAlignment(query, align, HW, cigar) (:24-88)
@@ -756,7 +761,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
         const int missingStart = h.startLoc;                       // tIdx = end - #nonINSERT = start - 1
         const int missingEnd = (h.endLoc < acols) ? acols - h.endLoc - 1 : 0;
         const int ncols = missingStart + nops + missingEnd;
-        if (ncols > acap - 2) { status = DELLYHIP_E_LIMIT; break; }
+        if (ncols > acap - 2) { status = LRW_LIMIT(759); break; }
         for (int c = lane; c < missingStart; c += WAVE) {
           for (int r = 0; r < arows; ++r) nxt[(size_t)r * acap + c] = cur[(size_t)r * acap + c];
           nxt[(size_t)arows * acap + c] = '-';
@@ -826,7 +831,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
           const int len = Lc - 2 * trim;
           if (len > 100) { o = trim; Lc = len; }
         }
-        if (Lc > A.out_cons_cap) status = DELLYHIP_E_LIMIT;
+        if (Lc > A.out_cons_cap) status = LRW_LIMIT(829);
         else {
           for (int k = lane; k < Lc; k += WAVE) cons_out[k] = cbuf[o + k];
           cons_len = Lc;
@@ -840,6 +845,7 @@ __device__ void lrwfa_junction(const LrWfaArgs& A, int j, LrMsaLds& L, uint8_t* 
   LRT_ADD(14, 1);
   LRT_ADD(15, wall_clock64() - tw0);
   (void)tw1; (void)tw2;
+  if (lane == 0 && A.n_work <= 64) printf("lrwfa junction %d: N %d status %d cons_len %d rows %d\n", j, N, status, cons_len, rows);
 #endif
   if (lane == 0) {
     out->sr_support = rows;
