@@ -11,8 +11,8 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "bin", "libdellyhip_lrt.so")
 SLOTS = {1: "seeding (k-mer tables, diagonal votes)", 2: "superstring NW paths (whole; parts in 7-9, 12)", 3: "buildSuperstring", 4: "column votes",
          5: "forward location pass", 6: "reverse location pass", 7: "Hirschberg last-row passes", 8: "direction fill of base rectangles",
-         9: "tracebacks + op reversal", 10: "convertAlignment", 11: "final consensus + trimming", 12: "between the phases (split search, set-up)",
-         13: "progressive NW / HW paths (whole; parts in 5-9, 12)"}
+         9: "tracebacks + op reversal", 10: "convertAlignment", 11: "final consensus + trimming",
+         13: "progressive NW / HW paths (whole; parts in 5-9)"}   # (slot 12 only re-arms the lap clock in front of a phase: not a phase)
 
 if "--build" in sys.argv:
     from delly_amd import build
