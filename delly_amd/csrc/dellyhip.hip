@@ -331,6 +331,7 @@ struct dellyhip_batch {
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
   bool sps_all = false;              // every junction of the dense bins is in the sparse list too
+  bool sps_identity = false;         // the sparse list is 0, 1, 2, ...: the kernel is launched without it (one dependent load less per junction)
   // msa() batches: the sparse kernel runs on every non-insertion junction straight behind the MSA kernels (it reads the
   // consensus lengths on the device) while the host routes the batch from the downloaded lengths
   DevBuf<int32_t> early_list;
@@ -558,7 +559,7 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
     a.sps_left = c->counters.p + 31;
     mid_done = true;
   } else if (b->sps_count > 0 && !direct) {   // sparse longNeedle first: the dense kernels below skip what it finishes
-    a.work_list = b->work.p + b->sps_first;
+    a.work_list = b->sps_identity ? nullptr : b->work.p + b->sps_first;
     a.n_work = b->sps_count;
     a.work_counter = c->counters.p + 30;
     a.sps_left = c->counters.p + 31;
@@ -1101,6 +1102,7 @@ int build_bins(dellyhip_batch* b, const dellyhip_params& P, int mode = BINS_ALL,
   work.insert(work.end(), lriv.begin(), lriv.end());
   b->sps_first = (int)work.size();
   b->sps_count = (int)sparse.size();
+  b->sps_identity = !sparse.empty() && sparse.front() == 0 && sparse.back() == (int32_t)sparse.size() - 1;   // (ascending junction indices: then entry i is junction i)
   {
     size_t dense = 0;
     for (auto& v : bins) dense += v.size();
@@ -1436,7 +1438,7 @@ void batch_reset(dellyhip_batch* b) {
   b->out_stride = 0;
   b->out_cons_cap = dh::OUT_CONS_CAP; b->out_allele_cap = dh::OUT_ALLELE_CAP; b->out_aln_cap = dh::OUT_ALN_CAP;
   b->bin_first.clear(); b->bin_count.clear(); b->qbin_first.clear(); b->qbin_count.clear(); b->qbin_pairs.clear();
-  b->ins_first = b->ins_count = 0; b->sps_all = false; b->early_count = 0; b->early_done = false; b->sps_first = b->sps_count = 0; b->spw_first = b->spw_count = 0;
+  b->ins_first = b->ins_count = 0; b->sps_all = false; b->sps_identity = false; b->early_count = 0; b->early_done = false; b->sps_first = b->sps_count = 0; b->spw_first = b->spw_count = 0;
   b->lr_first = b->lr_count = b->lr_blocks = 0; b->lri_first = b->lri_count = b->lri_blocks = 0;
   b->wfa_items = 0; b->wfa_pair_grid = 1; b->wfa_count = b->wfa_blocks = 0; b->small_inv_n = 0;
   b->lm_hbuf_half = 0; b->lm_pair_grid = 1; b->lm_items = b->lm_blocks = 0;

@@ -1008,23 +1008,36 @@ __device__ __forceinline__ bool sps_lists_small(const FRV& frF, const FRV& frR, 
                                                 int rlo, int rloR, SpsSmall& Q, int lane) {
   Q.qF = Q.qR = -1;
   int nF = 0, nR = 0;
-  for (int q0 = 0; q0 < ND; q0 += WAVE) {
-    const int q = q0 + lane;
-    const bool hf = (q < ND) && ((int)lvF[min(q, ND - 1)] - 1 >= rlo);
-    const bool hr = (q < ND) && ((int)lvR[min(q, ND - 1)] - 1 >= rloR);
-    unsigned long long bf = __ballot(hf), br = __ballot(hr);
-    if (nF + __popcll(bf) > WAVE || nR + __popcll(br) > WAVE) return false;
-    while (bf) {
-      const int b = __builtin_ctzll(bf);
-      bf &= bf - 1;
-      Q.qF = (lane == nF) ? q0 + b : Q.qF;
-      ++nF;
+  // four table entries per lane and LDS round trip (the rows are dword aligned, entries at and beyond ND are 0 = "none"); a step
+  // without a deep diagonal -- most of them: an alignment follows 1 - 20 diagonals -- costs one ballot.  The order of the list
+  // does not matter (the join takes minima over it, refRight a maximum).
+  for (int q0 = 0; q0 < ND; q0 += 4 * WAVE) {
+    const int qb = q0 + 4 * lane;
+    const uint32_t wf = *reinterpret_cast<const uint32_t*>(lvF + qb), wr = *reinterpret_cast<const uint32_t*>(lvR + qb);
+    uint32_t hf = 0u, hr = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool in = qb + i < ND;
+      hf |= (uint32_t)(in && (int)((wf >> (8 * i)) & 255u) - 1 >= rlo) << i;
+      hr |= (uint32_t)(in && (int)((wr >> (8 * i)) & 255u) - 1 >= rloR) << i;
     }
-    while (br) {
-      const int b = __builtin_ctzll(br);
-      br &= br - 1;
-      Q.qR = (lane == nR) ? q0 + b : Q.qR;
-      ++nR;
+    if (__ballot((hf | hr) != 0u) == 0ull) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned long long bf = __ballot((hf >> i) & 1u), br = __ballot((hr >> i) & 1u);
+      if (nF + __popcll(bf) > WAVE || nR + __popcll(br) > WAVE) return false;
+      while (bf) {
+        const int b = __builtin_ctzll(bf);
+        bf &= bf - 1;
+        Q.qF = (lane == nF) ? q0 + 4 * b + i : Q.qF;
+        ++nF;
+      }
+      while (br) {
+        const int b = __builtin_ctzll(br);
+        br &= br - 1;
+        Q.qR = (lane == nR) ? q0 + 4 * b + i : Q.qR;
+        ++nR;
+      }
     }
   }
   Q.nF = nF;
@@ -1477,6 +1490,44 @@ __device__ __forceinline__ int sparse_masks_counts_t(PL& L, RUNS runsF, int nF, 
   for (int o = 32; o >= 1; o >>= 1) b += __shfl_xor(b, o);
   both = b;
   __syncthreads();
+  return pos;
+}
+
+// sparse_masks_counts_t without LDS: lane w builds word w of the two masks from the run list (a run is a range of columns:
+// every lane clips it against its own 64 columns), the letter counts before a word are sums of clipped run lengths, the
+// number of columns with both letters is the total length of the 's' runs.  No barrier, no read-modify-write of LDS words,
+// no prefix scan; the result feeds split_detect's register path directly.  Alignments of at most MASKREG_COLS columns.
+template <typename RUNS>
+__device__ __forceinline__ int sparse_masks_regs(RUNS runsF, int nF, RUNS runsR, int nR, int gapref, int lane, int& posC, int& both,
+                                                 MaskRegs& M) {
+  unsigned long long mv = 0ull, mr = 0ull;
+  int cv = 0, cr = 0, pos = 0, b = 0;
+  const int base = lane * 64;
+  auto put = [&](int op, int len) {   // (op, len, pos: uniform)
+    if (len <= 0) return;
+    const int lo = min(max(pos - base, 0), 64), hi = min(max(pos + len - base, 0), 64);
+    const unsigned long long upto_hi = (hi >= 64) ? ~0ull : ((1ull << (hi & 63)) - 1ull), upto_lo = (lo >= 64) ? ~0ull : ((1ull << (lo & 63)) - 1ull);
+    const unsigned long long mk = upto_hi & ~upto_lo;
+    const int before = min(max(base - pos, 0), len);   // columns of the run that lie before this lane's word
+    if (op != 2) { mv |= mk; cv += before; }
+    if (op != 1) { mr |= mk; cr += before; }
+    if (op == 0) b += len;
+    pos += len;
+  };
+  const int xF = runsF.mine(nF - 1 - lane, nF);
+  const int xR = runsR.mine(lane, nR);
+  for (int i = 0; i < nF; ++i) {
+    const int x = (i < WAVE) ? __builtin_amdgcn_readlane(xF, i) : runsF.at(nF - 1 - i);
+    put(x >> 24, x & 0xffffff);
+  }
+  put(2, gapref);
+  posC = pos;
+  for (int i = 0; i < nR; ++i) {
+    const int x = (i < WAVE) ? __builtin_amdgcn_readlane(xR, i) : runsR.at(i);
+    put(x >> 24, x & 0xffffff);
+  }
+  both = b;
+  M.mv = mv; M.mr = mr; M.cv = cv; M.cr = cr; M.valid = true;
   return pos;
 }
 

@@ -117,6 +117,9 @@ __device__ __forceinline__ int dpp_from_next(int src, int old) {  // lane l <- l
   return __builtin_amdgcn_update_dpp(old, src, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t rfl64u(uint64_t v) {
+  return ((uint64_t)(uint32_t)rfl((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)rfl((int)(uint32_t)(v & 0xffffffffull));
+}
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ uint32_t ld_scratch(const uint32_t* p) {
   // L1-bypassing load: scratch words are re-written by this wave for every junction
@@ -523,10 +526,53 @@ __device__ __forceinline__ int select_bit(const unsigned long long* mk, const in
   return total;
 }
 
+// The same three queries with the masks in REGISTERS: lane w holds word w of the two masks and the letter counts before it
+// (alignments of fewer than 64 x 64 columns -- every short-read shape).  _findSplit on the LDS masks is a chain of dependent LDS
+// round trips (one per mask word it walks over: a 700-column deletion is eleven of them, ~130 cycles each); here a query is a
+// ballot and two v_readlane.  All arguments and results are wavefront-uniform.
+struct MaskRegs {
+  unsigned long long mv, mr;   // word `lane` of the var / ref masks (0 beyond the alignment)
+  int cv, cr;                  // var / ref letters in the columns before 64 * lane
+  bool valid;
+};
+constexpr int MASKREG_COLS = WAVE * 64 - 1;   // (position `total` itself must still name a lane)
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v & 0xffffffffull), l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int cnt_before_reg(unsigned long long mk, int cum, int pos) {
+  const int w = pos >> 6, o = pos & 63;
+  const unsigned long long x = readlane64(mk, w) & ((o == 0) ? 0ull : (~0ull >> (64 - o)));
+  return __builtin_amdgcn_readlane(cum, w) + __popcll(x);
+}
+// next position >= pos (< total) whose bit in x is set (x: one word per lane, no bits at or beyond total); total if none
+__device__ __forceinline__ int next_set_reg(unsigned long long x, int pos, int total, int lane) {
+  if (pos >= total) return total;
+  const int w = pos >> 6, o = pos & 63;
+  const unsigned long long y = (lane > w) ? x : (lane == w) ? (x & (~0ull << o)) : 0ull;
+  const unsigned long long b = __ballot(y != 0ull);
+  if (!b) return total;
+  const int l = __builtin_ctzll(b);
+  return (l << 6) + __builtin_ctzll(readlane64(y, l));
+}
+// position of the k-th (1-based) set bit, or total if fewer
+__device__ __forceinline__ int select_bit_reg(unsigned long long mk, int cum, int k, int total, int lane) {
+  const int pc = __popcll(mk);
+  const unsigned long long b = __ballot(k >= 1 && cum < k && k <= cum + pc);
+  if (!b) return total;
+  const int w = __builtin_ctzll(b);
+  unsigned long long x = readlane64(mk, w);
+  const int need = k - __builtin_amdgcn_readlane(cum, w);
+  for (int q = 1; q < need; ++q) x &= x - 1;
+  return (w << 6) + __builtin_ctzll(x);
+}
+
 // longestHomology(s1, s2, -1)  src/needle.h:13-42 (band k = 1) on strided views
 // a[i] = A[ia + i*da], b[j] = B[ib + j*db]; m, n lengths.  Uniform serial code.
-__device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da, int m, const uint8_t* B, int ib,
-                                                int db, int n) {
+// getA(i) = a[i], getB(j) = b[j]; rows 1 .. min(m, rows) are run; finished = the function's value is final
+template <typename GA, typename GB>
+__device__ __forceinline__ int longest_homology_rows(GA getA, GB getB, int m, int n, int rows, bool& finished) {
   // rolling band: prev row values at columns row-2..row (relative), cur row
   // mat[row][col] valid for |row-col| <= 1; everything else is never read.
   // prev[] indexed by h+1 (h = col-row in -1..1)
@@ -535,17 +581,18 @@ __device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da
   p0 = 0;     // mat[0][0]   (h=0 of row 0)
   pp1 = -1;   // mat[0][1]   (h=1 of row 0)
   pm1 = 0;    // unused for row 0
-  for (int row = 1; row <= m; ++row) {
+  finished = true;
+  for (int row = 1; row <= min(m, rows); ++row) {
     int best = -2;
     int cm1 = 0, c0 = 0, cp1 = 0;
     bool vm1 = false, v0 = false;
-    int ach = A[ia + (row - 1) * da];
+    int ach = getA(row - 1);
     // h = -1 : col = row-1
     {
       int col = row - 1;
       if (col >= 1 && col <= n) {
         // diag = mat[row-1][col-1] = (row-1, h=-1) -> pm1 ; for row==1,col==0 skipped
-        int v = pm1 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        int v = pm1 + ((ach == getB(col - 1)) ? 0 : -1);
         // vertical: mat[row-1][col]: row-1-col = 0 in band -> p0
         v = max(v, p0 - 1);
         // horizontal: row-col+1 = 2 > k : not allowed
@@ -561,7 +608,7 @@ __device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da
     {
       int col = row;
       if (col >= 1 && col <= n) {
-        int v = p0 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        int v = p0 + ((ach == getB(col - 1)) ? 0 : -1);
         v = max(v, pp1 - 1);                 // vertical: row-1-col = -1 in band
         if (vm1) v = max(v, cm1 - 1);        // horizontal: row-col+1 = 1 in band
         else v = max(v, 0 - 1);              // mat[row][col-1] never written: value-initialised 0
@@ -574,7 +621,7 @@ __device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da
     {
       int col = row + 1;
       if (col >= 1 && col <= n) {
-        int v = pp1 + ((ach == B[ib + (col - 1) * db]) ? 0 : -1);
+        int v = pp1 + ((ach == getB(col - 1)) ? 0 : -1);
         // vertical: row-1-col = -2 : not allowed
         if (v0) v = max(v, c0 - 1);  // horizontal: row-col+1 = 0 in band
         else v = max(v, 0 - 1);
@@ -587,7 +634,24 @@ __device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da
     p0 = c0;
     pp1 = cp1;
   }
+  finished = rows >= m;
   return 0;
+}
+// The usual junction has 0 - 3 bp of homology: the first seven rows only touch a[0 .. 6] and b[0 .. 7], which are fetched as two
+// 8-letter words (one LDS round trip instead of one per row) and walked with scalar code; longer homologies start over letter by
+// letter.  (Strings in LDS; a descending view needs its 8 letters to start inside the array.)
+template <bool LDS8 = false>   // LDS8: both strings live in LDS (sp_lds8a reads through an LDS address)
+__device__ __forceinline__ int longest_homology(const uint8_t* A, int ia, int da, int m, const uint8_t* B, int ib,
+                                                int db, int n) {
+  bool finished = false;
+  if (LDS8 && (da == 1 || ia >= 7) && (db == 1 || ib >= 7) && ia >= 0 && ib >= 0) {
+    const uint64_t pa = rfl64u((da == 1) ? sp_lds8a(A + ia) : __builtin_bswap64(sp_lds8a(A + ia - 7)));
+    const uint64_t pb = rfl64u((db == 1) ? sp_lds8a(B + ib) : __builtin_bswap64(sp_lds8a(B + ib - 7)));
+    const int h = longest_homology_rows([&](int i) { return (int)((pa >> (8 * i)) & 255u); }, [&](int j) { return (int)((pb >> (8 * j)) & 255u); },
+                                        m, n, 7, finished);
+    if (finished) return h;
+  }
+  return longest_homology_rows([&](int i) { return (int)A[ia + i * da]; }, [&](int j) { return (int)B[ib + j * db]; }, m, n, m, finished);
 }
 
 }  // namespace dh

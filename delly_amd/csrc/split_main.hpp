@@ -7,6 +7,7 @@
 // The DP passes between setup and finish are either the one-junction-per-wave passes of
 // split_kernel.hpp or the packed two-junctions-per-wave passes of split_pk.hpp.
 #pragma once
+#include <type_traits>
 #include <cstddef>
 
 #include "split_kernel.hpp"
@@ -128,17 +129,34 @@ struct JCtx {
 
 // _initBreakpoint (tags.h:151-172) + the pieces _getSVRef (split.h:70-163) concatenates.
 // Returns false for an unknown svt (_getSVRef returns "").
+// the chromosome a wavefront's previous junction lay on (uniform values): a batch is usually sorted by chromosome, and the
+// table look-up is one more dependent round trip between the junction record and the first letter of the window
+struct ChrCache {
+  int chr;
+  int len;
+  const uint8_t* seq;
+};
+
 template <bool INS>
 __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyhip_junction& J, int m, Seg (&seg)[3],
-                                                int& nseg, int& sBeg, int& sEnd, int& eBeg, int& eEnd) {
+                                                int& nseg, int& sBeg, int& sEnd, int& eBeg, int& eEnd, ChrCache* CC = nullptr) {
   const dellyhip_params& P = A.p;
   bool go = true;
   nseg = 0;
   const int boundary = m;
   const int svS = J.sv_start, svE = J.sv_end;
-  const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
-  const uint8_t* c1 = A.chr_seq[J.chr];
-  const uint8_t* c2 = A.chr_seq[J.chr2];
+  int len1, len2;
+  const uint8_t *c1, *c2;
+  if (CC && CC->chr == J.chr && J.chr2 == J.chr) {
+    len1 = len2 = CC->len;
+    c1 = c2 = CC->seq;
+  } else {
+    len1 = (int)(uint32_t)A.chr_len[J.chr];
+    len2 = (int)(uint32_t)A.chr_len[J.chr2];
+    c1 = A.chr_seq[J.chr];
+    c2 = A.chr_seq[J.chr2];
+    if (CC) { CC->chr = J.chr; CC->len = len1; CC->seq = c1; }
+  }
   if (INS) {
     // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
     const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
@@ -205,7 +223,7 @@ __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyh
 // FAST (split_sparse_kernel): quadword copies; the reverse complements assume clean letters, X.dirty tells the caller
 // when they are not (it then leaves the junction to a kernel with the exact byte-wise semantics).
 template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds, bool INS = false, bool FAST = false>
-__device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane) {
+__device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane, ChrCache* CC = nullptr) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
   X.j = j;
@@ -240,13 +258,12 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     go = false;
   }
   int dirty = 0;
+  // FAST: the consensus is fetched further down, together with the window (every load of the junction's letters in flight at
+  // once: copy loops that load, wait and store cost one memory round trip per pass -- consensus, its copy into the result
+  // slot and two or three passes over the window were five of them, most of this stage's time)
+  const bool go_cons = go;
   if (go && FAST) {
-    dirty |= copy_letters8<true>(S.cons, cons_g, m, lane);
-    if (WRITE_DEFAULTS && A.cons_base != A.out_blob) {
-      const int full = m & ~7;
-      for (int i = lane * 8; i < full; i += WAVE * 8) st8u(X.ob + i, ld8u(cons_g + i));
-      if (lane < m - full) X.ob[full + lane] = cons_g[full + lane];
-    }
+    static_assert(!FAST || STR::cons_cap <= WAVE * 8, "one quadword of the consensus per lane");
   } else if (go) {
     for (int i = lane; i < m; i += WAVE) {
       uint8_t ch = cons_g[i];
@@ -272,7 +289,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     }
   } else if (go) {
     int sBeg, sEnd, eBeg, eEnd;
-    if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
+    if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd, CC)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     // (the loops over the <= 3 segments are unrolled with constant indices: a dynamically indexed Seg array lives in
     //  scratch memory -- every lane of every wavefront stored and re-loaded it through HBM)
@@ -283,7 +300,68 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
       status = DELLYHIP_E_LIMIT;
       go = false;
     }
-    if (go) {
+    if (go && FAST) {
+      // quadword t of segment q: letters [8 lane + 512 t, + 8); the tail of a segment (len % 8 letters) one byte per lane
+      constexpr int T = (STR::ref_cap + WAVE * 8 - 1) / (WAVE * 8);
+      uint64_t wv[3][T], cv = 0;
+      uint8_t wt[3] = {0, 0, 0}, ct = 0;
+      const int cfull = m & ~7;
+      if (lane * 8 < cfull) cv = ld8u(cons_g + lane * 8);
+      if (lane < m - cfull) ct = cons_g[cfull + lane];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) wv[q][t] = 0;
+        if (q < nseg && !seg[q].rc) {
+          const uint8_t* src = seg[q].base + seg[q].beg;
+          const int full = seg[q].len & ~7;
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (lane * 8 + t * WAVE * 8 < full) wv[q][t] = ld8u(src + lane * 8 + t * WAVE * 8);
+          if (lane < seg[q].len - full) wt[q] = src[full + lane];
+        }
+      }
+      uint64_t bad = 0;
+      if (lane * 8 < cfull) {
+        bad |= not_acgtn8(cv);
+        st8u(S.cons + lane * 8, cv);
+        if (WRITE_DEFAULTS && A.cons_base != A.out_blob) st8u(X.ob + lane * 8, cv);
+      }
+      if (lane < m - cfull) {
+        bad |= comp_acgtn(ct) ? 0ull : 1ull;
+        S.cons[cfull + lane] = ct;
+        if (WRITE_DEFAULTS && A.cons_base != A.out_blob) X.ob[cfull + lane] = ct;
+      }
+      int o = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (q < nseg) {
+          const Seg sg = seg[q];
+          if (!sg.rc) {
+            const int full = sg.len & ~7;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              if (lane * 8 + t * WAVE * 8 < full) {
+                const uint64_t v = upc8(wv[q][t]);
+                bad |= not_acgtn8(v);
+                st8u(S.ref + o + lane * 8 + t * WAVE * 8, v);
+              }
+            }
+            if (lane < sg.len - full) {
+              const uint8_t c = upc(wt[q]);
+              bad |= comp_acgtn(c) ? 0ull : 1ull;
+              S.ref[o + full + lane] = c;
+            }
+          } else {   // (a reverse-complemented piece keeps letters outside A, C, G, T, N: check what was written)
+            fill_segment(S.ref + o, sg, lane);
+            DH_SYNC();
+            for (int i = lane; i < sg.len; i += WAVE) dirty |= comp_acgtn(S.ref[o + i]) ? 0 : 1;
+          }
+          o += sg.len;
+        }
+      }
+      dirty |= bad != 0ull;
+    } else if (go) {
       int o = 0;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -300,6 +378,14 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
           o += sg.len;
         }
       }
+    }
+  }
+  if (FAST && go_cons && !(go && !X.direct)) {   // (no window was fetched: alignConsensus's early exits, limits, direct mode -- the consensus alone)
+    dirty |= copy_letters8<true>(S.cons, cons_g, m, lane);
+    if (WRITE_DEFAULTS && A.cons_base != A.out_blob) {
+      const int full = m & ~7;
+      for (int i = lane * 8; i < full; i += WAVE * 8) st8u(X.ob + i, ld8u(cons_g + i));
+      if (lane < m - full) X.ob[full + lane] = cons_g[full + lane];
     }
   }
   X.n = n;
@@ -498,13 +584,20 @@ __device__ __forceinline__ void masks_finish(const SplitArgs& A, JCtx& X, STRS& 
 
 // _findSplit / _percentIdentity / _findHomology / _coordTransform / exact alleles on the column
 // masks (split.h:166-375, 596-637); writes the result record.
-template <typename STRS, typename PL>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// MID: called exactly once on every path, behind the homology stage when there is an alignment to look at (split_sparse_kernel
+// parks the answer of its work-counter atomic there: by then the round trip is over, and the register that waits for it is free
+// for the allele copies)
+template <typename STRS, typename PL, typename MID = NoHook>
 // pre_ma / pre_mm >= 0: the match / mismatch column counts are known (L.mE is not read).
 // clean_letters: consensus and window hold A, C, G, T, N only -- every alignment column then shows the letters of
 // S.cons / S.ref in their order (the output switch of needle.h:209-217 undoes the reverse complement), so the two
 // alleles are plain substrings and are copied eight letters at a time instead of column by column.
+// MR.valid: the masks in registers (sparse_masks_regs: nothing of L is read then); without it they are fetched from L once when the
+// alignment has fewer than 64 x 64 columns (MaskRegs, split_kernel.hpp), longer alignments walk the LDS masks.
 __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& S, PL& L, bool go, int Ltot,
-                                             int posC, int lane, int pre_ma = -1, int pre_mm = -1, bool clean_letters = false) {
+                                             int posC, int lane, int pre_ma = -1, int pre_mm = -1, bool clean_letters = false,
+                                             const MaskRegs MR = MaskRegs{0ull, 0ull, 0, 0, false}, MID mid = MID()) {
   const dellyhip_params& P = A.p;
   const int m = X.m, n = X.n;
   uint8_t* ob = X.ob;
@@ -515,10 +608,41 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
 #endif
   if (go) {
     const int svt = X.svt;
-    int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
-    int J0 = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
+    const bool regs = MR.valid || Ltot <= MASKREG_COLS;
+    MaskRegs M = MR;   // (by value: a MaskRegs whose address is taken lives in scratch memory)
+    if (!MR.valid && regs) {
+      const int nw = (Ltot + 63) >> 6;
+      M.mv = (lane < nw) ? L.mV[lane] : 0ull;
+      M.mr = (lane < nw) ? L.mR[lane] : 0ull;
+      M.cv = L.cumV[min(lane, nw)];
+      M.cr = L.cumR[min(lane, nw)];
+    }
     int cStart = 0, cEnd = 0, rStart = 0, rEnd = 0;
     int closedLen = 0, chosenLen = 0;
+    if (regs) {
+      const unsigned long long inside = (lane < (Ltot >> 6)) ? ~0ull : (lane == (Ltot >> 6)) ? ((1ull << (Ltot & 63)) - 1ull) : 0ull;
+      const unsigned long long bothw = M.mv & M.mr & inside, gapw = ~(M.mv & M.mr) & inside;
+      const int fv = next_set_reg(M.mv & inside, 0, Ltot, lane), fr = next_set_reg(M.mr & inside, 0, Ltot, lane);
+      int pos = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
+      while (pos < Ltot) {
+        const int a = next_set_reg(gapw, pos, Ltot, lane);    // next gap column: NOT (v & r)
+        if (a >= Ltot) break;
+        const int b1 = next_set_reg(bothw, a, Ltot, lane);    // end of the run: next non-gap column
+        if (b1 >= Ltot) break;  // trailing run: never closed, never evaluated
+        const int ra = cnt_before_reg(M.mr, M.cr, a), rb = cnt_before_reg(M.mr, M.cr, b1);
+        const int va = cnt_before_reg(M.mv, M.cv, a), vb = cnt_before_reg(M.mv, M.cv, b1);
+        const int refspan = rb - ra + 1, varspan = vb - va + 1;
+        closedLen += b1 - a;
+        const bool better = (svt == 4) ? (varspan > (cEnd - cStart)) : (refspan > (rEnd - rStart));
+        if (better) {
+          rStart = ra; rEnd = ra + refspan; cStart = va; cEnd = va + varspan;
+          chosenLen = b1 - a;
+        }
+        pos = b1 + 1;
+      }
+    } else {
+    int fv = next_set(L.mV, 0ull, 0, Ltot), fr = next_set(L.mR, 0ull, 0, Ltot);
+    int J0 = max(fv, fr);  // first column with varIndex > 0 && refIndex > 0
     int pos = J0;
     while (pos < Ltot) {
       int a = pos;  // next gap column: NOT (v & r)
@@ -547,6 +671,7 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
         chosenLen = b1 - a;
       }
       pos = b1 + 1;
+    }
     }
 #ifdef DH_SPS_FINE
     td[1] = wall_clock64();
@@ -580,12 +705,13 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
     int homLeft = 0, homRight = 0;
     if (ok) {
       // _findHomology split.h:262-280
+      constexpr bool LDSSTR = std::is_array<typename std::remove_reference<decltype(S.cons)>::type>::value;   // (StrPtr: strings in the workspace)
       if (svt == 4) {
-        homRight = longest_homology(S.cons, cStart, 1, m - cStart, S.ref, rEnd - 1, 1, n - (rEnd - 1));
-        homLeft = longest_homology(S.cons, cEnd - 2, -1, min(cEnd - 1, m), S.ref, rStart - 1, -1, min(rStart, n));
+        homRight = longest_homology<LDSSTR>(S.cons, cStart, 1, m - cStart, S.ref, rEnd - 1, 1, n - (rEnd - 1));
+        homLeft = longest_homology<LDSSTR>(S.cons, cEnd - 2, -1, min(cEnd - 1, m), S.ref, rStart - 1, -1, min(rStart, n));
       } else {
-        homRight = longest_homology(S.cons, cEnd - 1, 1, m - (cEnd - 1), S.ref, rStart, 1, n - rStart);
-        homLeft = longest_homology(S.cons, cStart - 1, -1, min(cStart, m), S.ref, rEnd - 2, -1, min(rEnd - 1, n));
+        homRight = longest_homology<LDSSTR>(S.cons, cEnd - 1, 1, m - (cEnd - 1), S.ref, rStart, 1, n - rStart);
+        homLeft = longest_homology<LDSSTR>(S.cons, cStart - 1, -1, min(cStart, m), S.ref, rEnd - 2, -1, min(rEnd - 1, n));
       }
       const int varIndex = m, refIndex = n;
       if ((homLeft + P.minimum_flank_size > cStart) || (varIndex < cEnd + homRight + P.minimum_flank_size)) ok = false;
@@ -594,6 +720,7 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
 #ifdef DH_SPS_FINE
     td[3] = wall_clock64();
 #endif
+    mid();
     if (ok) {
       // _coordTransform split.h:166-244
       uint32_t gs = 0, ge = 0;
@@ -639,12 +766,26 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
       if (final_ok) {
         // exact alleles split.h:606-624
         if ((svE - svS <= P.indelsize) && (svt == 2 || svt == 4)) {
-          int colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
-          int colB = select_bit(L.mV, L.cumV, cEnd, Ltot);
-          if (colA > colB) colA = colB;
-          int rA = cnt_before(L.mR, L.cumR, colA), rB = cnt_before(L.mR, L.cumR, colB);
-          int vA = cnt_before(L.mV, L.cumV, colA), vB = cnt_before(L.mV, L.cumV, colB);
-          int nr = rB - rA, na = vB - vA;
+          // The chosen run [a, b1) lies between two columns that carry both letters (a - 1 and b1), so the cStart-th consensus letter
+          // sits in column a - 1 and the cEnd-th in column b1: REF = ref[rStart - 1 .. rEnd - 1), ALT = cons[cStart - 1 .. cEnd - 1)
+          // without looking at the masks -- unless the run starts at the first column that has both indices > 0 (cStart or rStart 0).
+          int colA = 0, colB = 0, rA, vA, nr, na;
+          const bool direct_cut = cStart >= 1 && rStart >= 1;
+          if (direct_cut) {
+            rA = rStart - 1; vA = cStart - 1; nr = rEnd - rStart; na = cEnd - cStart;
+          } else if (regs) {
+            colA = (cStart >= 1) ? select_bit_reg(M.mv, M.cv, cStart, Ltot, lane) : Ltot;
+            colB = select_bit_reg(M.mv, M.cv, cEnd, Ltot, lane);
+            if (colA > colB) colA = colB;
+            rA = cnt_before_reg(M.mr, M.cr, colA); vA = cnt_before_reg(M.mv, M.cv, colA);
+            nr = cnt_before_reg(M.mr, M.cr, colB) - rA; na = cnt_before_reg(M.mv, M.cv, colB) - vA;
+          } else {
+            colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
+            colB = select_bit(L.mV, L.cumV, cEnd, Ltot);
+            if (colA > colB) colA = colB;
+            rA = cnt_before(L.mR, L.cumR, colA); vA = cnt_before(L.mV, L.cumV, colA);
+            nr = cnt_before(L.mR, L.cumR, colB) - rA; na = cnt_before(L.mV, L.cumV, colB) - vA;
+          }
           uint8_t* al = ob + A.out_cons_cap;
           if ((P.reserved & 4) && clean_letters && nr + na + 1 <= A.out_allele_cap) {
             // compact payload (dellyhip_params.reserved bit 2): the two alleles are plain substrings -- REF = window[rStart-1 .. rEnd-1),
@@ -661,6 +802,11 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
             if (lane == 0) al[nr] = ',';
             allele_len = nr + na + 1;
           } else if (nr + na + 1 <= A.out_allele_cap) {
+            if (direct_cut || regs) {   // (letters outside A, C, G, T, N: column by column from the LDS masks, which every caller with such letters has)
+              colA = (cStart >= 1) ? select_bit(L.mV, L.cumV, cStart, Ltot) : Ltot;
+              colB = select_bit(L.mV, L.cumV, cEnd, Ltot);
+              if (colA > colB) colA = colB;
+            }
             for (int base = colA & ~63; base < colB; base += 64) {
               int jcol = base + lane;
               int w = base >> 6;
@@ -711,6 +857,8 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
 #endif
       }
     }
+  } else {
+    mid();
   }
   DH_SYNC();
 }

@@ -44,6 +44,7 @@ struct __attribute__((aligned(16))) SpsLds {
     SpsTile t;
   } u;
   int16_t reachF[SPS_SMAX + 2], reachR[SPS_SMAX + 2];
+  int32_t next_item;   // the answer of the work-counter atomic, parked by split_detect's MID hook
 };
 
 // bytes of per-wavefront global scratch the kernel needs
@@ -52,16 +53,33 @@ __host__ __device__ inline uint64_t sps_scratch_bytes() {
   return 4ull * SPS_LIST * 4 + 2ull * (SPS_SMAX + 1) * ndp + 2ull * (SPS_SMAX + 1) * (SPS_MMAX + 1) * 4;
 }
 
-// next_raw: lane 0 receives the wavefront's NEXT work index, asked for just before the last stage of this junction (the
-// atomic's round trip then runs under split_detect; asked for any earlier, idle wavefronts at the end of a launch would find
-// the last junctions already claimed by busy ones -- measured: -15 %)
-__device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane, int& next_raw, bool& asked) {
+// Lane 0 asks the launch's counter for the wavefront's next item.  Written as atomicAdd(counter, 1) on a uniform address the
+// compiler turns the atomic into "one lane adds the number of active lanes, every lane derives its value from the result" and
+// needs that result AT ONCE (s_waitcnt vmcnt(0) right behind the atomic); and a result that stays live until the next
+// junction starts is spilled to scratch memory the moment it is defined -- again a wait for the whole round trip (1 - 3 us
+// under load) in front of split_detect instead of under it.  So: the pointer is laundered through vector registers (no
+// rewrite), the atomic is issued before the column masks are built, and split_detect's MID hook parks the answer in LDS
+// (SpsLds::next_item) a few microseconds later, which is the last use of the register.
+__device__ __forceinline__ int sps_ask_next(int32_t* counter, int lane, int keep) {
+  uintptr_t p = reinterpret_cast<uintptr_t>(counter);
+  uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+  asm volatile("" : "+v"(plo), "+v"(phi));
+  gptr_i32 q = (gptr_i32)(((uintptr_t)phi << 32) | plo);
+  int r = keep;
+  if (lane == 0) r = __hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return r;
+}
+
+// asked: the wavefront's NEXT work index has been asked for and will be in L.next_item (the atomic's round trip runs under the
+// masks and split_detect; asked for any earlier -- at the start of the junction -- idle wavefronts at the end of a launch would
+// find the last junctions already claimed by busy ones: measured, -15 %)
+__device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane, bool& asked, ChrCache& CC) {
 #ifdef DH_LR_TIMING
   const unsigned long long tq0 = wall_clock64();
 #endif
   JCtx X;
   const int prior = A.res[j].status;
-  junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
+  junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane, &CC);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
   if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
     const int st = X.out->status;
     const bool final = st == 0;
@@ -114,7 +132,9 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
   X.refRight = sr.found ? sr.refRight : 0;
   X.consRight = m - X.consLeft;
   X.go = sr.found != 0;
+  const int pending = sps_ask_next(A.work_counter, lane, 0);
   int Ltot = 0, posC = 0, pre_ma = -1, pre_mm = -1;
+  MaskRegs MR{0ull, 0ull, 0, 0, false};
   if (sr.found) {
     const int gapref = (n - sr.refRight) - sr.refLeft;
     if (A.want_alignment) {   // the alignment rows need every column's letters
@@ -123,18 +143,18 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
       masks_finish(A, X, L.s, L.u.p, Ltot, posC, lane);
     } else {
       int both = 0;
-      Ltot = sparse_masks_counts_t(L.u.p, RunsReg{sr.runF}, sr.nrunsF, RunsReg{sr.runR}, sr.nrunsR, gapref, MASKW, lane, posC, both);
+      Ltot = sparse_masks_regs(RunsReg{sr.runF}, sr.nrunsF, RunsReg{sr.runR}, sr.nrunsR, gapref, lane, posC, both, MR);   // (<= 254 + 1 280 + gap columns: one word per lane)
       pre_mm = rfl(sr.mmF + sr.mmR);
       pre_ma = rfl(both) - pre_mm;
     }
   }
   X.uniformize();
-  if (lane == 0) next_raw = atomicAdd(A.work_counter, 1);
   asked = true;
 #ifdef DH_LR_TIMING
   const unsigned long long tq3 = wall_clock64();
 #endif
-  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm, true);
+  split_detect(A, X, L.s, L.u.p, X.go, Ltot, posC, lane, pre_ma, pre_mm, true, MR,
+               [&]() { if (lane == 0) L.next_item = pending; });
 #ifdef DH_LR_TIMING
   if (lane == 0) {   // debug build: phase times in microseconds overwrite diagnostic slots of the record
     const unsigned long long tq4 = wall_clock64();
@@ -174,21 +194,23 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
   // queue up behind each other for tens of microseconds -- the following ones come from the counter (offset by the grid size)
   bool first = true, asked = false;
   int next_raw = 0;
+  ChrCache CC{-0x7fffffff, 0, nullptr};
   for (;;) {
     int w = (int)blockIdx.x;
     if (!first) {
-      if (!asked && lane == 0) next_raw = atomicAdd(A.work_counter, 1);   // (a junction that left before its last stage)
+      if (!asked) next_raw = sps_ask_next(A.work_counter, lane, next_raw);   // (a junction that left before its last stage)
+      else next_raw = L.next_item;
       w = rfl(next_raw) + (int)gridDim.x;
     }
     first = false;
     asked = false;
     if (w >= A.n_work) break;
-    const int j = A.work_list[w];
+    const int j = A.work_list ? A.work_list[w] : w;   // (no list: the batch's junctions in their order)
     // (the lane index is laundered once per junction: address arithmetic on it is then recomputed per junction instead of being
     //  hoisted out of this loop and kept -- or spilled to scratch memory -- for the whole kernel)
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    if (j >= 0 && !process_sparse(A, j, L, scratch, ln, next_raw, asked) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
+    if (j >= 0 && !process_sparse(A, j, L, scratch, ln, asked, CC) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
     __syncthreads();
   }
 }
