@@ -353,6 +353,12 @@ __device__ unsigned long long dh_dbg[16];   // profiling builds: [0] level calls
 #define DH_DBG_ADD(i, v) do { } while (0)
 #define DH_DBG_T() 0ull
 #endif
+#ifdef DH_SPS_FINE
+__shared__ unsigned long long dh_tl[6];   // debug build: wall clock at the start of a level block, after the tile is cleared, after the steps of its last level, at its end
+#define DH_TL(i) do { if (lane == 0) dh_tl[i] = wall_clock64(); } while (0)
+#else
+#define DH_TL(i) do { } while (0)
+#endif
 constexpr int SPS_OFF = 20;   // index of diagonal 0 in a byte row of the short-read tile (dword aligned; entry -1 is padding)
 
 // ---- the level loop of the short-read kernel, second formulation (round 4) ------------------------------------------------
@@ -538,11 +544,14 @@ __device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* re
   static_assert(sizeof(T.row[0][0]) % 4 == 0 && SPS_OFF % 4 == 0, "dword access to the tile rows");
   const int ND = n + m + 1;
   const unsigned long long tz0 = DH_DBG_T();
+  DH_TL(0);
   if (d0 == 0) {
-    uint32_t* z = reinterpret_cast<uint32_t*>(&T.row[0][0][0]);
-    for (int i = lane; i < (int)(sizeof(T.row) / 4); i += WAVE) z[i] = 0u;
+    static_assert(sizeof(T.row) % 16 == 0 && alignof(TILE) >= 16, "the tile is cleared sixteen bytes per lane and store");
+    uint4* z = reinterpret_cast<uint4*>(&T.row[0][0][0]);
+    for (int i = lane; i < (int)(sizeof(T.row) / 16); i += WAVE) z[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  DH_TL(1);
   DH_DBG_ADD(0, 1);
   DH_DBG_ADD(7, DH_DBG_T() - tz0);
   for (int d = d0; d <= d1; ++d) {
@@ -574,6 +583,7 @@ __device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* re
       }
     }
     const unsigned long long tl1 = DH_DBG_T();
+    DH_TL(2);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       maxB_F = max(maxB_F, __shfl_xor(maxB_F, o));
@@ -589,8 +599,12 @@ __device__ DH_SP_FN void sps_level_block(const uint8_t* consF, const uint8_t* re
     DH_DBG_ADD(3, DH_DBG_T() - tl1);
   }
   const unsigned long long tw0 = DH_DBG_T();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (levels that left the tile are read back by the traces: their stores first.  Without such a level -- every junction resolved
+  //  at S = 0, half of BASELINE's -- this would only wait for the acknowledgements of the set-up stage's stores, the record
+  //  defaults and the consensus copy: microseconds under load)
+  if (d1 >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DH_TL(3);
   DH_DBG_ADD(4, DH_DBG_T() - tw0);
 }
 
@@ -1059,16 +1073,19 @@ __device__ __forceinline__ bool sps_lists_small(const FRV& frF, const FRV& frR, 
 // One row of the join with at most nine levels in registers (needle.h:96-115): lo_[d] = first column the forward side reaches
 // with d deficits, c2_[q] = first column of the reverse side with q.  The minimal e for a d is the number of levels whose reverse
 // column is still too far right.  Written without branches: as nested ifs over per-lane data this compiled to exec-mask trees.
+// NL: the levels 0 .. SE fit NL slots (the loops are unrolled over NL, not over nine: at SE = 0 -- half of BASELINE's junctions --
+// the 81 comparisons of the general form were 80 too many)
+template <int NL>
 __device__ __forceinline__ void sps_row_best(const int (&lo_)[9], const int (&c2_)[9], int SE, int n, int r, long long& kb, int& db) {
-  int thr[9];
+  int thr[NL];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) thr[q] = (q <= SE) ? ((c2_[q] > n) ? -1 : n - c2_[q]) : SP_INF;   // level q is "too far" iff lo > thr[q]
+  for (int q = 0; q < NL; ++q) thr[q] = (q <= SE) ? ((c2_[q] > n) ? -1 : n - c2_[q]) : SP_INF;   // level q is "too far" iff lo > thr[q]
 #pragma unroll
-  for (int d = 0; d < 9; ++d) {
+  for (int d = 0; d < NL; ++d) {
     const int lo = lo_[d];
     int e = 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) e += (int)(lo > thr[q]);
+    for (int q = 0; q < NL; ++q) e += (int)(lo > thr[q]);
     const long long kk = ((long long)(d + e) << 40) | ((long long)r << 20) | (long long)lo;
     const bool take = (bool)((int)(d <= SE) & (int)(lo <= n) & (int)(e <= SE) & (int)(d + e <= SE) & (int)(kk <= kb));
     kb = take ? kk : kb;
@@ -1078,7 +1095,8 @@ __device__ __forceinline__ void sps_row_best(const int (&lo_)[9], const int (&c2
 
 // join over the rows rlo .. rhi (needle.h:96-115) from the registers of sps_lists_small: key = (total deficit << 40) | (row << 20)
 // | column of the winner (0x7fff... : none), dsel = its forward deficit.  Same arithmetic as the table version below.
-__device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, int SE, int rlo, int rhi, long long& key, int& dsel, int lane) {
+template <int NL>
+__device__ __forceinline__ void sps_join_small_t(const SpsSmall& Q, int m, int n, int SE, int rlo, int rhi, long long& key, int& dsel, int lane) {
   key = 0x7fffffffffffffffll;
   int dbest = 0;
   for (int r0 = rlo; r0 <= rhi; r0 += WAVE) {
@@ -1092,7 +1110,7 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
                      p2 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pF[2], t);
       const bool on = r + k >= 0;              // the row exists on this diagonal (k < 0: rows >= -k)
 #pragma unroll
-      for (int d = 0; d < 9; ++d) {
+      for (int d = 0; d < NL; ++d) {
         if (d <= SE) {
           const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
           lo_[d] = min(lo_[d], ((int)on & (int)(v >= r)) ? r + k : SP_INF);   // (`on && ..` came out as divergent branches)
@@ -1105,7 +1123,7 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
                      p2 = (uint32_t)__builtin_amdgcn_readlane((int)Q.pR[2], t);
       const bool on = rr + k >= 0;
 #pragma unroll
-      for (int d = 0; d < 9; ++d) {
+      for (int d = 0; d < NL; ++d) {
         if (d <= SE) {
           const int v = (int)((((d < 4) ? p0 : (d < 8) ? p1 : p2) >> (8 * (d & 3))) & 255u) - 1;
           c2_[d] = min(c2_[d], ((int)on & (int)(v >= rr)) ? rr + k : SP_INF);
@@ -1115,7 +1133,7 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
     if (r <= rhi) {
       long long kb = 0x7fffffffffffffffll;
       int db = 0;
-      sps_row_best(lo_, c2_, SE, n, r, kb, db);
+      sps_row_best<NL>(lo_, c2_, SE, n, r, kb, db);
       if (kb < key) { key = kb; dbest = db; }
     }
   }
@@ -1129,6 +1147,11 @@ __device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, 
   const unsigned long long who = __ballot(key == kmin && key != 0x7fffffffffffffffll);
   dsel = who ? __shfl(dbest, __builtin_ctzll(who)) : 0;
   key = kmin;
+}
+__device__ __forceinline__ void sps_join_small(const SpsSmall& Q, int m, int n, int SE, int rlo, int rhi, long long& key, int& dsel, int lane) {
+  if (SE <= 0) sps_join_small_t<1>(Q, m, n, SE, rlo, rhi, key, dsel, lane);
+  else if (SE <= 2) sps_join_small_t<3>(Q, m, n, SE, rlo, rhi, key, dsel, lane);
+  else sps_join_small_t<9>(Q, m, n, SE, rlo, rhi, key, dsel, lane);
 }
 
 // The whole procedure for one junction (one wavefront).  cons / ref: clean letters; rcons / rref: their reverse
@@ -1255,7 +1278,7 @@ __device__ DH_SP_FN SparseRes sparse_long_needle(const uint8_t* cons, const uint
               lo_[q] = (q <= SE) ? sp_ld32(cf + (size_t)q * (m + 1)) : SP_INF;
               c2_[q] = (q <= SE) ? sp_ld32(cr + (size_t)q * (m + 1)) : SP_INF;
             }
-            sps_row_best(lo_, c2_, SE, n, r, kb, db);
+            sps_row_best<9>(lo_, c2_, SE, n, r, kb, db);
           } else {
           // two pointers: minimal e for every d (first columns shrink with d, last allowed columns grow with e)
           int e = SE + 1;

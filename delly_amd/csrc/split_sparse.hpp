@@ -73,13 +73,13 @@ __device__ __forceinline__ int sps_ask_next(int32_t* counter, int lane, int keep
 // asked: the wavefront's NEXT work index has been asked for and will be in L.next_item (the atomic's round trip runs under the
 // masks and split_detect; asked for any earlier -- at the start of the junction -- idle wavefronts at the end of a launch would
 // find the last junctions already claimed by busy ones: measured, -15 %)
-__device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane, bool& asked, ChrCache& CC) {
+__device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds& L, uint32_t* scratch, int lane, bool& asked) {
 #ifdef DH_LR_TIMING
   const unsigned long long tq0 = wall_clock64();
 #endif
   JCtx X;
   const int prior = A.res[j].status;
-  junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane, &CC);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
+  junction_setup<KMAX, true, StrLdsS, false, true>(A, j, L.s, X, lane);   // (the host only lists junctions within StrLdsS: no E_LIMIT from here)
   if (!X.go) {   // alignConsensus's early exits (src/split.h:647), unknown svt, limits: the record is final
     const int st = X.out->status;
     const bool final = st == 0;
@@ -132,7 +132,6 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
   X.refRight = sr.found ? sr.refRight : 0;
   X.consRight = m - X.consLeft;
   X.go = sr.found != 0;
-  const int pending = sps_ask_next(A.work_counter, lane, 0);
   int Ltot = 0, posC = 0, pre_ma = -1, pre_mm = -1;
   MaskRegs MR{0ull, 0ull, 0, 0, false};
   if (sr.found) {
@@ -149,6 +148,7 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
     }
   }
   X.uniformize();
+  const int pending = sps_ask_next(A.work_counter, lane, 0);   // (behind the masks: in front of them the compiler waits for it at once, tools/sps_atomic_wait.py)
   asked = true;
 #ifdef DH_LR_TIMING
   const unsigned long long tq3 = wall_clock64();
@@ -176,6 +176,12 @@ __device__ __forceinline__ bool process_sparse(const SplitArgs& A, int j, SpsLds
       X.out->matches = (int)((tq3 - tq2) / 10);
       X.out->mismatches = (int)((tq4 - tq3) / 10);
     }
+    // the LAST level block of the junction: before it | clearing the tile | the steps (of its last level) | reductions + end | behind it
+    X.out->sr_support = (int)((dh_tl[0] - tq1) / 10);
+    X.out->hom_len = (int)((dh_tl[1] - dh_tl[0]) / 10);
+    X.out->ci_wiggle = (int)((dh_tl[2] - dh_tl[1]) / 10);
+    X.out->cons_bp = (int)((dh_tl[3] - dh_tl[2]) / 10);
+    X.out->ins_len = (int)((sr.t[0] - dh_tl[3]) / 10);
 #endif
   }
 #endif
@@ -194,7 +200,6 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
   // queue up behind each other for tens of microseconds -- the following ones come from the counter (offset by the grid size)
   bool first = true, asked = false;
   int next_raw = 0;
-  ChrCache CC{-0x7fffffff, 0, nullptr};
   for (;;) {
     int w = (int)blockIdx.x;
     if (!first) {
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(WAVE, DH_SPARSE_WAVES) void split_sparse_kernel(Spl
     //  hoisted out of this loop and kept -- or spilled to scratch memory -- for the whole kernel)
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    if (j >= 0 && !process_sparse(A, j, L, scratch, ln, asked, CC) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
+    if (j >= 0 && !process_sparse(A, j, L, scratch, ln, asked) && lane == 0 && A.sps_left) atomicAdd(A.sps_left, 1);
     __syncthreads();
   }
 }

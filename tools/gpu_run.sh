@@ -7,7 +7,8 @@
 #   lrpmc      instruction-cache / SQ / L2 counters of lrwfa_kernel and lrmsa_kernel at the small and the chip-filling batch
 #   bench      the default bench line (+ the driver's view of it)
 #   stats      rocprofv3 --kernel-trace --stats of the headline and of the side rows
-#   traffic    FETCH_SIZE / WRITE_SIZE of the headline's kernels -> pmc_traffic.json (stamped with the kernel sources' hash)
+#   traffic    (run `sq` BEFORE it in the same call: the summary takes SQ_INSTS_VALU from that pass)
+#              FETCH_SIZE / WRITE_SIZE of the headline's kernels -> pmc_traffic.json (stamped with the kernel sources' hash)
 #   sq         SQ instruction counters (tools/pmc_sq.sh), headline and side rows
 #   wait       SQ wait counters of split_sparse_kernel and msa_kernel (tools/pmc_wait.sh)
 #   pytest     the whole GPU suite; PYTEST_ARGS narrows it
