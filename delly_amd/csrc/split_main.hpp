@@ -770,7 +770,11 @@ __device__ __forceinline__ void split_detect(const SplitArgs& A, JCtx& X, STRS& 
           // sits in column a - 1 and the cEnd-th in column b1: REF = ref[rStart - 1 .. rEnd - 1), ALT = cons[cStart - 1 .. cEnd - 1)
           // without looking at the masks -- unless the run starts at the first column that has both indices > 0 (cStart or rStart 0).
           int colA = 0, colB = 0, rA, vA, nr, na;
+#ifdef DH_NO_DIRECT_CUT   // (verification builds: every junction locates its alleles on the masks, as the rare cStart / rStart == 0 ones do)
+          const bool direct_cut = false;
+#else
           const bool direct_cut = cStart >= 1 && rStart >= 1;
+#endif
           if (direct_cut) {
             rA = rStart - 1; vA = cStart - 1; nr = rEnd - rStart; na = cEnd - cStart;
           } else if (regs) {
