@@ -41,9 +41,15 @@ HEADLINE_KERNEL_SOURCES = ("sparse_needle.hpp", "split_sparse.hpp", "split_main.
 
 
 def headline_kernel_hash():
+    """hash of the CODE of the headline kernel's sources: `//` comments, trailing blanks and empty lines do not count (a stamp
+    that a reworded comment invalidates costs a GPU pass to renew)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in HEADLINE_KERNEL_SOURCES:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(CSRC, f), "r", encoding="utf-8", errors="replace") as fh:
+            for ln in fh:
+                ln = re.sub(r"//.*$", "", ln).rstrip()
+                if ln:
+                    h.update(ln.encode("utf-8") + b"\n")
     return h.hexdigest()[:16]

@@ -129,34 +129,17 @@ struct JCtx {
 
 // _initBreakpoint (tags.h:151-172) + the pieces _getSVRef (split.h:70-163) concatenates.
 // Returns false for an unknown svt (_getSVRef returns "").
-// the chromosome a wavefront's previous junction lay on (uniform values): a batch is usually sorted by chromosome, and the
-// table look-up is one more dependent round trip between the junction record and the first letter of the window
-struct ChrCache {
-  int chr;
-  int len;
-  const uint8_t* seq;
-};
-
 template <bool INS>
 __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyhip_junction& J, int m, Seg (&seg)[3],
-                                                int& nseg, int& sBeg, int& sEnd, int& eBeg, int& eEnd, ChrCache* CC = nullptr) {
+                                                int& nseg, int& sBeg, int& sEnd, int& eBeg, int& eEnd) {
   const dellyhip_params& P = A.p;
   bool go = true;
   nseg = 0;
   const int boundary = m;
   const int svS = J.sv_start, svE = J.sv_end;
-  int len1, len2;
-  const uint8_t *c1, *c2;
-  if (CC && CC->chr == J.chr && J.chr2 == J.chr) {
-    len1 = len2 = CC->len;
-    c1 = c2 = CC->seq;
-  } else {
-    len1 = (int)(uint32_t)A.chr_len[J.chr];
-    len2 = (int)(uint32_t)A.chr_len[J.chr2];
-    c1 = A.chr_seq[J.chr];
-    c2 = A.chr_seq[J.chr2];
-    if (CC) { CC->chr = J.chr; CC->len = len1; CC->seq = c1; }
-  }
+  const int len1 = (int)(uint32_t)A.chr_len[J.chr], len2 = (int)(uint32_t)A.chr_len[J.chr2];
+  const uint8_t* c1 = A.chr_seq[J.chr];
+  const uint8_t* c2 = A.chr_seq[J.chr2];
   if (INS) {
     // split.h:650-652: bufferSpace in size_t arithmetic, then (int32_t); tags.h:153-157; split.h:122
     const int bs = max((int)(int32_t)(((uint64_t)(int64_t)m - (uint64_t)(int64_t)J.ins_len) / 3ull), P.minimum_flank_size);
@@ -223,7 +206,7 @@ __device__ __forceinline__ bool window_segments(const SplitArgs& A, const dellyh
 // FAST (split_sparse_kernel): quadword copies; the reverse complements assume clean letters, X.dirty tells the caller
 // when they are not (it then leaves the junction to a kernel with the exact byte-wise semantics).
 template <int K, bool WRITE_DEFAULTS = true, typename STR = StrLds, bool INS = false, bool FAST = false>
-__device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane, ChrCache* CC = nullptr) {
+__device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S, JCtx& X, int lane) {
   const dellyhip_junction J = A.junc[j];
   const dellyhip_params& P = A.p;
   X.j = j;
@@ -289,7 +272,7 @@ __device__ __forceinline__ void junction_setup(const SplitArgs& A, int j, STR& S
     }
   } else if (go) {
     int sBeg, sEnd, eBeg, eEnd;
-    if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd, CC)) go = false;
+    if (!window_segments<INS>(A, J, m, seg, nseg, sBeg, sEnd, eBeg, eEnd)) go = false;
     X.sBeg = sBeg; X.sEnd = sEnd; X.eBeg = eBeg; X.eEnd = eEnd;
     // (the loops over the <= 3 segments are unrolled with constant indices: a dynamically indexed Seg array lives in
     //  scratch memory -- every lane of every wavefront stored and re-loaded it through HBM)

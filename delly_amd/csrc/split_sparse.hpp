@@ -58,7 +58,8 @@ __host__ __device__ inline uint64_t sps_scratch_bytes() {
 // needs that result AT ONCE (s_waitcnt vmcnt(0) right behind the atomic); and a result that stays live until the next
 // junction starts is spilled to scratch memory the moment it is defined -- again a wait for the whole round trip (1 - 3 us
 // under load) in front of split_detect instead of under it.  So: the pointer is laundered through vector registers (no
-// rewrite), the atomic is issued before the column masks are built, and split_detect's MID hook parks the answer in LDS
+// rewrite), the atomic is issued behind the column masks (in front of them the wait lands in a loop preheader: tools/
+// sps_atomic_wait.py), and split_detect's MID hook parks the answer in LDS
 // (SpsLds::next_item) a few microseconds later, which is the last use of the register.
 __device__ __forceinline__ int sps_ask_next(int32_t* counter, int lane, int keep) {
   uintptr_t p = reinterpret_cast<uintptr_t>(counter);
