@@ -83,3 +83,24 @@ def test_an_n_gt_1_line_starts_with_what_the_return_paths_cost():
               "shm_return_records_seen_by_rank0", "host_inclusive_alignments_per_s"):
         assert k[:40] in kept, k
     assert list(kept)[0] == "workload" and list(kept)[1] == "value_is" and list(kept)[2] == "value_return_path"
+
+
+def test_traffic_stamp_follows_the_code_not_the_comments(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC pass that carries the hash of the headline kernel's sources
+    (delly_amd/build.py: headline_kernel_hash); `traffic_stale` must flip when the code changes and must NOT when a comment
+    does (renewing the stamp costs a GPU pass) -- and the stamp committed with this tree must be the tree's."""
+    import shutil
+    from delly_amd import build
+    here = build.headline_kernel_hash()
+    t = bench._measured_traffic()
+    assert t["traffic"] and t["stale"] is False, "profiles/rNN/pmc_traffic.json was collected on other kernel sources: %r" % (t,)
+    for f in build.HEADLINE_KERNEL_SOURCES:
+        shutil.copy(os.path.join(build.CSRC, f), tmp_path / f)
+    monkeypatch.setattr(build, "CSRC", str(tmp_path))
+    assert build.headline_kernel_hash() == here
+    p = tmp_path / build.HEADLINE_KERNEL_SOURCES[0]
+    src = p.read_text()
+    p.write_text("// a reworded remark\n\n" + src.replace("\n", "   // trailing remark\n", 1))
+    assert build.headline_kernel_hash() == here
+    p.write_text(src + "\nnamespace dh { constexpr int dh_probe_of_the_stamp = 1; }\n")
+    assert build.headline_kernel_hash() != here
