@@ -31,6 +31,7 @@ Rank 0 prints ONE JSON line (contract in the task description) with the
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -418,15 +419,35 @@ def side_measurements(ctx, synth, device=0, steps=3, with_cpu=True, only=None):
         ctx.set_chromosomes(b.chroms)
         rb = ctx.upload(b)
         rb.run(); rb.sync(); rb.kernel_ms()
-        t0 = time.perf_counter()
-        for _ in range(row_steps):
+        def region(k):   # k steps behind one another, one wait: (seconds per step, ms the first enqueue took)
+            t0 = time.perf_counter()
             rb.run()
-        rb.sync()
-        dt = (time.perf_counter() - t0) / row_steps
+            t1 = time.perf_counter()
+            for _ in range(k - 1):
+                rb.run()
+            rb.sync()
+            return (time.perf_counter() - t0) / k, (t1 - t0) * 1e3
+        # A side row is the MEDIAN of three regions: a region that follows the tear-down of another row's pipelined stream can
+        # lose 0.4 - 25 ms -- the first enqueue behind a sync returns late and the GPU finishes late, with the old library as
+        # with the new one, and none of it inside dellyhip_batch_run's own clock (BENCH_ROW_DEBUG; CHANGELOG round 6, the same
+        # family as VERDICT r05 #7's "0.5 ms per step a five-slot stream leaves behind").  Regions shorter than ~25 ms are
+        # stretched to ~50 ms of steps so that what is left of such a delay does not carry weight.
+        regs = [region(row_steps)]
+        if regs[0][0] * row_steps < 0.025 and not kw.get("_steps"):
+            row_steps = int(min(200, max(row_steps, round(0.05 / max(regs[0][0], 1e-5)))))
+            rb.kernel_ms()
+            regs = [region(row_steps)]
+        regs += [region(row_steps) for _ in range(2)]
+        dt = sorted(r[0] for r in regs)[1]
+        first_enqueue_ms = max(r[1] for r in regs)
+        if os.environ.get("BENCH_ROW_DEBUG"):
+            print("row %s: %d steps per region; ms per step %s; first enqueue ms %s" % (name, row_steps, ["%.3f" % (r[0] * 1e3) for r in regs], ["%.3f" % r[1] for r in regs]),
+                  file=sys.stderr, flush=True)
         ms_split, ms_msa, _ = rb.kernel_ms()
         res, _ = rb.fetch()
         out[name] = {"junctions": n, "junctions_per_s": n / dt, "ms_per_step": dt * 1e3, "msa_stage_ms": ms_msa,
-                     "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum()), "steps": row_steps}
+                     "split_stage_ms": ms_split, "refined_ok": int(res["ok"].sum()), "steps": row_steps,
+                     "regions_ms_per_step": [r[0] * 1e3 for r in regs], "first_enqueue_ms_max": first_enqueue_ms}
         if b.with_msa == 1:   # short-read msa(): how many junctions left the score-table kernel (CHANGELOG.md 4)
             try:
                 ms = rb.msa_stats()

@@ -281,6 +281,7 @@ struct dellyhip_ctx {
   hipEvent_t serial_ev = nullptr;  // end of the last batch_run: runs of one context share its scratch area, so a run on
                                    // another stream first waits for it (overlap batches with one context per stream)
   bool serial_valid = false;
+  hipStream_t serial_stream = nullptr;   // the stream serial_ev was recorded on
   int msa_tmax = dh::TMAXC;  // column types per MSA node served by the score table (env DELLYHIP_MSA_TMAX)
   int wfa_lds_seed = 1;      // msaWfa's diagonal seeding in its own kernel with the k-mer table in LDS (wfa_seed_kernel; env DELLYHIP_WFA_LDS_SEED=0: inside wfa_pairs_kernel, tables in HBM)
   int myers_band = 1;        // banded bit-vector distances, several pairs per wavefront (myers_band.hpp; env DELLYHIP_MYERS_BAND=0: the full passes)
@@ -331,6 +332,7 @@ struct dellyhip_batch {
   std::vector<int32_t> bin_first, bin_count;  // per K = 1..KMAX
   int ins_first = 0, ins_count = 0;  // svt 4 junctions (insertion kernel): work[ins_first .. +ins_count)
   bool sps_all = false;              // every junction of the dense bins is in the sparse list too
+  bool zero_res_pending = false;     // the records are to be zeroed before the split kernels of this run (a re-run without an MSA stage)
   bool sps_identity = false;         // the sparse list is 0, 1, 2, ...: the kernel is launched without it (one dependent load less per junction)
   // msa() batches: the sparse kernel runs on every non-insertion junction straight behind the MSA kernels (it reads the
   // consensus lengths on the device) while the host routes the batch from the downloaded lengths
@@ -545,6 +547,27 @@ int launch_early_sparse(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s) {
   return 0;
 }
 
+// Two regions zeroed by ONE kernel launch.  hipMemsetAsync is a fill kernel behind a slower submission path: in the kernel trace of
+// the headline arrangement each of the two memsets of a step (the batch's records on a re-run, the work counters) sat behind a
+// gap of 16 / 6 us, 31 us of a stream's 330 us cycle with the fills themselves -- a kernel of this library follows its
+// predecessor without a gap.
+__global__ __launch_bounds__(256) void zero2_kernel(uint4* a, size_t na16, uint32_t* b, int nb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t k = i; k < na16; k += (size_t)gridDim.x * blockDim.x) a[k] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < (size_t)nb) b[i] = 0u;
+}
+static int launch_zero2(hipStream_t s, void* a, size_t a_bytes, void* b, int b_words) {
+  if (a_bytes % 16 || (reinterpret_cast<uintptr_t>(a) & 15)) {   // (never the case for the record array: 144-byte records in a hipMalloc block)
+    HIPCHK(hipMemsetAsync(a, 0, a_bytes, s));
+    a_bytes = 0;
+  }
+  const size_t na16 = a_bytes / 16;
+  const int blocks = (int)std::min<size_t>(std::max<size_t>((std::max<size_t>(na16, (size_t)b_words) + 255) / 256, 1), 2048);
+  hipLaunchKernelGGL(zero2_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(a), na16, reinterpret_cast<uint32_t*>(b), b_words);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Launches the split-alignment kernels for every K bin of the batch.
 int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   int rc;
@@ -552,7 +575,11 @@ int run_split(dellyhip_ctx* c, dellyhip_batch* b, hipStream_t s, bool direct) {
   if ((rc = ensure_scratch(c))) return rc;
   const bool early = b->early_done;   // (slots 30 / 31 of the counters belong to the kernel that already ran)
   b->early_done = false;
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, (early ? 30 : 32) * sizeof(int32_t), s));
+  {   // the work counters, and -- on a re-run without an MSA stage -- the batch's records (dellyhip_batch_run)
+    const bool zr = b->zero_res_pending;
+    b->zero_res_pending = false;
+    if ((rc = launch_zero2(s, zr ? (void*)b->res.p : nullptr, zr ? (size_t)b->n * sizeof(dellyhip_result) : 0, c->counters.p, early ? 30 : 32))) return rc;
+  }
   dh::SplitArgs a = make_split_args(c, b, direct);
   bool mid_done = false;
   if (early) {   // every junction of the dense bins was offered to the sparse kernel
@@ -1666,7 +1693,7 @@ void dellyhip_batch_free(dellyhip_ctx* c, dellyhip_batch* b) {
   if (b->lr_join) (void)hipEventDestroy(b->lr_join);
   if (b->lri_fork) (void)hipEventDestroy(b->lri_fork);
   if (b->lri_join) (void)hipEventDestroy(b->lri_join);
-  for (auto e : b->ev) (void)hipEventDestroy(e);
+  for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
   for (auto e : b->ev_free) (void)hipEventDestroy(e);
   if (b->len_ev) (void)hipEventDestroy(b->len_ev);
   delete b;
@@ -1995,29 +2022,51 @@ int dellyhip_batch_upload(dellyhip_ctx* c, int32_t n, const dellyhip_junction* j
   return rc;
 }
 
+static inline double now_s();
 int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
   if (!c || !b) return fail(DELLYHIP_E_ARG, "null argument");
+  // DELLYHIP_TRACE_RUN=1: a run that keeps the calling thread longer than 0.2 ms says where (stderr); =2: every run.  (Round 6 used it to
+  // show that the late first enqueue behind a sync -- CHANGELOG round 6 -- is not spent in here.)
+  static const bool trace_run = getenv("DELLYHIP_TRACE_RUN") != nullptr;
+  const double tr0 = trace_run ? now_s() : 0;
   HIPCHK(hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   if (b->n == 0) return 0;
+  double tr1 = 0, tr2 = 0, tr3 = 0;
+  struct TraceRun { bool on; double t0; double *a, *b_, *c_; ~TraceRun() { if (on) { double e = now_s(); if (e - t0 > 2e-4 || getenv("DELLYHIP_TRACE_RUN")[0] == '2') fprintf(stderr, "batch_run: %.3f ms on the host (events %.3f, serialisation %.3f, up to the split stage %.3f)\n", (e - t0) * 1e3, (*a - t0) * 1e3, (*b_ - *a) * 1e3, (*c_ - *b_) * 1e3); } } } trace_guard{trace_run, tr0, &tr1, &tr2, &tr3};
   // a fetch begun and not ended reads the results this run overwrites: same stream -> ordered already
   if (b->fetch_pending && b->fetch_ev && b->fetch_stream != s) HIPCHK(hipStreamWaitEvent(s, b->fetch_ev, 0));
   b->run_stream = s;
   int rc;
   hipEvent_t e3[4];
   bool ev1_done = false;
+  // Every event recorded on the stream is a barrier packet the next kernel sits behind for 5 - 7 us (kernel trace of the headline
+  // arrangement: 21 us between the last kernel of a step and the first of the next, four records).  A run records what its
+  // timing needs and nothing else: start of the MSA stage only when there is one (slot 0 stays empty), start of the split stage,
+  // end of the sparse kernel, end of the run; the context's serialisation event is recorded when a run on ANOTHER stream has to
+  // wait for this one, not after every run.
   for (int q = 0; q < 4; ++q) {
+    if (q == 0 && !b->with_msa) { e3[q] = nullptr; b->ev.push_back(nullptr); continue; }
     if (!b->ev_free.empty()) { e3[q] = b->ev_free.back(); b->ev_free.pop_back(); }
     else HIPCHK(hipEventCreate(&e3[q]));
     b->ev.push_back(e3[q]);
   }
   b->mid = e3[3];
-  if (!c->serial_ev) HIPCHK(hipEventCreateWithFlags(&c->serial_ev, hipEventDisableTiming));
-  if (c->serial_valid) HIPCHK(hipStreamWaitEvent(s, c->serial_ev, 0));
-  HIPCHK(hipEventRecord(e3[0], s));
+  if (trace_run) tr1 = now_s();
+  if (c->serial_valid && c->serial_stream != s) {   // (same stream: ordered already)
+    if (!c->serial_ev) HIPCHK(hipEventCreateWithFlags(&c->serial_ev, hipEventDisableTiming));
+    if (hipEventRecord(c->serial_ev, c->serial_stream) == hipSuccess) {
+      HIPCHK(hipStreamWaitEvent(s, c->serial_ev, 0));
+    } else {   // (the caller's stream of the previous run is gone)
+      (void)hipGetLastError();
+      HIPCHK(hipDeviceSynchronize());
+    }
+  }
+  if (trace_run) tr2 = now_s();
+  if (e3[0]) HIPCHK(hipEventRecord(e3[0], s));
   // with_msa == 0: junction_setup treats res[j].status / sr_support as input from an MSA stage; without one they
   // must be zero on EVERY run, or a junction flagged in run 1 takes the "prior status" branch in run 2
-  if (!b->with_msa && b->ever_run) HIPCHK(hipMemsetAsync(b->res.p, 0, (size_t)b->n * sizeof(dellyhip_result), s));   // (the upload zeroed them for the first run)
+  if (!b->with_msa && b->ever_run) b->zero_res_pending = true;   // (the upload zeroed them for the first run; run_split zeroes them together with its counters: launch_zero2)
   if (b->with_msa == 2) {
     // msaEdlib (src/assemble.h:383-473): all-pairs bit-vector distances, then one wavefront per junction
     if (b->lm_items > 0) {
@@ -2145,8 +2194,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
       HIPCHK(hipEventRecord(e3[1], s));
       HIPCHK(hipEventRecord(e3[3], s));
       HIPCHK(hipEventRecord(e3[2], s));
-      HIPCHK(hipEventRecord(c->serial_ev, s));
       c->serial_valid = true;
+      c->serial_stream = s;
       b->last = e3[2];
       b->pending = true;
       b->launches++;
@@ -2182,6 +2231,7 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     if (!b->lazy && (rc = route_after_msa(c, b))) return rc;   // (a consensus beyond 319 bp goes to the strip kernel)
   }
   if (!ev1_done) HIPCHK(hipEventRecord(e3[1], s));
+  if (trace_run) tr3 = now_s();
   if (!(b->lazy && b->with_msa == 1) && (rc = run_split(c, b, s, b->ref_blob.p != nullptr))) return rc;
   b->lazy_pending = b->lazy != 0;
   if (b->with_msa == 2 && b->small_inv_n > 0) {
@@ -2189,8 +2239,8 @@ int dellyhip_batch_run(dellyhip_ctx* c, dellyhip_batch* b, void* stream) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipEventRecord(e3[2], s));
-  HIPCHK(hipEventRecord(c->serial_ev, s));
   c->serial_valid = true;
+  c->serial_stream = s;
   b->last = e3[2];
   b->pending = true;
   b->lr_failed = false;
@@ -2214,14 +2264,14 @@ int dellyhip_batch_sync(dellyhip_ctx* c, dellyhip_batch* b) {
   HIPCHK(hipEventSynchronize(b->last));
   for (size_t q = 0; q + 3 < b->ev.size(); q += 4) {
     float a = 0, d = 0, e = 0;
-    HIPCHK(hipEventElapsedTime(&a, b->ev[q], b->ev[q + 1]));
+    if (b->ev[q]) HIPCHK(hipEventElapsedTime(&a, b->ev[q], b->ev[q + 1]));   // (no MSA stage: no start event)
     HIPCHK(hipEventElapsedTime(&d, b->ev[q + 1], b->ev[q + 2]));
     HIPCHK(hipEventElapsedTime(&e, b->ev[q + 1], b->ev[q + 3]));
     b->ms_msa += a;
     b->ms_split += d;
     b->ms_dp += e;
   }
-  for (auto e : b->ev) b->ev_free.push_back(e);
+  for (auto e : b->ev) if (e) b->ev_free.push_back(e);
   b->ev.clear();
   b->pending = false;
   hipError_t e = hipGetLastError();
