@@ -71,6 +71,31 @@ def test_headline_arrangement_two_launches_in_flight_gives_the_same_records(gpu_
     other.close()
 
 
+def test_one_context_on_alternating_streams_serialises_its_runs(gpu_ctx):
+    """Runs of ONE context share its scratch area and work counters, so a run on another stream than the previous one has to wait
+    for it: the context records its serialisation event on the previous run's stream only then (not after every run -- an event
+    record is 5 - 7 us of stream time).  Three batches, short and long ones mixed, alternate between the two compute streams without
+    host waits; every batch must come out as it does alone."""
+    # (2 % substitutions: every junction needs several deficit levels, whose tables pass through the wavefront's scratch area.  The
+    #  test exercises the record-then-wait path; it does not PROVE the serialisation -- a build that never waits passed it too on the
+    #  one box it was tried on: the second launch's workgroups only start as the first one's leave, and rarely next to their namesakes)
+    raw = [synth.make_batch(n, mode="c2", first=k * 10000, seed=40 + k, sub_rate=0.02) for k, n in enumerate((6000, 300, 9000))]
+    chroms, batches = bench.one_genome(synth, raw)
+    gpu_ctx.set_chromosomes(chroms)
+    alone = [gpu_ctx.refine(b) for b in batches]
+    streams = gpu_ctx.compute_streams()
+    rbs = [gpu_ctx.upload(b) for b in batches]
+    order = [0, 1, 2, 1, 0, 2, 2, 1, 0]
+    for i, k in enumerate(order):
+        rbs[k].run(streams[i % 2])
+    for k, rb in enumerate(rbs):
+        rb.sync()
+        r, bl = rb.fetch()
+        assert all((r[f] == alone[k][0][f]).all() for f in r.dtype.names), "batch %d" % k
+        assert bl.tobytes() == alone[k][1].tobytes()
+        rb.free()
+
+
 @pytest.mark.parametrize("name", [x[0] for x in bench.SWEEP_PLAN])
 def test_deficit_sweep_batches_vs_reference(gpu_ctx, reference, name):
     kw = [x[1] for x in bench.SWEEP_PLAN if x[0] == name][0]
